@@ -1,0 +1,87 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference) on the
+seeded cases of oracle/cases.py.  Build-container only; the fixtures are committed so that the GPU
+box (no /root/reference) can check both the oracle and the HIP path against reference outputs.
+
+    python -m oracle.make_golden [case ...]        # from the repo root
+
+What is stored per case (all produced by the reference model, eval mode, CPU fp32, torch 2.10):
+  sample: seq i64[B,L], seqLogprobs f32[B,L], att_idx i16[B,L,T] (main.py:364-365 per-frame argmax),
+          att2_weights f32[B,L,R] (only B<=4), sim_sub f32[B,D1,11] (every 97th region of sim_mat)
+  MLE:    losses f32[4] (lm, att2, ground, cls); for B<=8 also grad_norms (per-parameter L2 norm of the
+          gradient of lm + w_att2*att2 + w_grd*ground + w_cls*cls, cases.GRAD_WEIGHTS)
+  GRD:    cls_pred i64[N,2], att2_ind i16[B,Lc,T], grd_ind i16[B,Lc,T]
+plus weight/input fingerprints (float64 checksums) so a consumer can prove it regenerated the
+identical weights and inputs from the seeds.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import cases, ref_harness  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+
+def run_case(name):
+    import importlib
+    pkg = importlib.import_module('grounded-video-description_amd')
+    spec = cases.CASES[name]
+    opt, sd, inp = cases.build_case(name)
+    need_grad = spec['mode'] == 'MLE' and spec['B'] <= 8
+    ref = ref_harness.build_reference_model(opt, sd, need_grad=need_grad).eval()
+    args = pkg.synth.as_args(inp)
+    out = dict(weight_fp=np.float64(cases.weight_fingerprint(sd)),
+               input_fp=np.float64(cases.input_fingerprint(inp)),
+               torch_version=np.array(torch.__version__))
+    t0 = time.time()
+    if spec['mode'] == 'sample':
+        with torch.no_grad():
+            seq, lps, att2, sim = ref._sample(inp['segs_feat'], inp['ppls'], inp['num'], inp['ppls_feat'],
+                                              inp['sample_idx'], inp['pnt_mask'],
+                                              {'sample_max': 1, 'beam_size': 1})
+        B, L = seq.shape
+        idx = att2.view(B, L, opt.num_sampled_frm, opt.num_prop_per_frm).max(dim=-1)[1]
+        out.update(seq=seq.numpy(), seqLogprobs=lps.numpy(), att_idx=idx.numpy().astype(np.int16),
+                   sim_sub=sim[:, :, ::97].contiguous().numpy())
+        if B <= 4:
+            out['att2_weights'] = att2.numpy()
+    elif spec['mode'] == 'MLE':
+        if need_grad:
+            lm, a2, gl, cl = ref(*args, 'MLE')
+            w = cases.GRAD_WEIGHTS
+            loss = lm.sum() + w['w_att2'] * a2.sum() + w['w_grd'] * gl.sum() + w['w_cls'] * cl.sum()
+            ref.zero_grad()
+            loss.backward()
+            names, norms = [], []
+            for n, p in ref.named_parameters():
+                if p.grad is not None:
+                    names.append(n)
+                    norms.append(float(p.grad.double().norm()))
+            out.update(grad_names=np.array(names), grad_norms=np.array(norms, dtype=np.float64))
+        else:
+            with torch.no_grad():
+                lm, a2, gl, cl = ref(*args, 'MLE')
+        out['losses'] = np.array([lm.item(), a2.item(), gl.item(), cl.item()], dtype=np.float32)
+    elif spec['mode'] == 'GRD':
+        with torch.no_grad():
+            cp, ai, gi = ref(*args, 'GRD')
+        out.update(cls_pred=cp.numpy(), att2_ind=ai.numpy().astype(np.int16), grd_ind=gi.numpy().astype(np.int16))
+    else:
+        raise ValueError(spec['mode'])
+    out['ref_seconds'] = np.float64(time.time() - t0)
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, name + '.npz'), **out)
+    print('%-40s %6.1fs  %s' % (name, time.time() - t0,
+                                {k: (v.shape if hasattr(v, 'shape') else v) for k, v in out.items()
+                                 if k in ('seq', 'losses', 'cls_pred')}))
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(os.cpu_count())
+    todo = sys.argv[1:] or list(cases.CASES)
+    for n in todo:
+        run_case(n)

@@ -1,0 +1,118 @@
+"""The CPU oracle (oracle/gvd_oracle.py) against the committed reference outputs (tests/golden/,
+produced by oracle/make_golden.py from the real /root/reference model).  Runs anywhere (no GPU, no
+reference tree): this is the pin that travels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gvd_amd  # noqa: F401
+from oracle import cases, gvd_oracle as O
+
+SAMPLE = [n for n, s in cases.CASES.items() if s['mode'] == 'sample']
+MLE = [n for n, s in cases.CASES.items() if s['mode'] == 'MLE']
+GRD = [n for n, s in cases.CASES.items() if s['mode'] == 'GRD']
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def _build(name, g):
+    opt, sd, inp = cases.build_case(name)
+    # identical weights/inputs as the box that generated the fixture
+    assert cases.weight_fingerprint(sd) == float(g['weight_fp'])
+    assert cases.input_fingerprint(inp) == float(g['input_fp'])
+    return opt, sd, inp
+
+
+@pytest.mark.parametrize('name', SAMPLE)
+def test_greedy_matches_reference(name, golden_dir):
+    g = _load(golden_dir, name)
+    opt, sd, inp = _build(name, g)
+    with torch.no_grad():
+        seq, lps, att2, sim = O.sample_greedy(sd, opt, inp['segs_feat'], inp['num'], inp['ppls'],
+                                              inp['ppls_feat'], inp['sample_idx'], inp['pnt_mask'])
+    assert np.array_equal(seq.numpy(), g['seq'])                       # bit-exact token ids
+    idx = O.attended_region_indices(att2, opt).numpy()
+    assert np.array_equal(idx, g['att_idx'].astype(np.int64))          # bit-exact attended regions
+    np.testing.assert_allclose(lps.numpy(), g['seqLogprobs'], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(sim[:, :, ::97].numpy(), g['sim_sub'], rtol=0, atol=1e-6)
+    if 'att2_weights' in g:
+        np.testing.assert_allclose(att2.numpy(), g['att2_weights'], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('name', MLE)
+def test_mle_losses_match_reference(name, golden_dir):
+    g = _load(golden_dir, name)
+    opt, sd, inp = _build(name, g)
+    want_grad = 'grad_norms' in g
+    W = sd
+    if want_grad:
+        W = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v)
+             for k, v in sd.items()}
+    ctx = torch.enable_grad() if want_grad else torch.no_grad()
+    with ctx:
+        lm, a2, gl, cl, aux = O.forward_train(W, opt, *[inp[k] for k in gvd_amd.synth.FORWARD_ORDER])
+    got = np.array([lm.item(), a2.item(), gl.item(), cl.item()], dtype=np.float32)
+    np.testing.assert_allclose(got, g['losses'], rtol=0, atol=1e-4)    # BASELINE tolerance
+    if cases.CASES[name].get('max_cap_len'):
+        assert aux['seq_cnt'] < opt.seq_length                         # early `break` exercised (model.py:425)
+    if want_grad:
+        w = cases.GRAD_WEIGHTS
+        (lm + w['w_att2'] * a2 + w['w_grd'] * gl + w['w_cls'] * cl).backward()
+        ref = dict(zip([str(n) for n in g['grad_names']], g['grad_norms']))
+        for n, v in W.items():
+            if n in ref:
+                assert v.grad is not None, n
+                np.testing.assert_allclose(float(v.grad.double().norm()), ref[n], rtol=1e-4, atol=1e-7)
+            elif v.is_floating_point() and v.requires_grad:
+                assert v.grad is None or float(v.grad.abs().sum()) == 0.0, n   # i2h_2/h2h_2: unused
+
+
+@pytest.mark.parametrize('name', GRD)
+def test_grd_matches_reference(name, golden_dir):
+    g = _load(golden_dir, name)
+    opt, sd, inp = _build(name, g)
+    with torch.no_grad():
+        cp, ai, gi = O.forward_train(sd, opt, *[inp[k] for k in gvd_amd.synth.FORWARD_ORDER],
+                                     eval_obj_ground=True)
+    assert np.array_equal(cp.numpy(), g['cls_pred'])
+    assert np.array_equal(ai.numpy(), g['att2_ind'].astype(np.int64))
+    assert np.array_equal(gi.numpy(), g['grd_ind'].astype(np.int64))
+
+
+def test_gru_loop_matches_fused():
+    """The readable GRU spec and the fused library GRU the oracle uses for speed agree."""
+    opt = gvd_amd.opts.default_opt(vocab_size=50)
+    sd = gvd_amd.synth.init_state_dict(opt, seed=3)
+    x = torch.randn(2, 7, 1024, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        a = O.gru_bidir_2layer_loop(x, sd)
+        b = O.gru_bidir_2layer(x, sd)
+    np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=0, atol=2e-6)
+
+
+def test_beam1_equals_greedy_without_unk_rule():
+    """Beam search (unpinned: the reference's beam path cannot run) degenerates to greedy at
+    beam_size=1 when UNK never wins (the beam path has no UNK suppression, CaptionModelBU.py:130)."""
+    opt = gvd_amd.opts.default_opt(vocab_size=300, t_attn_size=10)
+    sd = gvd_amd.synth.init_state_dict(opt, seed=7, profile='trained_like')
+    sd['logit.bias'][opt.vocab_size - 1] -= 50.0
+    inp = gvd_amd.synth.make_inputs(opt, 2, seed=7, train=False)
+    a = [inp[k] for k in ('segs_feat', 'num', 'ppls', 'ppls_feat', 'sample_idx', 'pnt_mask')]
+    with torch.no_grad():
+        pre = O.preamble(sd, opt, *a)
+        seq, lps, att2, _ = O.sample_greedy(sd, opt, *a, pre=pre)
+        bseq, blps, batt, _ = O.sample_beam(sd, opt, *a, beam_size=1, pre=pre)
+    # greedy never stops at END; beam stops at the first END token (rest of the row stays 0)
+    for b in range(seq.shape[0]):
+        row = seq[b].tolist()
+        n = row.index(0) + 1 if 0 in row else len(row)
+        assert bseq[b, :n].tolist() == row[:n]
+        assert bseq[b, n:].abs().sum() == 0
+        np.testing.assert_allclose(blps[b, :n].numpy(), lps[b, :n].numpy(), atol=2e-5)
+        # beam att2 = argmax over all R of the step's masked logits (CaptionModelBU.py:182)
+        glob = att2[b].max(dim=1)[1]
+        assert batt[b, :n].tolist() == glob[:n].tolist()

@@ -1,0 +1,155 @@
+"""bench.py — captions/sec of the GVD greedy-decode hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--t-attn Ft] [--vocab V]
+
+One "step" = one full `'sample'` call (AttModel._sample: per-segment preamble + 20-token greedy loop)
+over one batch of synthetic segments that is already resident in HBM.  N>1 is launched by
+torch.distributed.run (one process per GPU); the path shards purely over the batch of video segments,
+so every rank decodes its own B segments with no data-path collective (weak scaling) and the only
+communication is the barrier + max-reduction of the elapsed time.
+
+Prints ONE JSON line (rank 0): metric/value (whole-job captions/s), `roofline` of the dominant kernel
+(the attention streaming kernel, timed live with HIP events on its stream over the timed region) and
+`cpu_baseline` (the CPU oracle = port of the reference path, timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured copy
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=256, help='segments per GPU per step')
+    ap.add_argument('--t-attn', type=int, default=10, help='temporal positions Ft (BASELINE: [B,10,3072]; reference default 480)')
+    ap.add_argument('--vocab', type=int, default=5000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(opt, sd, seconds):
+    """The oracle (CPU port of the reference path) on BASELINE configs[0]: B=4 greedy, same shapes."""
+    from gvd_amd import synth
+    from oracle import gvd_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    inp = synth.make_inputs(opt, 4, seed=0, train=False)
+    a = [inp[k] for k in ('segs_feat', 'num', 'ppls', 'ppls_feat', 'sample_idx', 'pnt_mask')]
+    with torch.no_grad():
+        O.sample_greedy(sd, opt, *a)      # warm-up
+        n, t0 = 0, time.time()
+        while True:
+            O.sample_greedy(sd, opt, *a)
+            n += 1
+            if time.time() - t0 >= seconds and n >= 3:
+                break
+        dt = time.time() - t0
+    return {'value': round(4 * n / dt, 3), 'unit': 'captions/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d greedy sample() calls of B=4 (L=20, 10x100 regions, Ft=%d, V=%d) with oracle/gvd_oracle.py '
+                      '(torch-CPU restatement pinned bit-for-bit to the reference), %.1f s' % (n, opt.t_attn_size, opt.vocab_size, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    import gvd_amd  # noqa: F401
+    from gvd_amd import att_model, hip, opts, synth
+    opt = opts.default_opt(vocab_size=args.vocab, t_attn_size=args.t_attn)
+    sd = synth.init_state_dict(opt, seed=0, profile='trained_like')
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    B = args.batch
+    inp = synth.make_inputs(opt, B, seed=100 + rank, train=False)     # each rank: its own shard of segments
+    keys = ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')
+    dinp = [inp[k].to(dev) for k in keys]
+    timer = hip.KernelTimer(max_pairs=opt.seq_length * max(args.steps, 1))
+    model.kernel_timer = None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model._sample(*dinp)
+        torch.cuda.synchronize()
+        barrier()
+        model.kernel_timer = timer
+        timer.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            seq, lps, att2, sim = model._sample(*dinp)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    attn_ms, attn_n = timer.read()
+
+    if rank == 0:
+        R = opt.num_sampled_frm * opt.num_prop_per_frm
+        A, H, Ft = opt.att_hid_size, opt.rnn_size, args.t_attn
+        bytes_per_launch = B * (R + Ft) * (A + H) * 4          # algorithmic bytes
+        avg_s = (attn_ms / max(attn_n, 1)) * 1e-3
+        achieved = bytes_per_launch / avg_s / 1e9 if attn_n else None
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'attn_traffic.json')
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get('batch') == B and tj.get('t_attn') == Ft:
+                traffic = tj.get('hbm_bytes_per_launch')
+        out = {
+            'metric': 'captions/sec (seq_len=20, 10x100 regions), greedy decode',
+            'value': round(world * B * args.steps / elapsed, 2),
+            'unit': 'captions/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': "greedy 'sample' (preamble + 20-token loop), %d segments/GPU/step, L=20, "
+                                   "T x P = 10 x 100 regions [B,1000,2048] fc6 + [B,%d,3072] frame feats, V=%d, "
+                                   "obj_interact on; random-init weights (trained_like profile)" % (B, Ft, args.vocab),
+                       'batch_per_gpu': B, 'parallelism': 'batch-sharded replicas x%d (no data-path collective)' % world},
+            'roofline': {'bound': 'hbm', 'kernel': 'attn_partial_kernel (region+temporal additive attention)',
+                         'achieved': None if achieved is None else round(achieved, 1), 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                         'traffic': traffic, 'bytes_per_launch': bytes_per_launch,
+                         'avg_launch_us': round(avg_s * 1e6, 2), 'launches_timed': attn_n},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(opt, sd, args.cpu_seconds)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

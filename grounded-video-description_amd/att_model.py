@@ -1,0 +1,277 @@
+"""Drop-in boundary: `TopDownModel(opt)` with the reference's constructor/forward contract and
+`state_dict` layout (misc/AttModel.py:167-171 + misc/model.py:28-234), whose
+hot path runs in hand-written HIP kernels (libgvd_hip.so) instead of chains of ATen ops.
+
+    model = TopDownModel(opt).cuda()
+    lm, att2, grd, cls = model(segs_feat, seq, gt_seq, num, ppls, gt_boxes, mask_boxes, ppls_feat,
+                               frm_mask, sample_idx, pnt_mask, 'MLE')
+    seq, att2_weights, sim_mat = model(..., 'sample', {'sample_max': 1, 'beam_size': 1})
+    cls_pred, att2_ind, grd_ind = model(..., 'GRD')
+
+What runs where (DESIGN.md has the table): the per-token step (two LSTM cells, both additive
+attentions, vocabulary head and token rule), the fc7 / attn_hid / logit / grounder projections and
+the target/loss reductions are HIP kernels; the remaining per-segment preamble (layer norms,
+pool_embed, obj_interact encoder, bi-GRU) currently uses torch-ROCm library ops (rocBLAS/MIOpen) and
+is scheduled as the "next" rows of SURVEY.md §8f.  There is no CPU path: inputs must live on the GPU.
+
+Supported configuration = the reference's README recipe (att_model='topdown', att_input_mode='both',
+region_attn_mode='mix', transfer_mode='cls', t_attn_mode='bigru', seq_per_img=1, enable_BUTD=False).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .hip import GvdHipError
+
+MIN_VALUE = -1e8
+
+
+class _Holder(nn.Module):
+    """Plain parameter container (keeps the reference's dotted state_dict names)."""
+
+
+def _linear_params(out_f, in_f, bias=True):
+    return nn.Linear(in_f, out_f, bias=bias)
+
+
+class _EncLayerNorm(nn.Module):
+    """transformer.py:66-77 (unbiased std, eps on std)."""
+
+    def __init__(self, d, eps=1e-6):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(d))
+        self.beta = nn.Parameter(torch.zeros(d))
+        self.eps = eps
+
+    def forward(self, x):
+        mean = x.mean(-1, keepdim=True)
+        std = x.std(-1, keepdim=True)
+        return self.gamma * (x - mean) / (std + self.eps) + self.beta
+
+
+def _build_obj_interact(d_model, d_hidden, n_layers):
+    root = _Holder()
+    root.encoder = _Holder()
+    layers = []
+    for _ in range(n_layers):
+        lay = _Holder()
+        lay.selfattn = _Holder()
+        lay.selfattn.layer = _Holder()
+        for n in ('wq', 'wk', 'wv', 'wo'):
+            setattr(lay.selfattn.layer, n, nn.Linear(d_model, d_model, bias=False))
+        lay.selfattn.layernorm = _EncLayerNorm(d_model)
+        lay.feedforward = _Holder()
+        lay.feedforward.layer = _Holder()
+        lay.feedforward.layer.linear1 = nn.Linear(d_model, d_hidden)
+        lay.feedforward.layer.linear2 = nn.Linear(d_hidden, d_model)
+        lay.feedforward.layernorm = _EncLayerNorm(d_model)
+        layers.append(lay)
+    root.encoder.layers = nn.ModuleList(layers)
+    return root
+
+
+class _AttParams(nn.Module):
+    def __init__(self, H, A):
+        super().__init__()
+        self.h2att = nn.Linear(H, A)
+        self.alpha_net = nn.Linear(A, 1)
+
+
+class _Core(nn.Module):
+    """Parameters of TopDownCore (AttModel.py:111-131); the math lives in the HIP library."""
+
+    def __init__(self, opt):
+        super().__init__()
+        H, E, A = opt.rnn_size, opt.input_encoding_size, opt.att_hid_size
+        self.att_lstm = nn.LSTMCell(E + H, H)
+        self.lang_lstm = nn.LSTMCell(2 * H, H)
+        self.attention = _AttParams(H, A)
+        self.attention2 = _AttParams(H, A)
+        self.i2h_2 = nn.Linear(2 * H, H)   # unused in the reference too (AttModel.py:130-131)
+        self.h2h_2 = nn.Linear(H, H)
+
+
+class TopDownModel(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        for k, want in (('att_model', 'topdown'), ('att_input_mode', 'both'), ('region_attn_mode', 'mix'),
+                        ('transfer_mode', 'cls'), ('t_attn_mode', 'bigru'), ('seq_per_img', 1),
+                        ('enable_BUTD', False)):
+            if getattr(opt, k) != want:
+                raise NotImplementedError('%s=%r: only the reference README configuration (%r) is built '
+                                          'on the HIP path' % (k, getattr(opt, k), want))
+        self.vocab_size = opt.vocab_size
+        self.detect_size = opt.detect_size
+        self.rnn_size = H = opt.rnn_size
+        self.att_hid_size = opt.att_hid_size
+        self.input_encoding_size = opt.input_encoding_size
+        self.drop_prob_lm = opt.drop_prob_lm
+        self.seq_length = opt.seq_length
+        self.seg_info_size = 50
+        self.fc_feat_size = opt.fc_feat_size + self.seg_info_size
+        self.att_feat_size = opt.att_feat_size
+        self.seq_per_img = opt.seq_per_img
+        self.num_sampled_frm = opt.num_sampled_frm
+        self.num_prop_per_frm = opt.num_prop_per_frm
+        self.t_attn_size = opt.t_attn_size
+        self.test_mode = opt.test_mode
+        self.unk_idx = int(opt.wtoi['UNK'])
+        self.vis_encoding_size = 2048
+        self.pool_feat_size = self.att_feat_size + 300 + self.detect_size + 1
+        self.num_layers = 2
+        opt.beta = 1                                  # model.py:72
+        self.beta = 1
+        D1 = self.detect_size + 1
+        p = self.drop_prob_lm
+
+        # parameter layout == reference (model.py:75-161); Sequential indices keep the '.0.' names
+        self.vis_classifiers_bias = nn.Parameter(torch.zeros(D1))
+        self.loc_fc = nn.Sequential(nn.Linear(5, 300), nn.ReLU(), nn.Dropout(0.5))
+        self.embed = nn.Sequential(nn.Embedding(self.vocab_size, self.input_encoding_size), nn.ReLU(), nn.Dropout(p))
+        self.vis_embed = nn.Sequential(nn.Embedding(D1, self.vis_encoding_size), nn.ReLU(), nn.Dropout(p))
+        self.fc_embed = nn.Sequential(nn.Linear(self.fc_feat_size, H), nn.ReLU(), nn.Dropout(p))
+        self.seg_info_embed = nn.Sequential(nn.Linear(4, self.seg_info_size), nn.ReLU(), nn.Dropout(p))
+        self.att_embed = nn.ModuleList([
+            nn.Sequential(nn.Linear(2048, H // 2), nn.ReLU(), nn.Dropout(p)),
+            nn.Sequential(nn.Linear(1024, H // 2), nn.ReLU(), nn.Dropout(p))])
+        self.att_embed_aux = nn.Sequential(nn.BatchNorm1d(H), nn.ReLU())
+        self.pool_embed = nn.Sequential(nn.Linear(self.pool_feat_size, H), nn.ReLU(), nn.Dropout(p))
+        self.ctx2att = nn.Linear(H, self.att_hid_size)
+        self.ctx2pool = nn.Linear(H, self.att_hid_size)
+        self.logit = nn.Linear(H, self.vocab_size)
+        self.has_obj_interact = bool(opt.obj_interact)
+        if self.has_obj_interact:
+            self.obj_interact = _build_obj_interact(H, H // 2, 2)
+        self.context_enc = nn.GRU(H, H // 2, 2, dropout=0.2, bidirectional=True, batch_first=True)
+        self.ctx2pool_grd = nn.Sequential(nn.Linear(self.att_feat_size, self.vis_encoding_size), nn.ReLU(),
+                                          nn.Dropout(p))
+        self.core = _Core(opt)
+
+    # ------------------------------------------------------------------ API (model.py:227-234)
+    def forward(self, segs_feat, seq, gt_seq, num, ppls, gt_boxes, mask_boxes, ppls_feat, frm_mask,
+                sample_idx, pnt_mask, opt, eval_opt={}):
+        if not ppls_feat.is_cuda:
+            raise GvdHipError('TopDownModel runs on the MI355X HIP path only; move the model and inputs to the GPU')
+        if opt == 'MLE':
+            return self._forward_train(segs_feat, seq, gt_seq, ppls, gt_boxes, mask_boxes, num, ppls_feat,
+                                       frm_mask, sample_idx, pnt_mask, False)
+        if opt == 'GRD':
+            return self._forward_train(segs_feat, seq, gt_seq, ppls, gt_boxes, mask_boxes, num, ppls_feat,
+                                       frm_mask, sample_idx, pnt_mask, True)
+        if opt == 'sample':
+            seq, lps, att2, sim = self._sample(segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, eval_opt)
+            return seq, att2, sim
+        raise ValueError(opt)
+
+    # ------------------------------------------------------------------ helpers
+    def _lin(self, x, lin, act=0):
+        """nn.Linear (+ReLU) on the fp32 MFMA GEMM."""
+        return ops.linear(x, lin.weight, lin.bias, act)
+
+    def _drop(self, x, p=None):
+        return F.dropout(x, self.drop_prob_lm if p is None else p, self.training)
+
+    def _obj_interact(self, x):
+        """transformer.py:135-190,244-254 as built at model.py:126-135 (6 uneven heads, scale sqrt(d_model),
+        no padding mask, custom LayerNorm).  Library GEMMs for now."""
+        d = x.shape[-1]
+        scale = math.sqrt(d)
+        for lay in self.obj_interact.encoder.layers:
+            sa = lay.selfattn.layer
+            q, k, v = sa.wq(x), sa.wk(x), sa.wv(x)
+            heads = []
+            for qh, kh, vh in zip(q.chunk(6, -1), k.chunk(6, -1), v.chunk(6, -1)):
+                w = F.softmax(torch.matmul(qh, kh.transpose(1, 2)) / scale, dim=-1)
+                heads.append(torch.matmul(F.dropout(w, 0.2, self.training), vh))
+            att = sa.wo(torch.cat(heads, -1))
+            x = lay.selfattn.layernorm(x + F.dropout(att, 0.2, self.training))
+            ff = lay.feedforward.layer
+            y = ff.linear2(F.relu(ff.linear1(x)))
+            x = lay.feedforward.layernorm(x + F.dropout(y, 0.2, self.training))
+        return x
+
+    def _preamble(self, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask):
+        """Per-segment work shared by the three drivers (model.py:302-409 / 504-568 / 634-698)."""
+        B, Ft = segs_feat.shape[0], segs_feat.shape[1]
+        R = ppls.shape[1]
+        D1 = self.detect_size + 1
+        pm = pnt_mask if pnt_mask.dtype == torch.uint8 else pnt_mask.to(torch.uint8)
+        pm = pm.contiguous()
+        # fc feature (model.py:306-308)
+        fc = segs_feat.mean(dim=1)
+        seg_info = self._drop(F.relu(self.seg_info_embed[0](num[:, 3:7].float())))
+        fc = torch.cat([F.layer_norm(fc, [fc.shape[-1]]), F.layer_norm(seg_info, [self.seg_info_size])], dim=-1)
+        # fc7 over the raw fc6 region features: MFMA GEMM + fused bias/ReLU (model.py:311-313)
+        g_pool = self._drop(self._lin(ppls_feat, self.ctx2pool_grd[0], act=1))
+        # region-class similarity: batched grounder GEMM with fused bias + proposal mask (model.py:321-340)
+        vis_word = self._drop(F.relu(self.vis_embed[0].weight))
+        sim_logits = ops.grounder(vis_word, g_pool, pm[:, 1:], mbias=self.vis_classifiers_bias, xt_shared=True)
+        sim_mat = F.softmax(sim_logits, dim=1)
+        # location / class-distribution features (model.py:357-364)
+        loc_in = torch.cat([ppls[:, :, :4] / 720., (ppls[:, :, 4] * 1. / self.num_sampled_frm).unsqueeze(-1)], dim=2)
+        loc = F.dropout(F.relu(self.loc_fc[0](loc_in)), 0.5, self.training)
+        label = sim_mat.permute(0, 2, 1)
+        pool = torch.cat([F.layer_norm(g_pool, [g_pool.shape[-1]]), F.layer_norm(loc, [300]),
+                          F.layer_norm(label, [D1])], dim=2)
+        fc = self._drop(F.relu(self.fc_embed[0](fc)))
+        pool = self._drop(F.relu(self.pool_embed[0](pool)))
+        if self.has_obj_interact:
+            pool = self._obj_interact(pool)
+        pool = pool.contiguous()
+        p_pool = self._lin(pool, self.ctx2pool)                           # MFMA GEMM (model.py:391)
+        # frame-wise context (model.py:393-405)
+        c = torch.cat([self._drop(F.relu(self.att_embed[0][0](segs_feat[:, :, :2048]))),
+                       self._drop(F.relu(self.att_embed[1][0](segs_feat[:, :, 2048:])))], dim=2)
+        c = self.att_embed_aux(c.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+        c = self.context_enc(c)[0]
+        t = torch.arange(Ft, device=c.device).view(1, Ft)
+        keep = (t >= sample_idx[:, 0:1]) & (t < sample_idx[:, 1:2])           # model.py:303-305
+        conv = c.masked_fill(~keep.unsqueeze(-1), 0).contiguous()
+        p_conv = self._lin(conv, self.ctx2att)                            # MFMA GEMM (model.py:405)
+        return dict(fc=fc, pool=pool, p_pool=p_pool, conv=conv, p_conv=p_conv, g_pool=g_pool,
+                    sim_mat_static=sim_mat, pnt_mask=pm)
+
+    def _decode_params(self):
+        c = self.core
+        return dict(
+            embed=self.embed[0].weight,
+            att_w_ih=c.att_lstm.weight_ih, att_w_hh=c.att_lstm.weight_hh,
+            att_b_ih=c.att_lstm.bias_ih, att_b_hh=c.att_lstm.bias_hh,
+            lang_w_ih=c.lang_lstm.weight_ih, lang_w_hh=c.lang_lstm.weight_hh,
+            lang_b_ih=c.lang_lstm.bias_ih, lang_b_hh=c.lang_lstm.bias_hh,
+            att1_h2att_w=c.attention.h2att.weight, att1_h2att_b=c.attention.h2att.bias,
+            att1_alpha_w=c.attention.alpha_net.weight, att1_alpha_b=c.attention.alpha_net.bias,
+            att2_h2att_w=c.attention2.h2att.weight, att2_h2att_b=c.attention2.h2att.bias,
+            att2_alpha_w=c.attention2.alpha_net.weight, att2_alpha_b=c.attention2.alpha_net.bias,
+            logit_w=self.logit.weight, logit_b=self.logit.bias)
+
+    # ------------------------------------------------------------------ 'sample' (model.py:492-624)
+    def _sample(self, segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, opt={}):
+        sample_max = opt.get('sample_max', 1)
+        beam_size = opt.get('beam_size', 1)
+        if not sample_max:
+            raise NotImplementedError('multinomial sampling is outside the hot-path scope (greedy/beam only)')
+        with torch.no_grad():
+            pre = self._preamble(segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask)
+            P = {k: v.detach() for k, v in self._decode_params().items()}
+            if beam_size > 1:
+                from . import beam
+                seq, lps, att2 = beam.beam_decode(self, pre, P, beam_size)
+            else:
+                seq, lps, att2 = ops.greedy_decode(pre, P, pre['pnt_mask'], self.seq_length, self.unk_idx,
+                                                    prof=getattr(self, 'kernel_timer', None))
+        return seq, lps, att2, pre['sim_mat_static']
+
+    # ------------------------------------------------------------------ 'MLE' / 'GRD' (model.py:283-489)
+    def _forward_train(self, segs_feat, input_seq, gt_seq, ppls, gt_boxes, mask_boxes, num, ppls_feat,
+                       frm_mask, sample_idx, pnt_mask, eval_obj_ground):
+        from . import train_step
+        return train_step.forward_train(self, segs_feat, input_seq, gt_seq, ppls, gt_boxes, mask_boxes, num,
+                                        ppls_feat, frm_mask, sample_idx, pnt_mask, eval_obj_ground)
+
+
+class AttModel(TopDownModel):
+    """Alias kept for drivers that import `misc.model.AttModel` semantics."""

@@ -1,0 +1,246 @@
+// Additive visual attention of the GVD decoder step — the HBM-bound north-star kernel.
+//
+//   e[n]   = w . tanh(p_feats[b,n,:] + q[b,:]) + alpha_b ;  e[att_mask] = -1e8
+//   alpha  = softmax_n(e) ;  ctx[b,:] = sum_n alpha[n] feats[b,n,:]
+//   logits_out[b,n] = e[n] with [pnt_mask] = -1e8
+//
+// Reference: Attention2.forward (region attention, AttModel.py:71-108) and Attention.forward (temporal
+// attention, AttModel.py:33-53).  The reference materialises att+q, tanh(.), the scores, the softmax and a
+// bmm as separate [B,N,512]-sized ATen ops (about 3x the traffic); here every byte of p_feats [B,N,A] and
+// feats [B,N,H] is read from HBM exactly once per step and nothing of size [B,N,*] is written.
+//
+// Decomposition (MI355X): the N axis is cut into chunks; one 256-thread workgroup per (chunk, sample),
+// both attentions (region chunks first, then temporal chunks) in ONE launch so the grid has >> 256
+// workgroups.  Phase 1: each wave scores rows — the lane owns 8 fixed columns of the A=512 projection
+// (two coalesced float4 loads per row; its 8 q and 8 w values live in registers after one LDS-staged
+// broadcast), 64-lane xor-shuffle reduction per row.  Phase 2: chunk-local softmax numerators (online
+// softmax partial: max m, sum l), then each thread owns 4 of the H=1024 feature columns and streams the
+// chunk's rows with coalesced float4 loads, 8 rows in flight.  A second tiny kernel merges the per-chunk
+// (m, l, ctx) partials of both attentions and emits att+att2 for the language LSTM.
+// Algorithmic bytes per sample-call: N*(A+H)*4 (+2N mask bytes) — SURVEY.md §8d.
+#include "gvd_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int ATT_A = 512;
+constexpr int ATT_H = 1024;
+constexpr int MAX_CHUNK = 64;   // rows per workgroup (LDS score buffer)
+
+struct SideDev {
+  const float* feats; const float* p_feats; const float* q; int64_t ldq;
+  const float* w; const float* alpha_bias;
+  const uint8_t* att_mask; int64_t ld_att_mask;
+  const uint8_t* pnt_mask; int64_t ld_pnt_mask;
+  float* logits_out; int64_t ld_logits;
+  int N, chunk, nchunks;
+};
+
+struct FwdParams {
+  SideDev side[2];
+  int nside;
+  float* part_ctx;   // [B, NCtot, H]
+  float* part_ml;    // [B, NCtot, 2]
+  int nctot;
+};
+
+// workgroup (chunk c of side s, sample b)
+__global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
+  __shared__ float s_score[MAX_CHUNK];
+  __shared__ float s_red[8];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.y;
+  int c = blockIdx.x;
+  const int sidx = (p.nside > 1 && c >= p.side[0].nchunks) ? 1 : 0;
+  const SideDev& S = p.side[sidx];
+  const int cglob = c;
+  if (sidx) c -= p.side[0].nchunks;
+  const int n0 = c * S.chunk;
+  const int rows = min(S.chunk, S.N - n0);
+
+  // ---- phase 1: scores.  lane owns columns [4*lane, 4*lane+4) and [256+4*lane, ...+4) of A = 512
+  const float* qb = S.q + (int64_t)b * S.ldq;
+  const f32x4 q0 = *reinterpret_cast<const f32x4*>(qb + 4 * lane);
+  const f32x4 q1 = *reinterpret_cast<const f32x4*>(qb + 256 + 4 * lane);
+  const f32x4 w0 = *reinterpret_cast<const f32x4*>(S.w + 4 * lane);
+  const f32x4 w1 = *reinterpret_cast<const f32x4*>(S.w + 256 + 4 * lane);
+  const float ab = *S.alpha_bias;
+  const float* pf = S.p_feats + ((int64_t)b * S.N + n0) * ATT_A;
+  const uint8_t* am = S.att_mask ? S.att_mask + (int64_t)b * S.ld_att_mask + n0 : nullptr;
+  const uint8_t* pm = S.pnt_mask ? S.pnt_mask + (int64_t)b * S.ld_pnt_mask + n0 : nullptr;
+  float* lo = S.logits_out ? S.logits_out + (int64_t)b * S.ld_logits + n0 : nullptr;
+
+  for (int r = wave * 2; r < rows; r += 8) {
+    const bool two = (r + 1) < rows;
+    const float* p0 = pf + (int64_t)r * ATT_A;
+    const float* p1 = two ? p0 + ATT_A : p0;
+    f32x4 x00 = *reinterpret_cast<const f32x4*>(p0 + 4 * lane);
+    f32x4 x01 = *reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane);
+    f32x4 x10 = *reinterpret_cast<const f32x4*>(p1 + 4 * lane);
+    f32x4 x11 = *reinterpret_cast<const f32x4*>(p1 + 256 + 4 * lane);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s0 = fmaf(w0[k], tanhf(x00[k] + q0[k]), s0);
+      s0 = fmaf(w1[k], tanhf(x01[k] + q1[k]), s0);
+      s1 = fmaf(w0[k], tanhf(x10[k] + q0[k]), s1);
+      s1 = fmaf(w1[k], tanhf(x11[k] + q1[k]), s1);
+    }
+    s0 = wave_sum(s0) + ab;
+    s1 = wave_sum(s1) + ab;
+    if (lane == 0) {
+      float e0 = (am && am[r]) ? GVD_MIN_VALUE : s0;
+      s_score[r] = e0;
+      if (lo) lo[r] = (pm && pm[r]) ? GVD_MIN_VALUE : e0;
+      if (two) {
+        float e1 = (am && am[r + 1]) ? GVD_MIN_VALUE : s1;
+        s_score[r + 1] = e1;
+        if (lo) lo[r + 1] = (pm && pm[r + 1]) ? GVD_MIN_VALUE : e1;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- chunk-local softmax numerators
+  float m = -INFINITY;
+  if (tid < rows) m = s_score[tid];
+  m = wave_max(m);   // rows <= 64: only wave 0 holds data
+  if (tid == 0) s_red[0] = m;
+  __syncthreads();
+  m = s_red[0];
+  float pr = 0.f;
+  if (tid < rows) { pr = expf(s_score[tid] - m); }
+  __syncthreads();
+  if (tid < rows) s_score[tid] = pr;
+  float l = wave_sum(pr);
+  if (tid == 0) {
+    float* ml = p.part_ml + ((int64_t)b * p.nctot + cglob) * 2;
+    ml[0] = m; ml[1] = l;
+  }
+  __syncthreads();
+
+  // ---- phase 2: partial context.  thread owns columns [4*tid, 4*tid+4) of H = 1024
+  const float* fb = S.feats + ((int64_t)b * S.N + n0) * ATT_H + 4 * tid;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int r = 0;
+  for (; r + 8 <= rows; r += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(fb + (int64_t)(r + u) * ATT_H);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float pw = s_score[r + u];
+      acc[0] = fmaf(pw, v[u][0], acc[0]); acc[1] = fmaf(pw, v[u][1], acc[1]);
+      acc[2] = fmaf(pw, v[u][2], acc[2]); acc[3] = fmaf(pw, v[u][3], acc[3]);
+    }
+  }
+  for (; r < rows; ++r) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(fb + (int64_t)r * ATT_H);
+    const float pw = s_score[r];
+    acc[0] = fmaf(pw, v[0], acc[0]); acc[1] = fmaf(pw, v[1], acc[1]);
+    acc[2] = fmaf(pw, v[2], acc[2]); acc[3] = fmaf(pw, v[3], acc[3]);
+  }
+  *reinterpret_cast<f32x4*>(p.part_ctx + ((int64_t)b * p.nctot + cglob) * ATT_H + 4 * tid) = acc;
+}
+
+struct CombParams {
+  const float* part_ctx; const float* part_ml;
+  int nc[2]; int nside; int nctot;
+  float* out_sum; int64_t ld_out;
+  float* ctx_out[2];   // optional, [B,H] each
+};
+
+__global__ __launch_bounds__(256) void attn_combine_kernel(const CombParams p) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  f32x4 total = {0.f, 0.f, 0.f, 0.f};
+  int c0 = 0;
+  for (int s = 0; s < p.nside; ++s) {
+    const int nc = p.nc[s];
+    const float* ml = p.part_ml + ((int64_t)b * p.nctot + c0) * 2;
+    float M = -INFINITY;
+    for (int c = 0; c < nc; ++c) M = fmaxf(M, ml[2 * c]);
+    float L = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* pc = p.part_ctx + ((int64_t)b * p.nctot + c0) * ATT_H + 4 * tid;
+    for (int c = 0; c < nc; ++c) {
+      const float sc = expf(ml[2 * c] - M);
+      L = fmaf(sc, ml[2 * c + 1], L);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pc + (int64_t)c * ATT_H);
+      acc[0] = fmaf(sc, v[0], acc[0]); acc[1] = fmaf(sc, v[1], acc[1]);
+      acc[2] = fmaf(sc, v[2], acc[2]); acc[3] = fmaf(sc, v[3], acc[3]);
+    }
+    const float inv = 1.0f / L;
+    acc[0] *= inv; acc[1] *= inv; acc[2] *= inv; acc[3] *= inv;
+    if (p.ctx_out[s]) *reinterpret_cast<f32x4*>(p.ctx_out[s] + (int64_t)b * ATT_H + 4 * tid) = acc;
+    total[0] += acc[0]; total[1] += acc[1]; total[2] += acc[2]; total[3] += acc[3];
+    c0 += nc;
+  }
+  if (p.out_sum) *reinterpret_cast<f32x4*>(p.out_sum + (int64_t)b * p.ld_out + 4 * tid) = total;
+}
+
+// rows per chunk: keep >= ~1024 workgroups in flight when the batch is small, 50-row chunks otherwise
+int pick_chunk(int N, int B) {
+  int chunk = 50;
+  while (chunk > 10 && (long)B * ((N + chunk - 1) / chunk) < 1024) chunk = (chunk + 1) / 2;
+  if (chunk > MAX_CHUNK) chunk = MAX_CHUNK;
+  if (chunk > N) chunk = N;
+  if (chunk < 1) chunk = 1;
+  return chunk;
+}
+
+int nchunks_of(int N, int B) { int c = pick_chunk(N, B); return (N + c - 1) / c; }
+
+bool side_ok(const gvd_attn_side* s) {
+  return s && s->feats && s->p_feats && s->q && s->w && s->alpha_bias && s->N > 0 && gvd_aligned16(s->feats) &&
+         gvd_aligned16(s->p_feats) && gvd_aligned16(s->q) && gvd_aligned16(s->w) && (s->ldq % 4) == 0;
+}
+
+void fill_side(SideDev& d, const gvd_attn_side* s, int B) {
+  d.feats = s->feats; d.p_feats = s->p_feats; d.q = s->q; d.ldq = s->ldq; d.w = s->w;
+  d.alpha_bias = s->alpha_bias; d.att_mask = s->att_mask; d.ld_att_mask = s->ld_att_mask;
+  d.pnt_mask = s->pnt_mask; d.ld_pnt_mask = s->ld_pnt_mask; d.logits_out = s->logits_out;
+  d.ld_logits = s->ld_logits; d.N = s->N; d.chunk = pick_chunk(s->N, B);
+  d.nchunks = (s->N + d.chunk - 1) / d.chunk;
+}
+
+}  // namespace
+
+extern "C" size_t gvd_attn_workspace_bytes(int B, int n_region, int n_temporal, int H) {
+  long nc = nchunks_of(n_region, B) + (n_temporal > 0 ? nchunks_of(n_temporal, B) : 0);
+  return (size_t)B * nc * (H + 4) * sizeof(float);
+}
+
+extern "C" int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_side* temporal, int B, int A, int H,
+                                 float* out_sum, int64_t ld_out, float* ctx_region, float* ctx_temporal,
+                                 void* workspace, gvd_prof* prof, gvd_stream_t stream) {
+  if (A != ATT_A || H != ATT_H || B <= 0 || !workspace || !gvd_aligned16(workspace)) return GVD_EINVAL;
+  if (!side_ok(region) || (temporal && !side_ok(temporal))) return GVD_EINVAL;
+  if (out_sum && (!gvd_aligned16(out_sum) || (ld_out % 4) != 0)) return GVD_EINVAL;
+  FwdParams p = {};
+  fill_side(p.side[0], region, B);
+  p.nside = 1;
+  if (temporal) { fill_side(p.side[1], temporal, B); p.nside = 2; }
+  p.nctot = p.side[0].nchunks + (temporal ? p.side[1].nchunks : 0);
+  p.part_ctx = reinterpret_cast<float*>(workspace);
+  p.part_ml = p.part_ctx + (int64_t)B * p.nctot * ATT_H;
+  hipStream_t st = gvd_s(stream);
+  gvd_prof_begin(prof, st);
+  hipLaunchKernelGGL(attn_partial_kernel, dim3((unsigned)p.nctot, (unsigned)B), dim3(256), 0, st, p);
+  gvd_prof_end(prof, st);
+  GVD_CHECK_LAUNCH();
+  CombParams c = {};
+  c.part_ctx = p.part_ctx; c.part_ml = p.part_ml; c.nside = p.nside; c.nctot = p.nctot;
+  c.nc[0] = p.side[0].nchunks; c.nc[1] = temporal ? p.side[1].nchunks : 0;
+  c.out_sum = out_sum; c.ld_out = ld_out; c.ctx_out[0] = ctx_region; c.ctx_out[1] = ctx_temporal;
+  hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)B), dim3(256), 0, st, c);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gvd_attn_fwd(const gvd_attn_side* region, const gvd_attn_side* temporal, int B, int A, int H,
+                            float* out_sum, int64_t ld_out, float* ctx_region, float* ctx_temporal,
+                            void* workspace, gvd_stream_t stream) {
+  return gvd_attn_fwd_prof(region, temporal, B, A, H, out_sum, ld_out, ctx_region, ctx_temporal, workspace,
+                           nullptr, stream);
+}

@@ -1,0 +1,147 @@
+// Greedy decode driver: the whole token loop of AttModel._sample (model.py:580-624; sample_max=1,
+// beam_size=1) as one asynchronous launch sequence on one stream — no host round trip per token, no
+// per-step tensor allocation, no concatenations (the LSTM kernels read their input blocks in place).
+//
+// Per step (TopDownCore.forward, AttModel.py:134-164):
+//   1 att-LSTM   gates = [fc | xt] W_ih^T + h_att W_hh^T + b    (fc part hoisted out of the loop)
+//   2 q          [q_temporal | q_region] = h_att [W_att ; W_att2]^T + b      (one GEMM, stacked weights)
+//   3 attention  temporal + region partials in one streaming pass, 4 combine -> att + att2
+//   5 lang-LSTM  gates = [att+att2 | h_att] W_ih^T + h_lang W_hh^T + b
+//   6 logits     h_lang W_logit^T + b ;  7 token rule: log-softmax, top-2, UNK -> runner-up, embed next
+#include "gvd_common.h"
+
+namespace {
+
+struct Ws {
+  float *fc_gates, *h_att[2], *c_att[2], *h_lang[2], *c_lang[2], *q12, *att_sum, *logits, *xt, *w_stack,
+      *b_stack;
+  int64_t* it0;
+  void* attn_ws;
+  size_t total;
+};
+
+size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+Ws carve(void* base, int B, int Ft, int R, int H, int A, int E, int V) {
+  Ws w;
+  size_t off = 0;
+  char* b = reinterpret_cast<char*>(base);
+  auto take = [&](size_t bytes) { void* p = b ? b + off : nullptr; off += align_up(bytes); return p; };
+  const size_t f = sizeof(float);
+  w.fc_gates = (float*)take((size_t)B * 4 * H * f);
+  for (int i = 0; i < 2; ++i) {
+    w.h_att[i] = (float*)take((size_t)B * H * f); w.c_att[i] = (float*)take((size_t)B * H * f);
+    w.h_lang[i] = (float*)take((size_t)B * H * f); w.c_lang[i] = (float*)take((size_t)B * H * f);
+  }
+  w.q12 = (float*)take((size_t)B * 2 * A * f);
+  w.att_sum = (float*)take((size_t)B * H * f);
+  w.logits = (float*)take((size_t)B * V * f);
+  w.xt = (float*)take((size_t)B * E * f);
+  w.w_stack = (float*)take((size_t)2 * A * H * f);
+  w.b_stack = (float*)take((size_t)2 * A * f);
+  w.it0 = (int64_t*)take((size_t)B * sizeof(int64_t));
+  w.attn_ws = take(gvd_attn_workspace_bytes(B, R, Ft, H));
+  w.total = off;
+  return w;
+}
+
+#define GVD_TRY(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
+#define GVD_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return (int)e__; } while (0)
+
+}  // namespace
+
+extern "C" size_t gvd_greedy_workspace_bytes(int B, int Ft, int R, int H, int A, int E, int V) {
+  return carve(nullptr, B, Ft, R, H, A, E, V).total;
+}
+
+extern "C" int gvd_greedy_decode(const gvd_greedy_args* a, gvd_stream_t stream) {
+  if (!a || !a->workspace || !gvd_aligned16(a->workspace) || a->B <= 0 || a->L <= 0) return GVD_EINVAL;
+  const int B = a->B, H = a->H, A = a->A, E = a->E, V = a->V, R = a->R, Ft = a->Ft, L = a->L;
+  hipStream_t st = gvd_s(stream);
+  Ws w = carve(a->workspace, B, Ft, R, H, A, E, V);
+
+  // zero state, BOS token ids, stacked h2att weights [W_att ; W_att2]
+  for (int i = 0; i < 1; ++i) {
+    GVD_HIP(hipMemsetAsync(w.h_att[0], 0, (size_t)B * H * 4, st));
+    GVD_HIP(hipMemsetAsync(w.c_att[0], 0, (size_t)B * H * 4, st));
+    GVD_HIP(hipMemsetAsync(w.h_lang[0], 0, (size_t)B * H * 4, st));
+    GVD_HIP(hipMemsetAsync(w.c_lang[0], 0, (size_t)B * H * 4, st));
+  }
+  GVD_HIP(hipMemsetAsync(w.it0, 0, (size_t)B * sizeof(int64_t), st));
+  GVD_HIP(hipMemcpyAsync(w.w_stack, a->att1_h2att_w, (size_t)A * H * 4, hipMemcpyDeviceToDevice, st));
+  GVD_HIP(hipMemcpyAsync(w.w_stack + (size_t)A * H, a->att2_h2att_w, (size_t)A * H * 4, hipMemcpyDeviceToDevice, st));
+  GVD_HIP(hipMemcpyAsync(w.b_stack, a->att1_h2att_b, (size_t)A * 4, hipMemcpyDeviceToDevice, st));
+  GVD_HIP(hipMemcpyAsync(w.b_stack + A, a->att2_h2att_b, (size_t)A * 4, hipMemcpyDeviceToDevice, st));
+
+  // loop-invariant part of the att-LSTM gates: fc W_ih[:, :H]^T + b_ih + b_hh   (AttModel.py:138)
+  {
+    gvd_gemm_args g = {};
+    g.nseg = 1;
+    g.seg[0] = {a->fc, H, 0, a->att_w_ih, (int64_t)(E + H), 0, H};
+    g.nbias = a->att_b_ih; g.nbias2 = a->att_b_hh;
+    g.C = w.fc_gates; g.ldc = 4 * H; g.M = B; g.N = 4 * H; g.batch = 1;
+    GVD_TRY(gvd_gemm_nt_f32(&g, stream));
+  }
+  GVD_TRY(gvd_embed_relu(w.it0, 1, B, a->embed, E, w.xt, E, stream));   // BOS = token 0 (model.py:588)
+
+  int cur = 0;
+  for (int t = 0; t < L; ++t) {
+    const int nxt = cur ^ 1;
+    {  // attention LSTM
+      gvd_lstm_args l = {};
+      l.nseg = 2;
+      l.seg[0] = {w.xt, E, 0, a->att_w_ih + H, (int64_t)(E + H), 0, E};
+      l.seg[1] = {w.h_att[cur], H, 0, a->att_w_hh, H, 0, H};
+      l.rowbias = w.fc_gates; l.rowbias_ld = 4 * H;
+      l.c_prev = w.c_att[cur]; l.ldc_prev = H;
+      l.h_out = w.h_att[nxt]; l.ldh = H; l.c_out = w.c_att[nxt]; l.ldc_out = H;
+      l.B = B; l.H = H;
+      GVD_TRY(gvd_lstm_cell_fwd(&l, stream));
+    }
+    {  // both attention queries
+      gvd_gemm_args g = {};
+      g.nseg = 1;
+      g.seg[0] = {w.h_att[nxt], H, 0, w.w_stack, H, 0, H};
+      g.nbias = w.b_stack;
+      g.C = w.q12; g.ldc = 2 * A; g.M = B; g.N = 2 * A; g.batch = 1;
+      GVD_TRY(gvd_gemm_nt_f32(&g, stream));
+    }
+    {  // temporal + region attention -> att + att2
+      gvd_attn_side reg = {};
+      reg.feats = a->pool; reg.p_feats = a->p_pool; reg.q = w.q12 + A; reg.ldq = 2 * A;
+      reg.w = a->att2_alpha_w; reg.alpha_bias = a->att2_alpha_b;
+      reg.att_mask = a->pnt_mask + 1; reg.ld_att_mask = R + 1;
+      reg.pnt_mask = a->pnt_mask + 1; reg.ld_pnt_mask = R + 1;
+      reg.logits_out = a->att2_weights + (int64_t)t * R; reg.ld_logits = (int64_t)L * R;
+      reg.N = R;
+      gvd_attn_side tmp = {};
+      tmp.feats = a->conv; tmp.p_feats = a->p_conv; tmp.q = w.q12; tmp.ldq = 2 * A;
+      tmp.w = a->att1_alpha_w; tmp.alpha_bias = a->att1_alpha_b; tmp.N = Ft;
+      GVD_TRY(gvd_attn_fwd_prof(&reg, &tmp, B, A, H, w.att_sum, H, nullptr, nullptr, w.attn_ws, a->prof, stream));
+    }
+    {  // language LSTM
+      gvd_lstm_args l = {};
+      l.nseg = 3;
+      l.seg[0] = {w.att_sum, H, 0, a->lang_w_ih, (int64_t)(2 * H), 0, H};
+      l.seg[1] = {w.h_att[nxt], H, 0, a->lang_w_ih + H, (int64_t)(2 * H), 0, H};
+      l.seg[2] = {w.h_lang[cur], H, 0, a->lang_w_hh, H, 0, H};
+      l.b_ih = a->lang_b_ih; l.b_hh = a->lang_b_hh;
+      l.c_prev = w.c_lang[cur]; l.ldc_prev = H;
+      l.h_out = w.h_lang[nxt]; l.ldh = H; l.c_out = w.c_lang[nxt]; l.ldc_out = H;
+      l.B = B; l.H = H;
+      GVD_TRY(gvd_lstm_cell_fwd(&l, stream));
+    }
+    {  // vocabulary logits
+      gvd_gemm_args g = {};
+      g.nseg = 1;
+      g.seg[0] = {w.h_lang[nxt], H, 0, a->logit_w, H, 0, H};
+      g.nbias = a->logit_b;
+      g.C = w.logits; g.ldc = V; g.M = B; g.N = V; g.batch = 1;
+      GVD_TRY(gvd_gemm_nt_f32(&g, stream));
+    }
+    GVD_TRY(gvd_logsoftmax_top2_embed(w.logits, V, B, V, a->unk_idx, a->seq + t, L, a->seq_logprobs + t, L,
+                                      a->embed, E, w.xt, E, stream));
+    cur = nxt;
+  }
+  return 0;
+}

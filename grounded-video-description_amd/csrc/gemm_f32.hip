@@ -1,0 +1,303 @@
+// fp32 "NT" GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chains, 157 TF peak)
+// with fused epilogues:  plain (bias / per-row bias / 2-D bias / ReLU / masked fill)  and  LSTM cell.
+//
+//   C[b][M,N] = epi( sum_s A_s[b][M,K_s] * W_s[b][N,K_s]^T )
+//
+// Replaces the implicit cuBLAS GEMM + elementwise ATen chains of the reference hot path
+// (SURVEY.md §2.3 P2,P4,P8,S1,S4,S6,T4; reference call sites cited in include/gvd_hip.h).
+//
+// Design (MI355X): 256 threads = 4 waves (one per SIMD) per workgroup; each wave owns a grid of 32x32
+// MFMA tiles.  Operand tiles [rows][32 k] are staged global -> registers -> LDS (float4, 128-B row
+// segments: fully coalesced), double-buffered so one barrier per k-tile suffices; LDS rows are padded to
+// 36 floats, which makes the per-lane ds_read_b128 fragment reads bank-conflict free.  Each lane reads 4
+// consecutive k of its row once (16 B) and feeds them to 4 successive MFMAs: lane-half h supplies
+// k = 8*kb + 4*h + t at MFMA step t, so the two k-slots of a 32x32x2 MFMA carry k and k+4 — a
+// permutation of the summation order only.  The f32 MFMA issues every 64 cycles per SIMD, so LDS and
+// global traffic hide completely behind the matrix pipe.  Workgroup ids are remapped XCD-aware so the
+// tiles that share an A panel land on one XCD's L2.
+#include "gvd_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = 36;  // padded LDS row (floats)
+
+struct KParams {
+  const float* A[3]; int64_t lda[3]; int64_t abs_[3];
+  const float* W[3]; int64_t ldw[3]; int64_t wbs[3];
+  int K[3]; int nseg;
+  const float* nbias; const float* nbias2;
+  const float* mbias; int64_t mbias_bs;
+  const float* rowbias; int64_t rowbias_ld; int64_t rowbias_bs;
+  const uint8_t* mask; int64_t mask_ldm; int64_t mask_bs;
+  float* C; int64_t ldc; int64_t cbs;
+  int M, N, act;
+  // LSTM epilogue
+  const float* c_prev; int64_t ldcp;
+  float* h_out; int64_t ldh;
+  float* c_out; int64_t ldco;
+  float* gates_out; int64_t ldg;
+  int H;
+  int ntn, ntm;
+};
+
+template <int BM, int BN, int WGM, int WGN, bool LSTM>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;   // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;     // MFMA tiles per wave
+  constexpr int NA = BM / 32, NW = BN / 32;       // float4 loads per thread per k-tile
+  constexpr int HU = BN / 4;                      // LSTM: hidden units per tile
+  static_assert(WGM * WGN == 4, "4 waves");
+  static_assert(TM >= 1 && TN >= 1, "tile");
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
+  float* As = smem;
+  float* Ws = smem + 2 * BM * LDK;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, half = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const unsigned nwg = gridDim.x;
+  const unsigned lid = xcd_remap(blockIdx.x, nwg);
+  const int tn_ = lid % p.ntn, tm_ = lid / p.ntn;
+  const int bz = blockIdx.y;
+  const int m0 = tm_ * BM;
+  const int n0 = LSTM ? 0 : tn_ * BN;
+
+  // per-thread global row pointers are recomputed per segment; row validity is segment independent
+  int a_row[NA], w_row[NW];
+  bool a_ok[NA], w_ok[NW];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    int row = (tid + i * 256) >> 3;
+    int gm = m0 + row;
+    a_ok[i] = gm < p.M;
+    a_row[i] = a_ok[i] ? gm : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    int nl = (tid + i * 256) >> 3;
+    if (LSTM) {
+      w_row[i] = (nl / HU) * p.H + tn_ * HU + (nl % HU);
+      w_ok[i] = true;
+    } else {
+      int gn = n0 + nl;
+      w_ok[i] = gn < p.N;
+      w_row[i] = w_ok[i] ? gn : 0;
+    }
+  }
+  const int kq4 = (tid & 7) * 4;
+
+  int nkt = 0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+    if (s < p.nseg) nkt += p.K[s] / BK;
+
+  f32x4 ra[NA], rw[NW];
+  auto load_tile = [&](int kt) {
+    int s = 0, k0 = kt * BK;
+    while (s + 1 < p.nseg && k0 >= p.K[s]) { k0 -= p.K[s]; ++s; }
+    const float* Ab = p.A[s] + (int64_t)bz * p.abs_[s] + k0 + kq4;
+    const float* Wb = p.W[s] + (int64_t)bz * p.wbs[s] + k0 + kq4;
+    const int64_t lda = p.lda[s], ldw = p.ldw[s];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (a_ok[i]) v = *reinterpret_cast<const f32x4*>(Ab + (int64_t)a_row[i] * lda);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (w_ok[i]) v = *reinterpret_cast<const f32x4*>(Wb + (int64_t)w_row[i] * ldw);
+      rw[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int row = (tid + i * 256) >> 3;
+      *reinterpret_cast<f32x4*>(&As[(buf * BM + row) * LDK + kq4]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      int row = (tid + i * 256) >> 3;
+      *reinterpret_cast<f32x4*>(&Ws[(buf * BN + row) * LDK + kq4]) = rw[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    const float* Ab = &As[(buf * BM + wm * WTM + r) * LDK + half * 4];
+    const float* Wb = &Ws[(buf * BN + wn * WTN + r) * LDK + half * 4];
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + kb * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Wb + j * 32 * LDK + kb * 8);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  if (!LSTM) {
+    float* Cb = p.C + (int64_t)bz * p.cbs;
+    const float* rb = p.rowbias ? p.rowbias + (int64_t)bz * p.rowbias_bs : nullptr;
+    const float* mb = p.mbias ? p.mbias + (int64_t)bz * p.mbias_bs : nullptr;
+    const uint8_t* mk = p.mask ? p.mask + (int64_t)bz * p.mask_bs : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int gn = n0 + wn * WTN + j * 32 + r;
+        if (gn >= p.N) continue;
+        float nb = 0.f;
+        if (p.nbias) nb += p.nbias[gn];
+        if (p.nbias2) nb += p.nbias2[gn];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+          const int gm = m0 + wm * WTM + i * 32 + row;
+          if (gm < p.M) {
+            float v = acc[i][j][e] + nb;
+            if (mb) v += mb[gm];
+            if (rb) v += rb[(int64_t)gm * p.rowbias_ld + gn];
+            if (p.act == 1) v = fmaxf(v, 0.f);
+            if (mk && mk[(int64_t)gm * p.mask_ldm + gn]) v = GVD_MIN_VALUE;
+            Cb[(int64_t)gm * p.ldc + gn] = v;
+          }
+        }
+      }
+  } else {
+    // gates -> LDS tile G[BM][BN+1] (columns grouped i|f|g|o, HU units each), then the pointwise cell.
+    constexpr int LDG = BN + 1;
+    static_assert(BM * LDG <= 2 * (BM + BN) * LDK, "G tile fits");
+    float* G = smem;   // all waves passed the loop's final barrier: operand tiles are dead
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nl = wn * WTN + j * 32 + r;
+        const int wrow = (nl / HU) * p.H + tn_ * HU + (nl % HU);
+        float nb = 0.f;
+        if (p.nbias) nb += p.nbias[wrow];
+        if (p.nbias2) nb += p.nbias2[wrow];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+          const int ml = wm * WTM + i * 32 + row;
+          const int gm = m0 + ml;
+          float v = acc[i][j][e] + nb;
+          if (p.rowbias && gm < p.M) v += p.rowbias[(int64_t)gm * p.rowbias_ld + wrow];
+          G[ml * LDG + nl] = v;
+        }
+      }
+    __syncthreads();
+    for (int idx = tid; idx < BM * HU; idx += 256) {
+      const int ml = idx / HU, jl = idx % HU;
+      const int gm = m0 + ml;
+      if (gm >= p.M) continue;
+      const int j = tn_ * HU + jl;
+      const float gi = sigmoid_f(G[ml * LDG + jl]);
+      const float gf = sigmoid_f(G[ml * LDG + HU + jl]);
+      const float gg = tanhf(G[ml * LDG + 2 * HU + jl]);
+      const float go = sigmoid_f(G[ml * LDG + 3 * HU + jl]);
+      const float c = gf * p.c_prev[(int64_t)gm * p.ldcp + j] + gi * gg;
+      p.c_out[(int64_t)gm * p.ldco + j] = c;
+      p.h_out[(int64_t)gm * p.ldh + j] = go * tanhf(c);
+      if (p.gates_out) {
+        float* g = p.gates_out + (int64_t)gm * p.ldg;
+        g[j] = gi; g[p.H + j] = gf; g[2 * p.H + j] = gg; g[3 * p.H + j] = go;
+      }
+    }
+  }
+}
+
+bool seg_ok(const gvd_gemm_seg& s) {
+  return s.A && s.W && s.K > 0 && (s.K % BK) == 0 && gvd_aligned16(s.A) && gvd_aligned16(s.W) &&
+         (s.lda % 4) == 0 && (s.ldw % 4) == 0 && (s.a_batch_stride % 4) == 0 && (s.w_batch_stride % 4) == 0;
+}
+
+template <int BM, int BN, int WGM, int WGN, bool LSTM>
+int launch(KParams& p, int batch, hipStream_t st) {
+  p.ntm = (p.M + BM - 1) / BM;
+  p.ntn = LSTM ? p.H / (BN / 4) : (p.N + BN - 1) / BN;
+  dim3 grid((unsigned)(p.ntm * p.ntn), (unsigned)batch);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, WGN, LSTM>), grid, dim3(256), 0, st, p);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
+  if (!a || a->nseg < 1 || a->nseg > 3 || !a->C || a->M <= 0 || a->N <= 0 || a->batch <= 0) return GVD_EINVAL;
+  KParams p = {};
+  p.nseg = a->nseg;
+  for (int s = 0; s < a->nseg; ++s) {
+    if (!seg_ok(a->seg[s])) return GVD_EINVAL;
+    p.A[s] = a->seg[s].A; p.lda[s] = a->seg[s].lda; p.abs_[s] = a->seg[s].a_batch_stride;
+    p.W[s] = a->seg[s].W; p.ldw[s] = a->seg[s].ldw; p.wbs[s] = a->seg[s].w_batch_stride;
+    p.K[s] = a->seg[s].K;
+  }
+  p.nbias = a->nbias; p.nbias2 = a->nbias2;
+  p.mbias = a->mbias; p.mbias_bs = a->mbias_batch_stride;
+  p.rowbias = a->rowbias; p.rowbias_ld = a->rowbias_ld; p.rowbias_bs = a->rowbias_batch_stride;
+  p.mask = a->mask; p.mask_ldm = a->mask_ldm; p.mask_bs = a->mask_batch_stride;
+  p.C = a->C; p.ldc = a->ldc; p.cbs = a->c_batch_stride;
+  p.M = a->M; p.N = a->N; p.act = a->act;
+  hipStream_t st = gvd_s(stream);
+  if (a->M <= 32) return launch<32, 128, 1, 4, false>(p, a->batch, st);
+  const long big = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
+  if (big >= 256) return launch<128, 128, 2, 2, false>(p, a->batch, st);
+  return launch<64, 64, 2, 2, false>(p, a->batch, st);
+}
+
+extern "C" int gvd_lstm_cell_fwd(const gvd_lstm_args* a, gvd_stream_t stream) {
+  if (!a || a->nseg < 1 || a->nseg > 3 || a->B <= 0 || a->H <= 0 || (a->H % 32) != 0 || !a->c_prev ||
+      !a->h_out || !a->c_out)
+    return GVD_EINVAL;
+  KParams p = {};
+  p.nseg = a->nseg;
+  for (int s = 0; s < a->nseg; ++s) {
+    if (!seg_ok(a->seg[s])) return GVD_EINVAL;
+    p.A[s] = a->seg[s].A; p.lda[s] = a->seg[s].lda; p.abs_[s] = 0;
+    p.W[s] = a->seg[s].W; p.ldw[s] = a->seg[s].ldw; p.wbs[s] = 0;
+    p.K[s] = a->seg[s].K;
+  }
+  p.nbias = a->b_ih; p.nbias2 = a->b_hh;
+  p.rowbias = a->rowbias; p.rowbias_ld = a->rowbias_ld;
+  p.M = a->B; p.N = 4 * a->H; p.H = a->H;
+  p.c_prev = a->c_prev; p.ldcp = a->ldc_prev;
+  p.h_out = a->h_out; p.ldh = a->ldh;
+  p.c_out = a->c_out; p.ldco = a->ldc_out;
+  p.gates_out = a->gates_out; p.ldg = a->ldg;
+  hipStream_t st = gvd_s(stream);
+  if (a->B <= 32) return launch<32, 128, 1, 4, true>(p, 1, st);
+  return launch<64, 64, 2, 2, true>(p, 1, st);
+}

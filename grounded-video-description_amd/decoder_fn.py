@@ -1,0 +1,91 @@
+"""Teacher-forced decoder loop (AttModel._forward token loop, model.py:421-453) on the HIP kernels.
+
+`decoder_loop` runs Lc steps of TopDownCore.forward (AttModel.py:134-164): fused LSTM cells, one GEMM for
+both attention queries, one streaming pass for both attentions.  Under autograd the loop is ONE
+autograd.Function whose backward is a hand-scheduled BPTT (see `_DecoderLoopFn`), so no per-step
+autograd graph, no saved [B,R,512] tanh tensors (SURVEY.md §7 "BPTT memory") and no per-step
+[B,R,*] gradient buffers exist.
+"""
+import torch
+
+from . import ops
+
+
+def _params(model):
+    c = model.core
+    H = model.rnn_size
+    return dict(
+        att_w_ih=c.att_lstm.weight_ih, att_w_hh=c.att_lstm.weight_hh, att_b_ih=c.att_lstm.bias_ih,
+        att_b_hh=c.att_lstm.bias_hh, lang_w_ih=c.lang_lstm.weight_ih, lang_w_hh=c.lang_lstm.weight_hh,
+        lang_b_ih=c.lang_lstm.bias_ih, lang_b_hh=c.lang_lstm.bias_hh,
+        a1_w=c.attention.h2att.weight, a1_b=c.attention.h2att.bias,
+        a1_aw=c.attention.alpha_net.weight, a1_ab=c.attention.alpha_net.bias,
+        a2_w=c.attention2.h2att.weight, a2_b=c.attention2.h2att.bias,
+        a2_aw=c.attention2.alpha_net.weight, a2_ab=c.attention2.alpha_net.bias)
+
+
+def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks, save=None):
+    """The forward recurrence.  `save` (dict) receives what the BPTT needs when given."""
+    B, Lc, E = xt_all.shape
+    H = fc.shape[1]
+    A = p_pool.shape[2]
+    R = pool.shape[1]
+    dev = fc.device
+    w_ih_fc, w_ih_xt = P['att_w_ih'][:, :H], P['att_w_ih'][:, H:]
+    w_ih_att, w_ih_h = P['lang_w_ih'][:, :H], P['lang_w_ih'][:, H:]
+    w_stack = torch.cat([P['a1_w'], P['a2_w']], 0)
+    b_stack = torch.cat([P['a1_b'], P['a2_b']], 0)
+    a1_aw, a2_aw = P['a1_aw'].reshape(-1), P['a2_aw'].reshape(-1)
+    # loop-invariant part of the att-LSTM gates: fc W_ih[:, :H]^T + b_ih + b_hh
+    fc_gates = ops.gemm_nt(fc, w_ih_fc, P['att_b_ih']) + P['att_b_hh']
+    h_att = torch.zeros(B, H, device=dev); c_att = torch.zeros(B, H, device=dev)
+    h_lang = torch.zeros(B, H, device=dev); c_lang = torch.zeros(B, H, device=dev)
+    h_all = torch.empty(B, Lc, H, device=dev)
+    att2_w = torch.empty(B, Lc, R, device=dev)
+    am = att_mask[:, 1:]
+    per_step_mask = pnt_masks.dim() == 3
+    if save is not None:
+        save.update(gates_att=torch.empty(Lc, B, 4 * H, device=dev), gates_lang=torch.empty(Lc, B, 4 * H, device=dev),
+                    c_att=torch.empty(Lc + 1, B, H, device=dev), c_lang=torch.empty(Lc + 1, B, H, device=dev),
+                    h_att=torch.empty(Lc + 1, B, H, device=dev), h_lang=torch.empty(Lc + 1, B, H, device=dev),
+                    q12=torch.empty(Lc, B, 2 * A, device=dev), att_sum=torch.empty(Lc, B, H, device=dev),
+                    ctx_r=torch.empty(Lc, B, H, device=dev), ctx_t=torch.empty(Lc, B, H, device=dev),
+                    w_stack=w_stack)
+        for k in ('c_att', 'c_lang', 'h_att', 'h_lang'):
+            save[k][0].zero_()
+    for t in range(Lc):
+        xt = xt_all[:, t]
+        g_att = save['gates_att'][t] if save is not None else None
+        h_att, c_att = ops.lstm_cell([xt], [w_ih_xt], h_att, P['att_w_hh'], None, None, c_att,
+                                     rowbias=fc_gates, gates_out=g_att)
+        q12 = ops.gemm_nt(h_att, w_stack, b_stack, out=save['q12'][t] if save is not None else None)
+        pmask = (pnt_masks[:, t] if per_step_mask else pnt_masks)[:, 1:]
+        region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P['a2_ab'], att_mask=am,
+                      pnt_mask=pmask, logits_out=att2_w[:, t])
+        temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab'])
+        if save is not None:
+            att_sum, cr, ct = ops.attention_step(region, temporal, want_separate=True)
+            save['ctx_r'][t].copy_(cr); save['ctx_t'][t].copy_(ct); save['att_sum'][t].copy_(att_sum)
+        else:
+            att_sum = ops.attention_step(region, temporal)
+        g_lang = save['gates_lang'][t] if save is not None else None
+        h_lang, c_lang = ops.lstm_cell([att_sum, h_att], [w_ih_att, w_ih_h], h_lang, P['lang_w_hh'],
+                                       P['lang_b_ih'], P['lang_b_hh'], c_lang, gates_out=g_lang)
+        h_all[:, t].copy_(h_lang)
+        if save is not None:
+            save['h_att'][t + 1].copy_(h_att); save['c_att'][t + 1].copy_(c_att)
+            save['h_lang'][t + 1].copy_(h_lang); save['c_lang'][t + 1].copy_(c_lang)
+    return h_all, att2_w
+
+
+def decoder_loop(model, pre, xt_all, att_mask, pnt_masks):
+    P = _params(model)
+    tensors = [pre['fc'], pre['conv'], pre['p_conv'], pre['pool'], pre['p_pool'], xt_all] + list(P.values())
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        from .decoder_bwd import DecoderLoopFn
+        keys = list(P.keys())
+        return DecoderLoopFn.apply(att_mask, pnt_masks, keys, pre['fc'], pre['conv'], pre['p_conv'], pre['pool'],
+                                   pre['p_pool'], xt_all.contiguous(), *[P[k] for k in keys])
+    Pd = {k: v.detach() for k, v in P.items()}
+    return forward_loop(Pd, pre['fc'].detach(), pre['conv'].detach(), pre['p_conv'].detach(), pre['pool'].detach(),
+                        pre['p_pool'].detach(), xt_all.detach().contiguous(), att_mask, pnt_masks)

@@ -1,0 +1,177 @@
+"""ctypes binding of libgvd_hip.so (C-ABI declared in include/gvd_hip.h).
+
+The product path has NO fallback: if the library is missing or a call returns non-zero, a
+`GvdHipError` is raised.  torch is used here only to obtain device pointers and the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import build as _build
+
+
+class GvdHipError(RuntimeError):
+    pass
+
+
+c_f32p = C.c_void_p
+c_u8p = C.c_void_p
+c_i64p = C.c_void_p
+
+
+class GemmSeg(C.Structure):
+    _fields_ = [('A', c_f32p), ('lda', C.c_int64), ('a_batch_stride', C.c_int64),
+                ('W', c_f32p), ('ldw', C.c_int64), ('w_batch_stride', C.c_int64),
+                ('K', C.c_int)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [('seg', GemmSeg * 3), ('nseg', C.c_int),
+                ('nbias', c_f32p), ('nbias2', c_f32p),
+                ('mbias', c_f32p), ('mbias_batch_stride', C.c_int64),
+                ('rowbias', c_f32p), ('rowbias_ld', C.c_int64), ('rowbias_batch_stride', C.c_int64),
+                ('mask', c_u8p), ('mask_ldm', C.c_int64), ('mask_batch_stride', C.c_int64),
+                ('C', c_f32p), ('ldc', C.c_int64), ('c_batch_stride', C.c_int64),
+                ('M', C.c_int), ('N', C.c_int), ('batch', C.c_int), ('act', C.c_int)]
+
+
+class LstmArgs(C.Structure):
+    _fields_ = [('seg', GemmSeg * 3), ('nseg', C.c_int),
+                ('b_ih', c_f32p), ('b_hh', c_f32p),
+                ('rowbias', c_f32p), ('rowbias_ld', C.c_int64),
+                ('c_prev', c_f32p), ('ldc_prev', C.c_int64),
+                ('h_out', c_f32p), ('ldh', C.c_int64),
+                ('c_out', c_f32p), ('ldc_out', C.c_int64),
+                ('gates_out', c_f32p), ('ldg', C.c_int64),
+                ('B', C.c_int), ('H', C.c_int)]
+
+
+class AttnSide(C.Structure):
+    _fields_ = [('feats', c_f32p), ('p_feats', c_f32p), ('q', c_f32p), ('ldq', C.c_int64),
+                ('w', c_f32p), ('alpha_bias', c_f32p),
+                ('att_mask', c_u8p), ('ld_att_mask', C.c_int64),
+                ('pnt_mask', c_u8p), ('ld_pnt_mask', C.c_int64),
+                ('logits_out', c_f32p), ('ld_logits', C.c_int64),
+                ('N', C.c_int)]
+
+
+class GreedyArgs(C.Structure):
+    _fields_ = [('fc', c_f32p), ('conv', c_f32p), ('p_conv', c_f32p), ('pool', c_f32p), ('p_pool', c_f32p),
+                ('pnt_mask', c_u8p), ('embed', c_f32p),
+                ('att_w_ih', c_f32p), ('att_w_hh', c_f32p), ('att_b_ih', c_f32p), ('att_b_hh', c_f32p),
+                ('lang_w_ih', c_f32p), ('lang_w_hh', c_f32p), ('lang_b_ih', c_f32p), ('lang_b_hh', c_f32p),
+                ('att1_h2att_w', c_f32p), ('att1_h2att_b', c_f32p), ('att1_alpha_w', c_f32p), ('att1_alpha_b', c_f32p),
+                ('att2_h2att_w', c_f32p), ('att2_h2att_b', c_f32p), ('att2_alpha_w', c_f32p), ('att2_alpha_b', c_f32p),
+                ('logit_w', c_f32p), ('logit_b', c_f32p),
+                ('B', C.c_int), ('Ft', C.c_int), ('R', C.c_int), ('H', C.c_int), ('A', C.c_int), ('E', C.c_int),
+                ('V', C.c_int), ('L', C.c_int), ('unk_idx', C.c_int),
+                ('seq', c_i64p), ('seq_logprobs', c_f32p), ('att2_weights', c_f32p), ('workspace', C.c_void_p),
+                ('prof', C.c_void_p)]
+
+
+# every symbol include/gvd_hip.h declares: (restype, argtypes)
+_SIG = {
+    'gvd_version': (C.c_char_p, []),
+    'gvd_abi_version': (C.c_int, []),
+    'gvd_prof_create': (C.c_void_p, [C.c_int]),
+    'gvd_prof_destroy': (None, [C.c_void_p]),
+    'gvd_prof_reset': (None, [C.c_void_p]),
+    'gvd_prof_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    'gvd_attn_fwd_prof': (C.c_int, [C.POINTER(AttnSide), C.POINTER(AttnSide), C.c_int, C.c_int, C.c_int,
+                                    c_f32p, C.c_int64, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'gvd_gemm_nt_f32': (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    'gvd_lstm_cell_fwd': (C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),
+    'gvd_attn_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'gvd_attn_fwd': (C.c_int, [C.POINTER(AttnSide), C.POINTER(AttnSide), C.c_int, C.c_int, C.c_int,
+                               c_f32p, C.c_int64, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
+    'gvd_logsoftmax_top2_embed': (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_i64p, C.c_int64,
+                                            c_f32p, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_int64, C.c_void_p]),
+    'gvd_embed_relu': (C.c_int, [c_i64p, C.c_int64, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int64, C.c_void_p]),
+    'gvd_logsoftmax_rows': (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, c_i64p, c_f32p, C.c_int,
+                                      c_f32p, c_i64p, C.c_void_p]),
+    'gvd_greedy_workspace_bytes': (C.c_size_t, [C.c_int] * 7),
+    'gvd_greedy_decode': (C.c_int, [C.POINTER(GreedyArgs), C.c_void_p]),
+    'gvd_iou_targets': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_u8p, c_u8p, C.c_int, C.c_int, C.c_int,
+                                  c_f32p, c_i64p, C.c_void_p]),
+    'gvd_step_targets': (C.c_int, [c_f32p, c_u8p, c_u8p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   c_f32p, c_u8p, C.c_void_p]),
+    'gvd_masked_lsm_loss': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, c_f32p,
+                                      C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIG)
+_lib = None
+
+
+def lib():
+    """Load libgvd_hip.so (built in-tree by build.py).  Raises GvdHipError if it is missing."""
+    global _lib
+    if _lib is None:
+        path = _build.library_path()
+        if not os.path.exists(path):
+            raise GvdHipError('libgvd_hip.so not built (%s): run `python __graft_entry__.py build`; '
+                              'there is no CPU/eager fallback for the hot path' % path)
+        try:
+            l = C.CDLL(path)
+        except OSError as e:   # e.g. libamdhip64 missing
+            raise GvdHipError('cannot load %s: %s' % (path, e))
+        for name, (res, args) in _SIG.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                raise GvdHipError('libgvd_hip.so does not export %s (stale build?)' % name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise GvdHipError('%s failed with code %d (%s)' % (
+            what, rc, 'unsupported shape/alignment' if rc == -1 else 'hipError_t'))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def require_cuda_f32(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise GvdHipError('HIP hot path called with a non-GPU tensor; there is no CPU fallback')
+        if t.dtype != torch.float32:
+            raise GvdHipError('expected float32, got %s' % t.dtype)
+
+
+class KernelTimer:
+    """Event pairs around the attention streaming kernel (gvd_prof_*): live kernel durations on its stream."""
+
+    def __init__(self, max_pairs=4096):
+        self.h = C.c_void_p(lib().gvd_prof_create(max_pairs))
+        if not self.h:
+            raise GvdHipError('gvd_prof_create failed')
+
+    def reset(self):
+        lib().gvd_prof_reset(self.h)
+
+    def read(self):
+        ms, n = C.c_float(0), C.c_int(0)
+        check(lib().gvd_prof_read(self.h, C.byref(ms), C.byref(n)), 'gvd_prof_read')
+        return ms.value, n.value
+
+    def __del__(self):
+        try:
+            lib().gvd_prof_destroy(self.h)
+        except Exception:
+            pass

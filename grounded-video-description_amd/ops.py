@@ -1,0 +1,358 @@
+"""Python-side operators of the hot path: thin wrappers that marshal torch tensors into the C-ABI of
+libgvd_hip.so (include/gvd_hip.h).  All compute happens in the HIP library; torch only provides
+device memory and the current stream.  No CPU/eager fallback exists: non-GPU tensors raise.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+from .hip import AttnSide, GemmArgs, GemmSeg, GreedyArgs, LstmArgs, check, lib, ptr, require_cuda_f32, stream_ptr
+
+
+def _seg(A, W, K=None, a_bs=0, w_bs=0):
+    """A: [..., M, K] view with unit inner stride; W: [..., N, K] likewise."""
+    assert A.stride(-1) == 1 and W.stride(-1) == 1
+    K = A.shape[-1] if K is None else K
+    assert W.shape[-1] == K, (A.shape, W.shape)
+    return GemmSeg(ptr(A), A.stride(-2), a_bs, ptr(W), W.stride(-2), w_bs, K)
+
+
+def gemm_nt(A, W, bias=None, act=0, out=None):
+    """out[M,N] = act(A[M,K] @ W[N,K]^T + bias).  nn.Linear forward on the fp32 matrix cores."""
+    require_cuda_f32(A, W, bias)
+    lead = A.shape[:-1]
+    A2 = A.reshape(-1, A.shape[-1])
+    if A2.stride(-1) != 1:
+        A2 = A2.contiguous()
+    M, N = A2.shape[0], W.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    g = GemmArgs()
+    g.nseg = 1
+    g.seg[0] = _seg(A2, W)
+    g.nbias = ptr(bias)
+    g.C = ptr(out); g.ldc = out.stride(0)
+    g.M, g.N, g.batch, g.act = M, N, 1, act
+    check(lib().gvd_gemm_nt_f32(C.byref(g), stream_ptr()), 'gvd_gemm_nt_f32')
+    return out.view(*lead, N)
+
+
+def grounder_dot(xt, feats, mask, mbias=None, rowbias=None, xt_shared=False):
+    """`AttModel._grounder` dot-product branch (model.py:243-280), batched over B in one launch:
+    out[b,m,r] = xt[b,m,:] . feats[b,r,:] + mbias[(b,)m] + rowbias[b,m,r];  out[mask] = -1e8.
+    xt: [B,M,K] (or [M,K] with xt_shared, e.g. the D1 visual words); feats: [B,R,K];
+    mask: u8 [B,R] (broadcast over m) or [B,M,R]."""
+    require_cuda_f32(xt, feats, mbias, rowbias)
+    B, R, K = feats.shape
+    M = xt.shape[-2]
+    out = torch.empty(B, M, R, device=feats.device, dtype=torch.float32)
+    g = GemmArgs()
+    g.nseg = 1
+    assert xt.is_contiguous() and feats.is_contiguous()
+    g.seg[0] = GemmSeg(ptr(xt), K, 0 if xt_shared else M * K, ptr(feats), K, R * K, K)
+    if mbias is not None:
+        assert mbias.is_contiguous()
+        g.mbias = ptr(mbias)
+        g.mbias_batch_stride = 0 if mbias.dim() == 1 else M
+    if rowbias is not None:
+        assert rowbias.is_contiguous() and rowbias.shape == (B, M, R)
+        g.rowbias = ptr(rowbias); g.rowbias_ld = R; g.rowbias_batch_stride = M * R
+    if mask is not None:
+        assert mask.dtype == torch.uint8 and mask.stride(-1) == 1
+        g.mask = ptr(mask)
+        if mask.dim() == 2:
+            g.mask_ldm = 0; g.mask_batch_stride = mask.stride(0)
+        else:
+            g.mask_ldm = mask.stride(1); g.mask_batch_stride = mask.stride(0)
+    g.C = ptr(out); g.ldc = R; g.c_batch_stride = M * R
+    g.M, g.N, g.batch, g.act = M, R, B, 0
+    check(lib().gvd_gemm_nt_f32(C.byref(g), stream_ptr()), 'gvd_gemm_nt_f32(grounder)')
+    return out
+
+
+def lstm_cell(xs, ws, h_prev, w_hh, b_ih, b_hh, c_prev, rowbias=None, gates_out=None):
+    """Fused nn.LSTMCell forward.  xs/ws: lists of input blocks [B,K_s] and the matching column blocks
+    of weight_ih ([4H,K_s] views, row stride = full weight_ih width).  Returns (h, c)."""
+    B, H = c_prev.shape
+    require_cuda_f32(h_prev, c_prev, w_hh, *xs, *ws)
+    h = torch.empty(B, H, device=c_prev.device, dtype=torch.float32)
+    c = torch.empty(B, H, device=c_prev.device, dtype=torch.float32)
+    a = LstmArgs()
+    segs = list(zip(xs, ws)) + [(h_prev, w_hh)]
+    a.nseg = len(segs)
+    for i, (x, w) in enumerate(segs):
+        a.seg[i] = _seg(x, w)
+    a.b_ih, a.b_hh = ptr(b_ih), ptr(b_hh)
+    if rowbias is not None:
+        a.rowbias = ptr(rowbias); a.rowbias_ld = rowbias.stride(0)
+    a.c_prev = ptr(c_prev); a.ldc_prev = c_prev.stride(0)
+    a.h_out = ptr(h); a.ldh = H
+    a.c_out = ptr(c); a.ldc_out = H
+    if gates_out is not None:
+        a.gates_out = ptr(gates_out); a.ldg = gates_out.stride(0)
+    a.B, a.H = B, H
+    check(lib().gvd_lstm_cell_fwd(C.byref(a), stream_ptr()), 'gvd_lstm_cell_fwd')
+    return h, c
+
+
+def _side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, logits_out=None):
+    s = AttnSide()
+    assert feats.is_contiguous() and p_feats.is_contiguous() and q.stride(-1) == 1
+    s.feats, s.p_feats = ptr(feats), ptr(p_feats)
+    s.q = ptr(q); s.ldq = q.stride(0)
+    s.w = ptr(w); s.alpha_bias = ptr(alpha_bias)
+    if att_mask is not None:
+        assert att_mask.dtype == torch.uint8 and att_mask.stride(-1) == 1
+        s.att_mask = ptr(att_mask); s.ld_att_mask = att_mask.stride(0)
+    if pnt_mask is not None:
+        assert pnt_mask.dtype == torch.uint8 and pnt_mask.stride(-1) == 1
+        s.pnt_mask = ptr(pnt_mask); s.ld_pnt_mask = pnt_mask.stride(0)
+    if logits_out is not None:
+        assert logits_out.stride(-1) == 1
+        s.logits_out = ptr(logits_out); s.ld_logits = logits_out.stride(0)
+    s.N = feats.shape[1]
+    return s
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+def attention_step(region, temporal, want_separate=False):
+    """Both additive attentions of one decoder step (AttModel.py:33-53,71-108) in one streaming pass.
+
+    region / temporal: dicts(feats, p_feats, q, w, alpha_bias[, att_mask, pnt_mask, logits_out]).
+    Returns att+att2 [B,H] (and the two contexts when want_separate)."""
+    f = region['feats']
+    B, Nr, H = f.shape
+    A = region['p_feats'].shape[-1]
+    require_cuda_f32(f, region['p_feats'], region['q'])
+    sr = _side(**region)
+    st = _side(**temporal) if temporal is not None else None
+    Nt = temporal['feats'].shape[1] if temporal is not None else 0
+    ws = _workspace(lib().gvd_attn_workspace_bytes(B, Nr, Nt, H), f.device)
+    out = torch.empty(B, H, device=f.device, dtype=torch.float32)
+    cr = torch.empty(B, H, device=f.device, dtype=torch.float32) if want_separate else None
+    ct = torch.empty(B, H, device=f.device, dtype=torch.float32) if (want_separate and st is not None) else None
+    check(lib().gvd_attn_fwd(C.byref(sr), C.byref(st) if st is not None else None, B, A, H, ptr(out), H,
+                             ptr(cr), ptr(ct), ptr(ws), stream_ptr()), 'gvd_attn_fwd')
+    return (out, cr, ct) if want_separate else out
+
+
+def embed_relu(it, embed):
+    B = it.shape[0]
+    xt = torch.empty(B, embed.shape[1], device=embed.device, dtype=torch.float32)
+    assert it.dtype == torch.int64
+    check(lib().gvd_embed_relu(ptr(it), it.stride(0), B, ptr(embed), embed.shape[1], ptr(xt), xt.stride(0),
+                               stream_ptr()), 'gvd_embed_relu')
+    return xt
+
+
+def logsoftmax_rows(logits, target=None, topk=0):
+    """Per-row logsumexp (+ log-prob of `target`, + top-k log-probs/indices)."""
+    require_cuda_f32(logits)
+    rows, V = logits.shape
+    lse = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    picked = torch.empty(rows, device=logits.device, dtype=torch.float32) if target is not None else None
+    tv = torch.empty(rows, topk, device=logits.device, dtype=torch.float32) if topk else None
+    ti = torch.empty(rows, topk, device=logits.device, dtype=torch.int64) if topk else None
+    check(lib().gvd_logsoftmax_rows(ptr(logits), logits.stride(0), rows, V, ptr(lse), ptr(target), ptr(picked),
+                                    topk, ptr(tv), ptr(ti), stream_ptr()), 'gvd_logsoftmax_rows')
+    return lse, picked, tv, ti
+
+
+def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None):
+    """Whole greedy token loop (AttModel._sample, model.py:580-624) in one C call.
+    pre: dict(fc, conv, p_conv, pool, p_pool) from the preamble; P: dict of parameter tensors."""
+    fc, conv, p_conv, pool, p_pool = (pre[k].contiguous() for k in ('fc', 'conv', 'p_conv', 'pool', 'p_pool'))
+    require_cuda_f32(fc, conv, p_conv, pool, p_pool)
+    B, H = fc.shape
+    Ft, R, A = conv.shape[1], pool.shape[1], p_pool.shape[2]
+    V, E = P['embed'].shape
+    dev = fc.device
+    seq = torch.empty(B, L, dtype=torch.int64, device=dev)
+    lps = torch.empty(B, L, dtype=torch.float32, device=dev)
+    att2 = torch.empty(B, L, R, dtype=torch.float32, device=dev)
+    pm = pnt_mask.contiguous()
+    assert pm.dtype == torch.uint8 and pm.shape == (B, R + 1)
+    ws = torch.empty(lib().gvd_greedy_workspace_bytes(B, Ft, R, H, A, E, V), dtype=torch.uint8, device=dev)
+    a = GreedyArgs()
+    a.fc, a.conv, a.p_conv, a.pool, a.p_pool = ptr(fc), ptr(conv), ptr(p_conv), ptr(pool), ptr(p_pool)
+    a.pnt_mask = ptr(pm)
+    for k in ('embed', 'att_w_ih', 'att_w_hh', 'att_b_ih', 'att_b_hh', 'lang_w_ih', 'lang_w_hh', 'lang_b_ih',
+              'lang_b_hh', 'att1_h2att_w', 'att1_h2att_b', 'att1_alpha_w', 'att1_alpha_b', 'att2_h2att_w',
+              'att2_h2att_b', 'att2_alpha_w', 'att2_alpha_b', 'logit_w', 'logit_b'):
+        t = P[k]
+        assert t.is_contiguous() and t.is_cuda and t.dtype == torch.float32, k
+        setattr(a, k, ptr(t))
+    a.B, a.Ft, a.R, a.H, a.A, a.E, a.V, a.L, a.unk_idx = B, Ft, R, H, A, E, V, L, unk_idx
+    a.seq, a.seq_logprobs, a.att2_weights, a.workspace = ptr(seq), ptr(lps), ptr(att2), ptr(ws)
+    a.prof = prof.h if prof is not None else None
+    check(lib().gvd_greedy_decode(C.byref(a), stream_ptr()), 'gvd_greedy_decode')
+    return seq, lps, att2
+
+
+def iou_targets(ppls, gt_boxes, frm_mask, pnt_mask, want_sim_target=True):
+    require_cuda_f32(ppls, gt_boxes)
+    B, R, K = frm_mask.shape
+    ppls, gt_boxes = ppls.contiguous(), gt_boxes.contiguous()
+    frm_mask, pnt_mask = frm_mask.contiguous(), pnt_mask.contiguous()
+    ov = torch.empty(B, R, K, device=ppls.device, dtype=torch.float32)
+    st = torch.empty(B, K, R, device=ppls.device, dtype=torch.int64) if want_sim_target else None
+    check(lib().gvd_iou_targets(ptr(ppls), ppls.shape[2], ptr(gt_boxes), gt_boxes.shape[2], ptr(frm_mask),
+                                ptr(pnt_mask), B, R, K, ptr(ov), ptr(st), stream_ptr()), 'gvd_iou_targets')
+    return ov, st
+
+
+def step_targets(overlaps, mask_boxes, frm_mask, pnt_mask, Lc):
+    B, R, K = overlaps.shape
+    mask_boxes = mask_boxes.contiguous()
+    Lp1 = mask_boxes.shape[-1]
+    roi = torch.empty(B, Lc, R, device=overlaps.device, dtype=torch.float32)
+    fm = torch.empty(B, Lc, R + 1, device=overlaps.device, dtype=torch.uint8)
+    check(lib().gvd_step_targets(ptr(overlaps), ptr(mask_boxes), ptr(frm_mask.contiguous()),
+                                 ptr(pnt_mask.contiguous()), B, R, K, Lp1, Lc, ptr(roi), ptr(fm), stream_ptr()),
+          'gvd_step_targets')
+    return roi, fm
+
+
+def masked_lsm_loss(x, label):
+    """-mean(log_softmax(x, -1)[label != 0]) (utils.py:139,142); x, label: [..., N]."""
+    require_cuda_f32(x, label)
+    N = x.shape[-1]
+    x2, l2 = x.reshape(-1, N), label.reshape(-1, N)
+    assert x2.stride(-1) == 1 and l2.stride(-1) == 1
+    acc = torch.zeros(2, device=x.device, dtype=torch.float32)
+    lse = torch.empty(x2.shape[0], device=x.device, dtype=torch.float32)
+    check(lib().gvd_masked_lsm_loss(ptr(x2), x2.stride(0), ptr(l2), l2.stride(0), x2.shape[0], N, ptr(acc),
+                                    ptr(lse), stream_ptr()), 'gvd_masked_lsm_loss')
+    return acc[0] / acc[1], lse
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd-aware entry points (forward = HIP kernel; backward GEMMs are plain library GEMMs via torch)
+# --------------------------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        out = gemm_nt(x, w, b, act)
+        ctx.act = act
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, out if act else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, out = ctx.saved_tensors
+        if ctx.act:
+            dy = dy * (out > 0).to(dy.dtype)
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        dx = (dy2 @ w).view_as(x) if ctx.needs_input_grad[0] else None
+        dw = dy2.t() @ x2 if ctx.needs_input_grad[1] else None
+        db = dy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+def linear(x, w, b=None, act=0):
+    """nn.Linear(+ReLU): MFMA GEMM forward; differentiable when grad mode is on."""
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
+        return _LinearFn.apply(x, w, b, act)
+    return gemm_nt(x.detach(), w.detach(), None if b is None else b.detach(), act)
+
+
+class _GrounderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xt, feats, mask, mbias, rowbias, xt_shared):
+        out = grounder_dot(xt, feats, mask, mbias, rowbias, xt_shared)
+        ctx.xt_shared = xt_shared
+        ctx.save_for_backward(xt, feats, mask)
+        ctx.mbias_dim = None if mbias is None else mbias.dim()
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xt, feats, mask = ctx.saved_tensors
+        if mask is not None:
+            m = mask.bool()
+            if m.dim() == 2:
+                m = m.unsqueeze(1)
+            dout = dout.masked_fill(m, 0.0)
+        g = [None] * 6
+        if ctx.needs_input_grad[0]:
+            dxt = torch.matmul(dout, feats)                    # [B,M,K]
+            g[0] = dxt.sum(0) if ctx.xt_shared else dxt
+        if ctx.needs_input_grad[1]:
+            g[1] = torch.matmul(dout.transpose(1, 2), xt)     # [B,R,K] (xt broadcasts when shared)
+        if ctx.mbias_dim is not None and ctx.needs_input_grad[3]:
+            s = dout.sum(-1)
+            g[3] = s.sum(0) if ctx.mbias_dim == 1 else s
+        if ctx.needs_input_grad[4]:
+            g[4] = dout
+        return tuple(g)
+
+
+def grounder(xt, feats, mask, mbias=None, rowbias=None, xt_shared=False):
+    """`_grounder` dot branch (model.py:243-280); differentiable when grad mode is on."""
+    ts = [t for t in (xt, feats, mbias, rowbias) if t is not None]
+    if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
+        return _GrounderFn.apply(xt, feats, mask, mbias, rowbias, xt_shared)
+    d = lambda t: None if t is None else t.detach()
+    return grounder_dot(d(xt), d(feats), mask, d(mbias), d(rowbias), xt_shared)
+
+
+class _NllGatherFn(torch.autograd.Function):
+    """log_softmax(logits)[target] per row (utils.py:131-132) without materialising the log-softmax."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        lse, picked, _, _ = logsoftmax_rows(logits, target)
+        ctx.save_for_backward(logits, target, lse)
+        return picked
+
+    @staticmethod
+    def backward(ctx, dpicked):
+        logits, target, lse = ctx.saved_tensors
+        g = -torch.exp(logits - lse.unsqueeze(1)) * dpicked.unsqueeze(1)
+        g.scatter_add_(1, target.unsqueeze(1), dpicked.unsqueeze(1))
+        return g, None
+
+
+def nll_gather(logits, target):
+    if torch.is_grad_enabled() and logits.requires_grad:
+        return _NllGatherFn.apply(logits, target)
+    return logsoftmax_rows(logits.detach(), target)[1]
+
+
+class _MaskedLsmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, label):
+        loss, lse = masked_lsm_loss(x, label)
+        ctx.save_for_backward(x, label, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        x, label, lse = ctx.saved_tensors
+        N = x.shape[-1]
+        x2, l2 = x.reshape(-1, N), (label.reshape(-1, N) != 0).to(x.dtype)
+        cnt_row = l2.sum(1, keepdim=True)
+        total = cnt_row.sum()
+        g = (torch.exp(x2 - lse.unsqueeze(1)) * cnt_row - l2) * (dloss / total)
+        return g.view_as(x), None
+
+
+def masked_lsm(x, label):
+    """-mean(log_softmax(x,-1)[label != 0]); differentiable w.r.t. x when grad mode is on."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _MaskedLsmFn.apply(x, label)
+    return masked_lsm_loss(x.detach(), label)[0]

@@ -1,0 +1,224 @@
+/*
+ * gvd_hip.h — C-ABI of libgvd_hip.so: the MI355X (gfx950) kernels of the GVD decode/train hot path.
+ *
+ * The reference (facebookresearch/grounded-video-description) has no FFI: its hot path is a chain of
+ * implicit ATen ops behind the Python module API misc.AttModel.TopDownModel.  This
+ * library is what a maintainer binds (ctypes) to replace those ATen op chains.
+ * Every entry point cites the reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes + a hipStream_t; no torch types.  All floating point is fp32.
+ *   - the caller owns all memory (inputs, outputs, workspaces); the library never allocates or frees
+ *     device memory and keeps no state between calls: every function is re-entrant and may be called
+ *     concurrently from several host threads on different streams/devices (nn.DataParallel, main.py:655).
+ *   - return value: 0 on success, a hipError_t (> 0) when a launch failed, GVD_EINVAL (-1) when the
+ *     shapes/alignment are outside what the kernels support.  No exceptions cross the ABI.
+ *   - launches are asynchronous on `stream`; nothing synchronises with the host.
+ *   - row-major, innermost dimension contiguous; `ld*` are leading dimensions in ELEMENTS.
+ *   - masks are uint8 (0/1) exactly as the reference's dataloader produces them (dataloader_anet.py:336-354).
+ */
+#ifndef GVD_HIP_H
+#define GVD_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
+
+#define GVD_EINVAL (-1)
+#define GVD_MIN_VALUE (-1e8f) /* AttModel.py:31,66; model.py:71 */
+
+/* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded) */
+const char* gvd_version(void);
+int gvd_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel timing: pairs of HIP events recorded on the launch stream around the dominant kernel, so a
+ * benchmark can read that kernel's launch durations live over its timed region (bench.py `roofline`).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gvd_prof gvd_prof;
+gvd_prof* gvd_prof_create(int max_pairs);
+void gvd_prof_destroy(gvd_prof* p);
+void gvd_prof_reset(gvd_prof* p);
+/* call after synchronising the stream: sum of elapsed ms over the recorded pairs, and their count */
+int gvd_prof_read(gvd_prof* p, float* total_ms, int* count);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense projections (MFMA fp32, v_mfma_f32_32x32x2_f32: exact fp32 fma chains)
+ * ------------------------------------------------------------------------------------------- */
+
+/* One K-segment of a "NT" product: A[M,K] (lda) times W[N,K]^T (ldw).  K % 32 == 0, 16-B aligned. */
+typedef struct {
+  const float* A; int64_t lda; int64_t a_batch_stride;
+  const float* W; int64_t ldw; int64_t w_batch_stride;
+  int K;
+} gvd_gemm_seg;
+
+/* C[b][M,N] = act( sum_s A_s[b] W_s[b]^T + nbias[N] + nbias2[N] + mbias[M] + rowbias[b][M,N] ), then
+ * optional masked fill with GVD_MIN_VALUE where mask[b][m*mask_ldm + n] != 0.
+ * Replaces nn.Linear / torch.matmul call sites:
+ *   fc7 `ctx2pool_grd` + ReLU   model.py:158-161,312   (M=B*R, N=2048, K=2048, act=1)
+ *   `ctx2pool` / `ctx2att`      model.py:391,405       (N=512, K=1024)
+ *   `h2att`                     AttModel.py:39,77      (M=B, N=512(+512 stacked), K=1024)
+ *   `logit`                     model.py:464,615       (N=V, K=1024)
+ *   `_grounder` dot branch      model.py:262-278       (batched over B: A=vis words, W=g_pool[b])
+ */
+typedef struct {
+  gvd_gemm_seg seg[3]; int nseg;
+  const float* nbias;            /* [N] or NULL */
+  const float* nbias2;           /* [N] or NULL */
+  const float* mbias;            /* [M] or NULL; mbias_batch_stride elements between batches */
+  int64_t mbias_batch_stride;
+  const float* rowbias;          /* [M,N] (ld = rowbias_ld) or NULL */
+  int64_t rowbias_ld; int64_t rowbias_batch_stride;
+  const uint8_t* mask;           /* or NULL */
+  int64_t mask_ldm; int64_t mask_batch_stride;   /* mask_ldm may be 0 (broadcast over rows) */
+  float* C; int64_t ldc; int64_t c_batch_stride;
+  int M, N, batch;
+  int act;                       /* 0 = identity, 1 = ReLU */
+} gvd_gemm_args;
+
+int gvd_gemm_nt_f32(const gvd_gemm_args* args, gvd_stream_t stream);
+
+/* nn.LSTMCell forward (AttModel.py:121,123,139,160): gates = sum_s X_s W_s^T + b_ih + b_hh (+ rowbias),
+ * gate order i,f,g,o; c' = sig(f) c + sig(i) tanh(g); h' = sig(o) tanh(c').  The gate GEMM and the
+ * pointwise epilogue are one kernel.  `seg[s].W` points at the column block of weight_ih / weight_hh
+ * that multiplies X_s (all [4H, *] row-major), so concatenated inputs ([fc|xt], [att+att2|h_att]) never
+ * need to be materialised.  h_prev may alias nothing written here (h_out/c_out must be distinct buffers).
+ * gates_out (optional, [B,4H]): post-activation i,f,g,o kept for the backward pass. */
+typedef struct {
+  gvd_gemm_seg seg[3]; int nseg;
+  const float* b_ih; const float* b_hh;       /* [4H] each, or NULL */
+  const float* rowbias; int64_t rowbias_ld;   /* [B,4H] precomputed constant part (e.g. fc W_ih[:, :H]^T), or NULL */
+  const float* c_prev; int64_t ldc_prev;      /* [B,H] */
+  float* h_out; int64_t ldh;                  /* [B,H] */
+  float* c_out; int64_t ldc_out;              /* [B,H] */
+  float* gates_out; int64_t ldg;              /* [B,4H] or NULL */
+  int B, H;
+} gvd_lstm_args;
+
+int gvd_lstm_cell_fwd(const gvd_lstm_args* args, gvd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Additive visual attention (the HBM-bound north-star kernel)
+ * ------------------------------------------------------------------------------------------- */
+
+/* One attention "side": Attention2 over regions (AttModel.py:71-108) or Attention over frames
+ * (AttModel.py:33-53; masks NULL).
+ *   e[n] = w . tanh(p_feats[b,n,:] + q[b,:]) + *alpha_bias ; e[att_mask] = -1e8
+ *   alpha = softmax_n(e) ; ctx[b,:] = sum_n alpha[n] feats[b,n,:]
+ *   logits_out[b,n] = e[n] with [pnt_mask] = -1e8          (= `att2_weight`, pre-softmax)
+ */
+typedef struct {
+  const float* feats;    /* [B,N,H]  (att_feats / pool_feats / conv_feats) */
+  const float* p_feats;  /* [B,N,A]  (projected: p_pool_feats / p_conv_feats) */
+  const float* q; int64_t ldq;            /* [B,A] = h2att(h) incl. bias */
+  const float* w;                          /* [A]  alpha_net.weight */
+  const float* alpha_bias;                 /* device scalar alpha_net.bias */
+  const uint8_t* att_mask; int64_t ld_att_mask;   /* [B,N] or NULL */
+  const uint8_t* pnt_mask; int64_t ld_pnt_mask;   /* [B,N] or NULL */
+  float* logits_out; int64_t ld_logits;           /* [B,N] or NULL */
+  int N;
+} gvd_attn_side;
+
+/* Both attentions of one decoder step in one pass over HBM.
+ * out_sum[b,:] = ctx_region + ctx_temporal (the `att+att2` input of the language LSTM, AttModel.py:148);
+ * ctx_region / ctx_temporal (optional) receive the two contexts separately.  `temporal` may be NULL.
+ * Workspace: gvd_attn_workspace_bytes(B, Nr, Nt, H) bytes, 16-B aligned. */
+size_t gvd_attn_workspace_bytes(int B, int n_region, int n_temporal, int H);
+int gvd_attn_fwd(const gvd_attn_side* region, const gvd_attn_side* temporal, int B, int A, int H,
+                 float* out_sum, int64_t ld_out, float* ctx_region, float* ctx_temporal,
+                 void* workspace, gvd_stream_t stream);
+/* same, recording one event pair around the streaming (partial) kernel when prof != NULL */
+int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_side* temporal, int B, int A, int H,
+                      float* out_sum, int64_t ld_out, float* ctx_region, float* ctx_temporal,
+                      void* workspace, gvd_prof* prof, gvd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Vocabulary head
+ * ------------------------------------------------------------------------------------------- */
+
+/* Greedy token rule on one step's logits [B,V] (model.py:587-608): log_softmax, top-2, take the runner-up
+ * when the winner is UNK; writes token ids (int64) and their log-probs with the given strides (so they land
+ * in seq[:,t] / seqLogprobs[:,t]) and the next input embedding xt_next[b,:] = relu(embed[it[b],:])
+ * (model.py:79-82,605).  Ties resolve to the lowest index. */
+int gvd_logsoftmax_top2_embed(const float* logits, int64_t ld_logits, int B, int V, int unk_idx,
+                              int64_t* it_out, int64_t it_stride, float* lp_out, int64_t lp_stride,
+                              const float* embed, int E, float* xt_next, int64_t ld_xt,
+                              gvd_stream_t stream);
+
+/* xt[b,:] = relu(embed[it[b],:])   (model.py:79-82,428,605) */
+int gvd_embed_relu(const int64_t* it, int64_t it_stride, int B, const float* embed, int E,
+                   float* xt, int64_t ld_xt, gvd_stream_t stream);
+
+/* lse[row] = logsumexp(logits[row,:]);  optionally picked[row] = logits[row, target[row]] - lse[row]
+ * (= log_softmax gathered at the target: utils.py:131-132) and top-K (values as log-probs, indices) per row
+ * for beam search (CaptionModelBU.py:45,125).  target/picked/topk_* may be NULL. */
+int gvd_logsoftmax_rows(const float* logits, int64_t ld_logits, int rows, int V, float* lse,
+                        const int64_t* target, float* picked, int topk, float* topk_val, int64_t* topk_idx,
+                        gvd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole greedy decode: L x (embed, att-LSTM, 2 attentions, lang-LSTM, logit, token rule) on one stream,
+ * no host round trip per token (AttModel._sample, model.py:580-624, sample_max=1, beam_size=1).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  /* per-segment features from the preamble (model.py:504-568) */
+  const float* fc;      /* [B,H]   fc_embed output */
+  const float* conv;    /* [B,Ft,H] */
+  const float* p_conv;  /* [B,Ft,A] */
+  const float* pool;    /* [B,R,H] */
+  const float* p_pool;  /* [B,R,A] */
+  const uint8_t* pnt_mask; /* [B,R+1] (column 0 is the legacy pad, main.py:227) */
+  /* parameters (state_dict tensors) */
+  const float* embed;                                  /* embed.0.weight [V,E] */
+  const float *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh;    /* core.att_lstm.*  [4H,E+H],[4H,H] */
+  const float *lang_w_ih, *lang_w_hh, *lang_b_ih, *lang_b_hh; /* core.lang_lstm.* [4H,2H],[4H,H] */
+  const float *att1_h2att_w, *att1_h2att_b, *att1_alpha_w, *att1_alpha_b; /* core.attention.*  */
+  const float *att2_h2att_w, *att2_h2att_b, *att2_alpha_w, *att2_alpha_b; /* core.attention2.* */
+  const float *logit_w, *logit_b;                       /* logit.* [V,H] */
+  int B, Ft, R, H, A, E, V, L, unk_idx;
+  /* outputs */
+  int64_t* seq;        /* [B,L] */
+  float* seq_logprobs; /* [B,L] */
+  float* att2_weights; /* [B,L,R] masked pre-softmax logits */
+  void* workspace;     /* gvd_greedy_workspace_bytes(...) bytes */
+  gvd_prof* prof;      /* optional: times the attention streaming kernel of every step */
+} gvd_greedy_args;
+
+size_t gvd_greedy_workspace_bytes(int B, int Ft, int R, int H, int A, int E, int V);
+int gvd_greedy_decode(const gvd_greedy_args* args, gvd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training targets and losses
+ * ------------------------------------------------------------------------------------------- */
+
+/* IoU with the '+1' pixel convention, frame/proposal masking and the zero-area rules
+ * (utils.py:293-297 -> bbox_transform.py:224-269; mask = frm_mask | pnt_mask[:,1:], model.py:317-318).
+ * ppls [B,R,ppl_ld>=5], gt [B,K,gt_ld>=5], frm_mask u8 [B,R,K], pnt_mask u8 [B,R+1] -> overlaps f32 [B,R,K].
+ * Also sim_target i64 [B,K,R] = (IoU>0.5) * cls (utils.py:299-305) when non-NULL. */
+int gvd_iou_targets(const float* ppls, int ppl_ld, const float* gt, int gt_ld, const uint8_t* frm_mask,
+                    const uint8_t* pnt_mask, int B, int R, int K, float* overlaps, int64_t* sim_target,
+                    gvd_stream_t stream);
+
+/* Per-step region labels and frame masks for all Lc steps at once (utils.py:307-328; model.py:431-440):
+ * roi_labels f32 [B,Lc,R] = max_k(IoU * (mask_boxes[b,0,k,t+1]==0)) > 0.5
+ * frm_masks  u8  [B,Lc,R+1] = [0 | no selected box on this proposal's frame] | pnt_mask */
+int gvd_step_targets(const float* overlaps, const uint8_t* mask_boxes, const uint8_t* frm_mask,
+                     const uint8_t* pnt_mask, int B, int R, int K, int Lp1, int Lc, float* roi_labels,
+                     uint8_t* frm_masks, gvd_stream_t stream);
+
+/* sum and count of -log_softmax(x[row,:])[n] over entries with label[row,n] != 0 (utils.py:139,142):
+ * acc[0] += sum, acc[1] += count (fp32 atomics on a zeroed 2-float buffer); row_lse (optional) keeps
+ * each row's logsumexp for the backward. */
+int gvd_masked_lsm_loss(const float* x, int64_t ldx, const float* label, int64_t ld_label, int rows, int N,
+                        float* acc, float* row_lse, gvd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVD_HIP_H */

@@ -1,0 +1,177 @@
+"""-m gpu: every HIP kernel (called through the C-ABI wrappers) against the CPU oracle on seeded inputs.
+Integer / index / boolean outputs must be bit-exact; fp32 outputs within the stated tolerance."""
+import numpy as np
+import pytest
+import torch
+
+import gvd_amd
+from gvd_amd import hip, ops
+from oracle import gvd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def test_library_is_the_hip_one():
+    assert b'gfx950' in hip.lib().gvd_version()
+    assert hip.lib().gvd_abi_version() == 1
+
+
+def test_cpu_tensor_fails_loudly():
+    with pytest.raises(hip.GvdHipError):
+        ops.gemm_nt(torch.zeros(4, 32), torch.zeros(8, 32))
+
+
+@pytest.mark.parametrize('M,N,K,act', [(4, 1024, 1024, 0), (32, 4096, 1536, 0), (256, 5000, 1024, 0),
+                                       (70, 433, 2048, 1), (4000, 2048, 2048, 1), (640, 512, 1024, 0)])
+def test_gemm_nt(M, N, K, act):
+    g = _g(M + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + b.double()
+    if act:
+        ref = ref.clamp(min=0)
+    out = ops.gemm_nt(A.cuda(), W.cuda(), b.cuda(), act).cpu()
+    # asymmetric random operands: a transposed / mis-tiled result cannot pass
+    np.testing.assert_allclose(out.numpy(), ref.float().numpy(), rtol=1e-5, atol=2e-5)
+
+
+def test_grounder_batched_masked():
+    g = _g(5)
+    B, M, R, K = 3, 20, 1000, 2048
+    xt = torch.randn(B, M, K, generator=g) * 0.05
+    feats = torch.relu(torch.randn(B, R, K, generator=g))
+    mask = (torch.rand(B, M, R + 1, generator=g) < 0.3).to(torch.uint8)
+    mb = torch.randn(B, M, generator=g)
+    rb = torch.randn(B, M, R, generator=g)
+    ref = O.grounder_dot(xt, feats, mask[:, :, 1:], mb.unsqueeze(2) + rb)
+    out = ops.grounder_dot(xt.cuda(), feats.cuda(), mask.cuda()[:, :, 1:], mb.cuda(), rb.cuda()).cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
+    assert torch.equal(out == O.MIN_VALUE, mask[:, :, 1:].bool())
+    # shared xt (visual words), 2-D mask broadcast over rows, per-class bias
+    vis = torch.randn(433, K, generator=g) * 0.02
+    pm = (torch.rand(B, R + 1, generator=g) < 0.2).to(torch.uint8)
+    cb = torch.randn(433, generator=g)
+    ref = O.grounder_dot(vis.unsqueeze(0).expand(B, 433, K).contiguous(), feats, pm[:, 1:], cb.view(1, -1, 1))
+    out = ops.grounder_dot(vis.cuda(), feats.cuda(), pm.cuda()[:, 1:], cb.cuda(), None, xt_shared=True).cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('B', [4, 64, 200])
+def test_lstm_cell(B):
+    g = _g(B)
+    H, E = 1024, 512
+    W = {'c.weight_ih': torch.randn(4 * H, E + H, generator=g) / 32, 'c.weight_hh': torch.randn(4 * H, H, generator=g) / 32,
+         'c.bias_ih': torch.randn(4 * H, generator=g) * 0.1, 'c.bias_hh': torch.randn(4 * H, generator=g) * 0.1}
+    fc, xt = torch.randn(B, H, generator=g), torch.randn(B, E, generator=g)
+    h, c = torch.randn(B, H, generator=g) * 0.5, torch.randn(B, H, generator=g)
+    rh, rc = O.lstm_cell(torch.cat([fc, xt], 1), h, c, W, 'c')
+    d = {k: v.cuda() for k, v in W.items()}
+    gates = torch.empty(B, 4 * H, device='cuda')
+    oh, oc = ops.lstm_cell([fc.cuda(), xt.cuda()], [d['c.weight_ih'][:, :H], d['c.weight_ih'][:, H:]], h.cuda(),
+                           d['c.weight_hh'], d['c.bias_ih'], d['c.bias_hh'], c.cuda(), gates_out=gates)
+    np.testing.assert_allclose(oh.cpu().numpy(), rh.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(oc.cpu().numpy(), rc.numpy(), rtol=1e-5, atol=2e-6)
+    assert torch.isfinite(gates).all() and float(gates[:, :H].min()) >= 0.0      # i gate is a sigmoid
+
+
+@pytest.mark.parametrize('B,R,Ft', [(4, 1000, 10), (3, 1000, 480), (40, 1000, 10), (2, 37, 5)])
+def test_attention_step(B, R, Ft):
+    g = _g(B * R + Ft)
+    H, A = 1024, 512
+    opt = gvd_amd.opts.default_opt(vocab_size=10)
+    sd = gvd_amd.synth.init_state_dict(opt, seed=2, profile='trained_like')
+    h = torch.randn(B, H, generator=g) * 0.5
+    pool, p_pool = torch.randn(B, R, H, generator=g), torch.randn(B, R, A, generator=g)
+    conv, p_conv = torch.randn(B, Ft, H, generator=g), torch.randn(B, Ft, A, generator=g)
+    am = (torch.rand(B, R + 1, generator=g) < 0.2).to(torch.uint8)
+    pm = (torch.rand(B, R + 1, generator=g) < 0.5).to(torch.uint8) | am
+    if B > 2:
+        am[1, 1:] = 1        # fully masked sample: uniform softmax over -1e8 logits (SURVEY §7 masks)
+        pm[1, 1:] = 1
+    r_att = O.attention_temporal(h, conv, p_conv, sd)
+    r_att2, r_logits, r_q = O.attention_region(h, pool, p_pool, am[:, 1:], pm[:, 1:], sd)
+    dv = {k: v.cuda() for k, v in sd.items() if k.startswith('core.attention')}
+    q12 = ops.gemm_nt(h.cuda(), torch.cat([dv['core.attention.h2att.weight'], dv['core.attention2.h2att.weight']]),
+                      torch.cat([dv['core.attention.h2att.bias'], dv['core.attention2.h2att.bias']]))
+    np.testing.assert_allclose(q12[:, A:].cpu().numpy(), r_q.numpy(), rtol=1e-5, atol=1e-5)
+    logits = torch.empty(B, R, device='cuda')
+    amc, pmc = am.cuda(), pm.cuda()
+    region = dict(feats=pool.cuda(), p_feats=p_pool.cuda(), q=q12[:, A:], w=dv['core.attention2.alpha_net.weight'].view(-1),
+                  alpha_bias=dv['core.attention2.alpha_net.bias'], att_mask=amc[:, 1:], pnt_mask=pmc[:, 1:],
+                  logits_out=logits)
+    temporal = dict(feats=conv.cuda(), p_feats=p_conv.cuda(), q=q12[:, :A], w=dv['core.attention.alpha_net.weight'].view(-1),
+                    alpha_bias=dv['core.attention.alpha_net.bias'])
+    s, cr, ct = ops.attention_step(region, temporal, want_separate=True)
+    np.testing.assert_allclose(ct.cpu().numpy(), r_att.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(cr.cpu().numpy(), r_att2.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(s.cpu().numpy(), (r_att + r_att2).numpy(), rtol=1e-4, atol=4e-5)
+    np.testing.assert_allclose(logits.cpu().numpy(), r_logits.numpy(), rtol=1e-5, atol=2e-5)
+    assert torch.equal(logits.cpu() == O.MIN_VALUE, pm[:, 1:].bool())
+
+
+def test_top2_unk_rule_and_embed():
+    g = _g(9)
+    B, V, E, unk = 37, 5000, 512, 4999
+    logits = torch.randn(B, V, generator=g) * 3
+    logits[::3, unk] = 50.0                      # UNK wins in a third of the rows -> runner-up is taken
+    logits[5, 17] = logits[5, 1234] = 60.0       # exact tie: lowest index wins
+    emb = torch.randn(V, E, generator=g)
+    lp = torch.log_softmax(logits, 1)
+    v, i = lp.topk(2, 1)
+    keep = i[:, 0] != unk
+    it = torch.where(keep, i[:, 0], i[:, 1])
+    it[5] = 17
+    want_lp = lp.gather(1, it.view(-1, 1)).view(-1)
+    seq = torch.zeros(B, 20, dtype=torch.int64, device='cuda')
+    lps = torch.zeros(B, 20, device='cuda')
+    xt = torch.empty(B, E, device='cuda')
+    lg, em = logits.cuda(), emb.cuda()
+    rc = hip.lib().gvd_logsoftmax_top2_embed(hip.ptr(lg), V, B, V, unk, hip.ptr(seq[:, 3:]), 20, hip.ptr(lps[:, 3:]), 20,
+                                             hip.ptr(em), E, hip.ptr(xt), E, hip.stream_ptr())
+    assert rc == 0
+    assert torch.equal(seq[:, 3].cpu(), it)
+    np.testing.assert_allclose(lps[:, 3].cpu().numpy(), want_lp.numpy(), atol=2e-6)
+    assert torch.equal(xt.cpu(), torch.relu(emb[it]))
+    assert int(seq[:, :3].abs().sum()) == 0 and int(seq[:, 4:].abs().sum()) == 0   # strided writes only
+    # rows helper: lse / picked / top-k
+    tgt = torch.randint(0, V, (B,), generator=g)
+    lse, picked, tv, ti = ops.logsoftmax_rows(lg, tgt.cuda(), topk=5)
+    np.testing.assert_allclose(lse.cpu().numpy(), torch.logsumexp(logits, 1).numpy(), rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(picked.cpu().numpy(), lp.gather(1, tgt.view(-1, 1)).view(-1).numpy(), atol=1e-5)
+    rv, ri = lp.topk(5, 1)
+    rows = [r for r in range(B) if r != 5]
+    assert torch.equal(ti.cpu()[rows], ri[rows])
+    np.testing.assert_allclose(tv.cpu().numpy(), rv.numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize('B,seed', [(4, 1), (9, 2)])
+def test_box_targets_bit_exact(B, seed):
+    opt = gvd_amd.opts.default_opt(vocab_size=200)
+    inp = gvd_amd.synth.trim_to_batch(gvd_amd.synth.make_inputs(opt, B, seed=seed, train=True))
+    pm, fm = inp['pnt_mask'], inp['frm_mask']
+    ref_ov = O.bbox_overlaps(inp['ppls'], inp['gt_boxes'], fm | pm[:, 1:].unsqueeze(-1))
+    ref_st = O.sim_mat_target(ref_ov, inp['gt_boxes'][:, :, 5])
+    ov, st = ops.iou_targets(inp['ppls'].cuda(), inp['gt_boxes'].cuda(), fm.cuda(), pm.cuda())
+    assert torch.equal(ov.cpu(), ref_ov)            # same fp32 operation order -> bit-exact IoU
+    assert torch.equal(st.cpu(), ref_st)
+    Lc = 17
+    roi, fms = ops.step_targets(ov, inp['mask_boxes'].cuda(), fm.cuda(), pm.cuda(), Lc)
+    for t in range(Lc):
+        assert torch.equal(roi[:, t].cpu(), O.roi_labels_for_step(inp['mask_boxes'][:, :, :, t + 1], ref_ov))
+        assert torch.equal(fms[:, t].cpu(), O.frame_mask_for_step(inp['mask_boxes'][:, 0, :, t + 1], fm, pm))
+    assert float(roi.sum()) > 0                     # positives exist (GT boxes are jittered proposals)
+
+
+def test_masked_lsm_loss():
+    g = _g(3)
+    x = torch.randn(6, 20, 1000, generator=g) * 4
+    x[x > 6] = O.MIN_VALUE
+    lab = (torch.rand(6, 20, 1000, generator=g) < 0.002).float()
+    ref = -torch.masked_select(torch.log_softmax(x, 2), lab.bool()).mean()
+    out, _ = ops.masked_lsm_loss(x.cuda(), lab.cuda())
+    assert abs(float(out) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))

@@ -41,24 +41,39 @@ def parse():
 
 
 def cpu_baseline(opt, sd, seconds):
-    """The oracle (CPU port of the reference path) on BASELINE configs[0]: B=4 greedy, same shapes."""
+    """The oracle (CPU port of the reference path) on BASELINE configs[0]: B=4 greedy, same shapes.
+    torch's default of one thread per hardware thread is pathologically slow on many-core hosts for these
+    small ops, so a few thread counts are tried (one call each) and the fastest is used and reported."""
     from gvd_amd import synth
     from oracle import gvd_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
     inp = synth.make_inputs(opt, 4, seed=0, train=False)
     a = [inp[k] for k in ('segs_feat', 'num', 'ppls', 'ppls_feat', 'sample_idx', 'pnt_mask')]
+    ncpu = os.cpu_count() or 1
+    best = None
     with torch.no_grad():
-        O.sample_greedy(sd, opt, *a)      # warm-up
+        for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):
+            torch.set_num_threads(nt)
+            O.sample_greedy(sd, opt, *a)      # warm-up at this thread count
+            t0 = time.time()
+            O.sample_greedy(sd, opt, *a)
+            dt = time.time() - t0
+            if best is None or dt < best[1]:
+                best = (nt, dt)
+            if dt > 20.0:
+                break
+        torch.set_num_threads(best[0])
         n, t0 = 0, time.time()
         while True:
             O.sample_greedy(sd, opt, *a)
             n += 1
-            if time.time() - t0 >= seconds and n >= 3:
+            if time.time() - t0 >= seconds or n >= 200:
                 break
         dt = time.time() - t0
-    return {'value': round(4 * n / dt, 3), 'unit': 'captions/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+    return {'value': round(4 * n / dt, 3), 'unit': 'captions/s', 'cores': best[0], 'kind': 'port',
+            'host_cpus': ncpu,
             'sample': '%d greedy sample() calls of B=4 (L=20, 10x100 regions, Ft=%d, V=%d) with oracle/gvd_oracle.py '
-                      '(torch-CPU restatement pinned bit-for-bit to the reference), %.1f s' % (n, opt.t_attn_size, opt.vocab_size, dt)}
+                      '(torch-CPU restatement pinned bit-for-bit to the reference), %.1f s, best of 8/16/32/64 threads'
+                      % (n, opt.t_attn_size, opt.vocab_size, dt)}
 
 
 def main():

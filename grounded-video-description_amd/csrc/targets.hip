@@ -13,6 +13,7 @@ namespace {
 __global__ void iou_kernel(const float* __restrict__ ppls, int ppl_ld, const float* __restrict__ gt, int gt_ld,
                            const uint8_t* __restrict__ frm_mask, const uint8_t* __restrict__ pnt_mask, int B, int R,
                            int K, float* __restrict__ overlaps, int64_t* __restrict__ sim_target) {
+#pragma clang fp contract(off)   // the reference rounds every product/sum separately: no fma fusion here
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)B * R * K) return;
   const int k = idx % K;

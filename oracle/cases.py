@@ -41,18 +41,29 @@ def build_case(name):
     return opt, sd, inp
 
 
+def _bits_checksum(t):
+    """Exact, order-independent checksum: the tensor's raw 32/64-bit words summed as int64 (wraps mod 2^64)."""
+    t = t.contiguous()
+    if t.dtype in (torch.float32, torch.int32):
+        w = t.view(torch.int32).to(torch.int64)
+    elif t.dtype in (torch.float64, torch.int64):
+        w = t.view(torch.int64)
+    else:
+        w = t.to(torch.int64)
+    idx = torch.arange(1, w.numel() + 1, dtype=torch.int64).view(w.shape) if w.numel() else w
+    return int((w * (idx % 8191 + 1)).sum()) if w.numel() else 0
+
+
 def weight_fingerprint(sd):
-    """Order-independent float64 checksum proving both boxes regenerated identical weights."""
-    tot = 0.0
+    """Integer checksum proving both boxes regenerated bit-identical weights from the seed."""
+    tot = 0
     for k in sorted(sd):
-        v = sd[k]
-        if v.is_floating_point():
-            tot += float(v.double().abs().sum()) + 3.0 * float(v.double().sum())
+        tot = (tot * 1000003 + _bits_checksum(sd[k])) % (1 << 61)
     return tot
 
 
 def input_fingerprint(inp):
-    tot = 0.0
+    tot = 0
     for k in sorted(inp):
-        tot += float(inp[k].double().sum()) + 0.5 * float(inp[k].double().abs().sum())
+        tot = (tot * 1000003 + _bits_checksum(inp[k])) % (1 << 61)
     return tot

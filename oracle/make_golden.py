@@ -10,7 +10,7 @@ What is stored per case (all produced by the reference model, eval mode, CPU fp3
   MLE:    losses f32[4] (lm, att2, ground, cls); for B<=8 also grad_norms (per-parameter L2 norm of the
           gradient of lm + w_att2*att2 + w_grd*ground + w_cls*cls, cases.GRAD_WEIGHTS)
   GRD:    cls_pred i64[N,2], att2_ind i16[B,Lc,T], grd_ind i16[B,Lc,T]
-plus weight/input fingerprints (float64 checksums) so a consumer can prove it regenerated the
+plus weight/input fingerprints (exact integer checksums of the raw bits) so a consumer can prove it regenerated the
 identical weights and inputs from the seeds.
 """
 import os
@@ -34,8 +34,8 @@ def run_case(name):
     need_grad = spec['mode'] == 'MLE' and spec['B'] <= 8
     ref = ref_harness.build_reference_model(opt, sd, need_grad=need_grad).eval()
     args = pkg.synth.as_args(inp)
-    out = dict(weight_fp=np.float64(cases.weight_fingerprint(sd)),
-               input_fp=np.float64(cases.input_fingerprint(inp)),
+    out = dict(weight_fp=np.int64(cases.weight_fingerprint(sd)),
+               input_fp=np.int64(cases.input_fingerprint(inp)),
                torch_version=np.array(torch.__version__))
     t0 = time.time()
     if spec['mode'] == 'sample':

@@ -29,8 +29,8 @@ def _model(opt, sd):
 def _case(name, golden_dir):
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     opt, sd, inp = cases.build_case(name)
-    assert cases.weight_fingerprint(sd) == float(g['weight_fp'])
-    assert cases.input_fingerprint(inp) == float(g['input_fp'])
+    assert cases.weight_fingerprint(sd) == int(g['weight_fp'])
+    assert cases.input_fingerprint(inp) == int(g['input_fp'])
     return g, opt, sd, inp
 
 

@@ -74,8 +74,9 @@ def test_lstm_cell(B):
     gates = torch.empty(B, 4 * H, device='cuda')
     oh, oc = ops.lstm_cell([fc.cuda(), xt.cuda()], [d['c.weight_ih'][:, :H], d['c.weight_ih'][:, H:]], h.cuda(),
                            d['c.weight_hh'], d['c.bias_ih'], d['c.bias_hh'], c.cuda(), gates_out=gates)
-    np.testing.assert_allclose(oh.cpu().numpy(), rh.numpy(), rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(oc.cpu().numpy(), rc.numpy(), rtol=1e-5, atol=2e-6)
+    # K = 2560-term fp32 dot products in a different summation order than oneDNN: few-ulp differences
+    np.testing.assert_allclose(oh.cpu().numpy(), rh.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(oc.cpu().numpy(), rc.numpy(), rtol=1e-5, atol=1e-5)
     assert torch.isfinite(gates).all() and float(gates[:, :H].min()) >= 0.0      # i gate is a sigmoid
 
 

@@ -22,8 +22,8 @@ def _load(golden_dir, name):
 def _build(name, g):
     opt, sd, inp = cases.build_case(name)
     # identical weights/inputs as the box that generated the fixture
-    assert cases.weight_fingerprint(sd) == float(g['weight_fp'])
-    assert cases.input_fingerprint(inp) == float(g['input_fp'])
+    assert cases.weight_fingerprint(sd) == int(g['weight_fp'])
+    assert cases.input_fingerprint(inp) == int(g['input_fp'])
     return opt, sd, inp
 
 

@@ -1,0 +1,63 @@
+"""Summarise rocprofv3 output directories into small text/JSON files for profiles/.
+
+  python tools/parse_rocprof.py stats <dir> <out.md> [title]     # --kernel-trace --stats run
+  python tools/parse_rocprof.py pmc <dir> <kernel-substr> <out.json> <COUNTER> [<COUNTER>...]
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(d, pattern):
+    return sorted(glob.glob(os.path.join(d, '**', pattern), recursive=True))
+
+
+def stats(d, out, title):
+    files = find(d, '*kernel_stats.csv')
+    rows = []
+    for f in files:
+        with open(f) as fh:
+            rows += list(csv.DictReader(fh))
+    if not rows:   # fall back to the raw trace
+        agg = defaultdict(lambda: [0, 0.0])
+        for f in find(d, '*kernel_trace.csv'):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    k = r.get('Kernel_Name') or r.get('Name')
+                    dur = float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+                    agg[k][0] += 1
+                    agg[k][1] += dur
+        rows = [{'Name': k, 'Calls': v[0], 'TotalDurationNs': v[1], 'AverageNs': v[1] / v[0]} for k, v in agg.items()]
+    tot = sum(float(r['TotalDurationNs']) for r in rows) or 1.0
+    rows.sort(key=lambda r: -float(r['TotalDurationNs']))
+    with open(out, 'w') as fh:
+        fh.write('# %s\n\nrocprofv3 --kernel-trace --stats; total GPU kernel time %.3f ms; top kernels:\n\n' % (title, tot / 1e6))
+        fh.write('| kernel | calls | total ms | avg us | %% |\n|---|---|---|---|---|\n')
+        for r in rows[:40]:
+            fh.write('| `%s` | %s | %.3f | %.2f | %.1f |\n' % (r['Name'][:110], r['Calls'], float(r['TotalDurationNs']) / 1e6,
+                                                           float(r['AverageNs']) / 1e3, 100 * float(r['TotalDurationNs']) / tot))
+    print(open(out).read()[:3000])
+
+
+def pmc(d, substr, out, counters):
+    vals = defaultdict(list)
+    for f in find(d, '*counter_collection.csv'):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if substr in r.get('Kernel_Name', '') and r.get('Counter_Name') in counters:
+                    vals[r['Counter_Name']].append(float(r['Counter_Value']))
+    res = {c: {'n': len(v), 'mean': (sum(v) / len(v) if v else None), 'min': min(v) if v else None,
+               'max': max(v) if v else None} for c, v in vals.items()}
+    with open(out, 'w') as fh:
+        json.dump({'kernel': substr, 'counters': res}, fh, indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'stats':
+        stats(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else 'kernel stats')
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5:])

@@ -31,7 +31,9 @@ __global__ void iou_kernel(const float* __restrict__ ppls, int ppl_ld, const flo
   // no fp contraction: the reference evaluates (a_area + g_area) - iw*ih and (iw*ih)/ua with separate roundings
   const float inter = __fmul_rn(iw, ih);
   const float ua = __fsub_rn(__fadd_rn(a_area, g_area), inter);
-  float ov = __fdiv_rn(inter, ua);
+  // fp32 '/' on gfx950 is not correctly rounded by default; an fp64 divide rounded to fp32 is
+  // (53 >= 2*24+2 bits), which is what the CPU reference computes.
+  float ov = (float)((double)inter / (double)ua);
   const bool masked = frm_mask[idx] | pnt_mask[(int64_t)b * (R + 1) + 1 + r];
   ov = ov * (masked ? 0.f : 1.f);
   if (gx == 1.f && gy == 1.f) ov = 0.f;

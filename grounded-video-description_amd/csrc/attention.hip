@@ -34,6 +34,7 @@ struct SideDev {
   const uint8_t* att_mask; int64_t ld_att_mask;
   const uint8_t* pnt_mask; int64_t ld_pnt_mask;
   float* logits_out; int64_t ld_logits;
+  float* scores_out; int64_t ld_scores;
   int N, chunk, nchunks;
 };
 
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   const uint8_t* am = S.att_mask ? S.att_mask + (int64_t)b * S.ld_att_mask + n0 : nullptr;
   const uint8_t* pm = S.pnt_mask ? S.pnt_mask + (int64_t)b * S.ld_pnt_mask + n0 : nullptr;
   float* lo = S.logits_out ? S.logits_out + (int64_t)b * S.ld_logits + n0 : nullptr;
+  float* so = S.scores_out ? S.scores_out + (int64_t)b * S.ld_scores + n0 : nullptr;
 
   for (int r = wave * 2; r < rows; r += 8) {
     const bool two = (r + 1) < rows;
@@ -92,10 +94,12 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
     if (lane == 0) {
       float e0 = (am && am[r]) ? GVD_MIN_VALUE : s0;
       s_score[r] = e0;
+      if (so) so[r] = e0;
       if (lo) lo[r] = (pm && pm[r]) ? GVD_MIN_VALUE : e0;
       if (two) {
         float e1 = (am && am[r + 1]) ? GVD_MIN_VALUE : s1;
         s_score[r + 1] = e1;
+        if (so) so[r + 1] = e1;
         if (lo) lo[r + 1] = (pm && pm[r + 1]) ? GVD_MIN_VALUE : e1;
       }
     }
@@ -200,7 +204,8 @@ void fill_side(SideDev& d, const gvd_attn_side* s, int B) {
   d.feats = s->feats; d.p_feats = s->p_feats; d.q = s->q; d.ldq = s->ldq; d.w = s->w;
   d.alpha_bias = s->alpha_bias; d.att_mask = s->att_mask; d.ld_att_mask = s->ld_att_mask;
   d.pnt_mask = s->pnt_mask; d.ld_pnt_mask = s->ld_pnt_mask; d.logits_out = s->logits_out;
-  d.ld_logits = s->ld_logits; d.N = s->N; d.chunk = pick_chunk(s->N, B);
+  d.ld_logits = s->ld_logits; d.scores_out = s->scores_out; d.ld_scores = s->ld_scores;
+  d.N = s->N; d.chunk = pick_chunk(s->N, B);
   d.nchunks = (s->N + d.chunk - 1) / d.chunk;
 }
 

@@ -1,0 +1,127 @@
+"""Hand-scheduled BPTT of the teacher-forced decoder loop as ONE autograd.Function.
+
+Forward = decoder_fn.forward_loop (HIP kernels), keeping only O(B*H) state per step (gates, cell states,
+queries, attention scores/contexts).  Backward walks the steps in reverse:
+  * pointwise LSTM backward kernel, dX GEMMs (library GEMMs) for the recurrent/input gradients;
+  * per step and attention side ONE streaming pass over feats/p_feats (gvd_attn_bwd_step) that recomputes
+    tanh, applies the softmax/mask backward and yields de[n], d_q, d_w, d_alpha_bias;
+  * after the loop, the gradients w.r.t. the big per-segment tensors are formed ONCE for all steps:
+    d_pool/d_conv = alpha^T d_ctx (batched GEMM), d_p_pool/d_p_conv by gvd_attn_bwd_pfeats, and every weight
+    gradient as one GEMM over the stacked [Lc*B, .] activations.
+Reference semantics: autograd through AttModel.py:134-164 x Lc (model.py:421-453).
+"""
+import torch
+
+from . import decoder_fn
+
+
+class DecoderLoopFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, att_mask, pnt_masks, keys, fc, conv, p_conv, pool, p_pool, xt_all, *params):
+        P = dict(zip(keys, params))
+        save = {}
+        h_all, att2_w = decoder_fn.forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks,
+                                                save=save)
+        ctx.keys = keys
+        ctx.save = save
+        ctx.masks = (att_mask, pnt_masks)
+        ctx.save_for_backward(fc, conv, p_conv, pool, p_pool, xt_all, *params)
+        return h_all, att2_w
+
+    @staticmethod
+    def backward(ctx, d_h_all, d_att2w):
+        K = decoder_fn.K
+        fc, conv, p_conv, pool, p_pool, xt_all = ctx.saved_tensors[:6]
+        P = dict(zip(ctx.keys, ctx.saved_tensors[6:]))
+        S = ctx.save
+        att_mask, pnt_masks = ctx.masks
+        B, Lc, E = xt_all.shape
+        H = fc.shape[1]
+        A = p_pool.shape[2]
+        R, Ft = pool.shape[1], conv.shape[1]
+        dev = fc.device
+        per_step_mask = pnt_masks.dim() == 3
+        am = att_mask[:, 1:]
+        w_stack = S['w_stack']
+        a1_aw, a2_aw = P['a1_aw'].reshape(-1), P['a2_aw'].reshape(-1)
+        alpha_r = torch.softmax(S['scores_r'], dim=-1)          # [B,Lc,R]
+        alpha_t = torch.softmax(S['scores_t'], dim=-1)          # [B,Lc,Ft]
+        if d_h_all is None:
+            d_h_all = torch.zeros(B, Lc, H, device=dev, dtype=fc.dtype)
+        dG_lang = torch.empty(Lc, B, 4 * H, device=dev, dtype=fc.dtype)
+        dG_att = torch.empty(Lc, B, 4 * H, device=dev, dtype=fc.dtype)
+        dq12_all = torch.empty(Lc, B, 2 * A, device=dev, dtype=fc.dtype)
+        dctx_all = torch.empty(Lc, B, H, device=dev, dtype=fc.dtype)
+        de_r_all = torch.empty(Lc, B, R, device=dev, dtype=fc.dtype)
+        de_t_all = torch.empty(Lc, B, Ft, device=dev, dtype=fc.dtype)
+        dw_r = torch.zeros(A, device=dev, dtype=fc.dtype); dw_t = torch.zeros(A, device=dev, dtype=fc.dtype)
+        dab_r = torch.zeros(1, device=dev, dtype=fc.dtype); dab_t = torch.zeros(1, device=dev, dtype=fc.dtype)
+        dh_att_next = dh_lang_next = None
+        dc_att_next = dc_lang_next = None
+        w_lang_ih, w_lang_hh, w_att_hh = P['lang_w_ih'], P['lang_w_hh'], P['att_w_hh']
+        for t in range(Lc - 1, -1, -1):
+            dh_lang = d_h_all[:, t] if dh_lang_next is None else d_h_all[:, t] + dh_lang_next
+            dg, dc_lang_next = K.lstm_cell_bwd(dh_lang, dc_lang_next, S['gates_lang'][t], S['c_lang'][t], S['c_lang'][t + 1])
+            dG_lang[t].copy_(dg)
+            dX = dg @ w_lang_ih                                  # [B,2H] = [d(att+att2) | d h_att]
+            dh_lang_next = dg @ w_lang_hh
+            d_att_sum = dX[:, :H].contiguous()
+            dctx_all[t].copy_(d_att_sum)
+            pmask = (pnt_masks[:, t] if per_step_mask else pnt_masks)[:, 1:]
+            q12 = S['q12'][t]
+            region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P['a2_ab'], att_mask=am,
+                          pnt_mask=pmask)
+            temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab'])
+            dl = d_att2w[:, t] if d_att2w is not None else None
+            de_r, dq_r, dwr, dabr = K.attn_bwd_step(region, alpha_r[:, t], S['ctx_r'][t], d_att_sum, dl)
+            de_t, dq_t, dwt, dabt = K.attn_bwd_step(temporal, alpha_t[:, t], S['ctx_t'][t], d_att_sum, None)
+            de_r_all[t].copy_(de_r); de_t_all[t].copy_(de_t)
+            dw_r += dwr.sum(0); dw_t += dwt.sum(0); dab_r += dabr.sum(); dab_t += dabt.sum()
+            dq12 = torch.cat([dq_t, dq_r], dim=1)
+            dq12_all[t].copy_(dq12)
+            dh_att = dX[:, H:] + dq12 @ w_stack
+            if dh_att_next is not None:
+                dh_att = dh_att + dh_att_next
+            dg, dc_att_next = K.lstm_cell_bwd(dh_att, dc_att_next, S['gates_att'][t], S['c_att'][t], S['c_att'][t + 1])
+            dG_att[t].copy_(dg)
+            dh_att_next = dg @ w_att_hh
+
+        # ---- gradients formed once for all steps
+        dGa = dG_att.view(Lc * B, 4 * H)
+        dGl = dG_lang.view(Lc * B, 4 * H)
+        xt_flat = xt_all.transpose(0, 1).reshape(Lc * B, E)
+        h_att_prev = S['h_att'][:Lc].reshape(Lc * B, H)
+        h_att_new = S['h_att'][1:].reshape(Lc * B, H)
+        h_lang_prev = S['h_lang'][:Lc].reshape(Lc * B, H)
+        att_sum = S['att_sum'].view(Lc * B, H)
+        w_att_ih = P['att_w_ih']
+        sumG = dG_att.sum(0)                                     # [B,4H]: the fc part of the input is loop invariant
+        g = {}
+        g['fc'] = sumG @ w_att_ih[:, :H]
+        g['xt_all'] = (dGa @ w_att_ih[:, H:]).view(Lc, B, E).transpose(0, 1).contiguous()
+        g['att_w_ih'] = torch.cat([sumG.t() @ fc, dGa.t() @ xt_flat], dim=1)
+        g['att_w_hh'] = dGa.t() @ h_att_prev
+        g['att_b_ih'] = dGa.sum(0)
+        g['att_b_hh'] = g['att_b_ih']
+        g['lang_w_ih'] = torch.cat([dGl.t() @ att_sum, dGl.t() @ h_att_new], dim=1)
+        g['lang_w_hh'] = dGl.t() @ h_lang_prev
+        g['lang_b_ih'] = dGl.sum(0)
+        g['lang_b_hh'] = g['lang_b_ih']
+        dq_flat = dq12_all.view(Lc * B, 2 * A)
+        d_wstack = dq_flat.t() @ h_att_new                       # [2A,H]
+        d_bstack = dq_flat.sum(0)
+        g['a1_w'], g['a2_w'] = d_wstack[:A], d_wstack[A:]
+        g['a1_b'], g['a2_b'] = d_bstack[:A], d_bstack[A:]
+        g['a1_aw'], g['a2_aw'] = dw_t.view(1, A), dw_r.view(1, A)
+        g['a1_ab'], g['a2_ab'] = dab_t, dab_r
+        dctx_b = dctx_all.transpose(0, 1)                        # [B,Lc,H]
+        g['pool'] = torch.bmm(alpha_r.transpose(1, 2), dctx_b)   # [B,R,H]
+        g['conv'] = torch.bmm(alpha_t.transpose(1, 2), dctx_b)
+        g['p_pool'] = K.attn_bwd_pfeats(p_pool, S['q12'][:, :, A:], de_r_all, a2_aw)
+        g['p_conv'] = K.attn_bwd_pfeats(p_conv, S['q12'][:, :, :A], de_t_all, a1_aw)
+        ctx.save = None
+        names = ['fc', 'conv', 'p_conv', 'pool', 'p_pool', 'xt_all'] + list(ctx.keys)
+        out = [None, None, None]
+        for i, n in enumerate(names):
+            out.append(g[n] if ctx.needs_input_grad[3 + i] else None)
+        return tuple(out)

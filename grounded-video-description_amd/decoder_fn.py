@@ -10,6 +10,8 @@ import torch
 
 from . import ops
 
+K = ops   # kernel backend (the HIP library); tests substitute a torch stand-in to check the BPTT algebra on CPU
+
 
 def _params(model):
     c = model.core
@@ -37,39 +39,42 @@ def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks,
     b_stack = torch.cat([P['a1_b'], P['a2_b']], 0)
     a1_aw, a2_aw = P['a1_aw'].reshape(-1), P['a2_aw'].reshape(-1)
     # loop-invariant part of the att-LSTM gates: fc W_ih[:, :H]^T + b_ih + b_hh
-    fc_gates = ops.gemm_nt(fc, w_ih_fc, P['att_b_ih']) + P['att_b_hh']
-    h_att = torch.zeros(B, H, device=dev); c_att = torch.zeros(B, H, device=dev)
-    h_lang = torch.zeros(B, H, device=dev); c_lang = torch.zeros(B, H, device=dev)
-    h_all = torch.empty(B, Lc, H, device=dev)
-    att2_w = torch.empty(B, Lc, R, device=dev)
+    fc_gates = K.gemm_nt(fc, w_ih_fc, P['att_b_ih']) + P['att_b_hh']
+    h_att = torch.zeros(B, H, device=dev, dtype=fc.dtype); c_att = torch.zeros(B, H, device=dev, dtype=fc.dtype)
+    h_lang = torch.zeros(B, H, device=dev, dtype=fc.dtype); c_lang = torch.zeros(B, H, device=dev, dtype=fc.dtype)
+    h_all = torch.empty(B, Lc, H, device=dev, dtype=fc.dtype)
+    att2_w = torch.empty(B, Lc, R, device=dev, dtype=fc.dtype)
     am = att_mask[:, 1:]
     per_step_mask = pnt_masks.dim() == 3
     if save is not None:
-        save.update(gates_att=torch.empty(Lc, B, 4 * H, device=dev), gates_lang=torch.empty(Lc, B, 4 * H, device=dev),
-                    c_att=torch.empty(Lc + 1, B, H, device=dev), c_lang=torch.empty(Lc + 1, B, H, device=dev),
-                    h_att=torch.empty(Lc + 1, B, H, device=dev), h_lang=torch.empty(Lc + 1, B, H, device=dev),
-                    q12=torch.empty(Lc, B, 2 * A, device=dev), att_sum=torch.empty(Lc, B, H, device=dev),
-                    ctx_r=torch.empty(Lc, B, H, device=dev), ctx_t=torch.empty(Lc, B, H, device=dev),
+        save.update(gates_att=torch.empty(Lc, B, 4 * H, device=dev, dtype=fc.dtype), gates_lang=torch.empty(Lc, B, 4 * H, device=dev, dtype=fc.dtype),
+                    c_att=torch.empty(Lc + 1, B, H, device=dev, dtype=fc.dtype), c_lang=torch.empty(Lc + 1, B, H, device=dev, dtype=fc.dtype),
+                    h_att=torch.empty(Lc + 1, B, H, device=dev, dtype=fc.dtype), h_lang=torch.empty(Lc + 1, B, H, device=dev, dtype=fc.dtype),
+                    q12=torch.empty(Lc, B, 2 * A, device=dev, dtype=fc.dtype), att_sum=torch.empty(Lc, B, H, device=dev, dtype=fc.dtype),
+                    ctx_r=torch.empty(Lc, B, H, device=dev, dtype=fc.dtype), ctx_t=torch.empty(Lc, B, H, device=dev, dtype=fc.dtype),
+                    scores_r=torch.empty(B, Lc, R, device=dev, dtype=fc.dtype), scores_t=torch.empty(B, Lc, conv.shape[1], device=dev, dtype=fc.dtype),
                     w_stack=w_stack)
         for k in ('c_att', 'c_lang', 'h_att', 'h_lang'):
             save[k][0].zero_()
     for t in range(Lc):
         xt = xt_all[:, t]
         g_att = save['gates_att'][t] if save is not None else None
-        h_att, c_att = ops.lstm_cell([xt], [w_ih_xt], h_att, P['att_w_hh'], None, None, c_att,
+        h_att, c_att = K.lstm_cell([xt], [w_ih_xt], h_att, P['att_w_hh'], None, None, c_att,
                                      rowbias=fc_gates, gates_out=g_att)
-        q12 = ops.gemm_nt(h_att, w_stack, b_stack, out=save['q12'][t] if save is not None else None)
+        q12 = K.gemm_nt(h_att, w_stack, b_stack, out=save['q12'][t] if save is not None else None)
         pmask = (pnt_masks[:, t] if per_step_mask else pnt_masks)[:, 1:]
         region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P['a2_ab'], att_mask=am,
                       pnt_mask=pmask, logits_out=att2_w[:, t])
         temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab'])
         if save is not None:
-            att_sum, cr, ct = ops.attention_step(region, temporal, want_separate=True)
+            region['scores_out'] = save['scores_r'][:, t]
+            temporal['scores_out'] = save['scores_t'][:, t]
+            att_sum, cr, ct = K.attention_step(region, temporal, want_separate=True)
             save['ctx_r'][t].copy_(cr); save['ctx_t'][t].copy_(ct); save['att_sum'][t].copy_(att_sum)
         else:
-            att_sum = ops.attention_step(region, temporal)
+            att_sum = K.attention_step(region, temporal)
         g_lang = save['gates_lang'][t] if save is not None else None
-        h_lang, c_lang = ops.lstm_cell([att_sum, h_att], [w_ih_att, w_ih_h], h_lang, P['lang_w_hh'],
+        h_lang, c_lang = K.lstm_cell([att_sum, h_att], [w_ih_att, w_ih_h], h_lang, P['lang_w_hh'],
                                        P['lang_b_ih'], P['lang_b_hh'], c_lang, gates_out=g_lang)
         h_all[:, t].copy_(h_lang)
         if save is not None:

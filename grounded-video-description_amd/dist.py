@@ -1,0 +1,136 @@
+"""Batch data parallelism: one process per GPU, RCCL all-reduce of gradients over xGMI.
+
+Replaces the reference's single-process nn.DataParallel (main.py:654-655), which every step broadcasts
+all parameters from GPU0, scatters the inputs from GPU0, and reduces all gradients back to GPU0
+(SURVEY.md §2.3 C1-C4).  Here replicas are persistent (no weight broadcast after construction), each rank
+reads its own shard of segments, and the only collective is a bucketed gradient all-reduce that is
+launched from autograd hooks as soon as a bucket's gradients exist, so it overlaps the rest of backward.
+
+Semantics: the reference's DP loss is the mean over replicas of per-replica masked
+means (main.py:239-255), so averaging per-rank gradients (sum, then / world) reproduces it exactly.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is per-link bound, so buckets are
+large (default 64 MiB: ~275 MB of fp32 gradients -> 5 collectives) rather than many small ones.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/LOCAL_RANK (torch.distributed.run); no-op for 1 rank."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'   # 'nccl' is RCCL on ROCm
+        kw = {}
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            kw['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def broadcast_parameters(module, src=0):
+    """One-time sync of the replicas (instead of DataParallel's per-forward broadcast)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
+class GradAllReducer:
+    """Bucketed, backward-overlapped gradient averaging for a replica.
+
+    Parameters are packed into flat buckets in REVERSE registration order (gradients of late layers are
+    produced first).  A post-accumulate-grad hook marks a parameter ready; when a bucket is complete its
+    gradients are copied into the flat buffer and an async all-reduce is issued.  `finish()` waits for all
+    buckets, divides by the world size and scatters the averages back into `.grad`.  Parameters that
+    received no gradient this step (the unused core.i2h_2/h2h_2, AttModel.py:130-131) contribute zeros, so
+    all ranks always issue identical collectives.
+    """
+
+    def __init__(self, module, bucket_mb=64, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.buckets = []          # list of dict(params, offsets, numel, flat)
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        cur, cur_n = [], 0
+        for p in reversed(self.params):
+            if cur and cur_n + p.numel() > cap:
+                self._close(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self._close(cur)
+        self.where = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b['params']:
+                self.where[id(p)] = bi
+        self._handles = []
+        self._hooks = []
+        if self.world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.reset()
+
+    def _close(self, params):
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += p.numel()
+        p0 = params[0]
+        self.buckets.append(dict(params=params, offsets=offs, numel=n,
+                                 flat=torch.zeros(n, dtype=p0.dtype, device=p0.device)))
+
+    def reset(self):
+        self._pending = [len(b['params']) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+
+    def _launch(self, bi):
+        b = self.buckets[bi]
+        flat = b['flat']
+        for p, o in zip(b['params'], b['offsets']):
+            if p.grad is None:
+                flat[o:o + p.numel()].zero_()
+            else:
+                flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
+        self._handles.append((bi, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        self._launched[bi] = True
+
+    def _on_grad(self, p):
+        bi = self.where[id(p)]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0 and not self._launched[bi]:
+            self._launch(bi)
+
+    def finish(self):
+        """Call after loss.backward(): completes every bucket and writes the averaged gradients back."""
+        if self.world == 1:
+            return
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:          # buckets holding parameters that got no gradient
+                self._launch(bi)
+        for bi, h in self._handles:
+            h.wait()
+            b = self.buckets[bi]
+            b['flat'].div_(self.world)
+            for p, o in zip(b['params'], b['offsets']):
+                g = b['flat'][o:o + p.numel()].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+        self.reset()
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -53,6 +53,7 @@ class AttnSide(C.Structure):
                 ('att_mask', c_u8p), ('ld_att_mask', C.c_int64),
                 ('pnt_mask', c_u8p), ('ld_pnt_mask', C.c_int64),
                 ('logits_out', c_f32p), ('ld_logits', C.c_int64),
+                ('scores_out', c_f32p), ('ld_scores', C.c_int64),
                 ('N', C.c_int)]
 
 
@@ -85,6 +86,15 @@ _SIG = {
     'gvd_attn_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'gvd_attn_fwd': (C.c_int, [C.POINTER(AttnSide), C.POINTER(AttnSide), C.c_int, C.c_int, C.c_int,
                                c_f32p, C.c_int64, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
+    'gvd_lstm_cell_bwd': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64,
+                                    c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int64,
+                                    C.c_void_p]),
+    'gvd_attn_bwd_chunks': (C.c_int, [C.c_int, C.c_int]),
+    'gvd_attn_bwd_step': (C.c_int, [C.POINTER(AttnSide), C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p,
+                                    C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p,
+                                    c_f32p, c_f32p, C.c_void_p]),
+    'gvd_attn_bwd_pfeats': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int64, c_f32p,
+                                      C.c_int64, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_void_p]),
     'gvd_logsoftmax_top2_embed': (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_i64p, C.c_int64,
                                             c_f32p, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_int64, C.c_void_p]),
     'gvd_embed_relu': (C.c_int, [c_i64p, C.c_int64, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int64, C.c_void_p]),

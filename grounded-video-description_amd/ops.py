@@ -96,7 +96,7 @@ def lstm_cell(xs, ws, h_prev, w_hh, b_ih, b_hh, c_prev, rowbias=None, gates_out=
     return h, c
 
 
-def _side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, logits_out=None):
+def _side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, logits_out=None, scores_out=None):
     s = AttnSide()
     assert feats.is_contiguous() and p_feats.is_contiguous() and q.stride(-1) == 1
     s.feats, s.p_feats = ptr(feats), ptr(p_feats)
@@ -111,6 +111,9 @@ def _side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, logits
     if logits_out is not None:
         assert logits_out.stride(-1) == 1
         s.logits_out = ptr(logits_out); s.ld_logits = logits_out.stride(0)
+    if scores_out is not None:
+        assert scores_out.stride(-1) == 1
+        s.scores_out = ptr(scores_out); s.ld_scores = scores_out.stride(0)
     s.N = feats.shape[1]
     return s
 
@@ -356,3 +359,59 @@ def masked_lsm(x, label):
     if torch.is_grad_enabled() and x.requires_grad:
         return _MaskedLsmFn.apply(x, label)
     return masked_lsm_loss(x.detach(), label)[0]
+
+
+# --------------------------------------------------------------------------------------------------
+# backward kernels of the decoder loop (used by decoder_bwd.DecoderLoopFn)
+# --------------------------------------------------------------------------------------------------
+def lstm_cell_bwd(dh, dc_next, gates, c_prev, c_new):
+    """Pointwise LSTMCell backward -> (d pre-activation gates [B,4H], dc_prev [B,H])."""
+    require_cuda_f32(dh, dc_next, gates, c_prev, c_new)
+    B, H = c_prev.shape
+    dh = dh if dh.stride(-1) == 1 else dh.contiguous()
+    dg = torch.empty(B, 4 * H, device=dh.device, dtype=torch.float32)
+    dcp = torch.empty(B, H, device=dh.device, dtype=torch.float32)
+    check(lib().gvd_lstm_cell_bwd(ptr(dh), dh.stride(0), ptr(dc_next), dc_next.stride(0) if dc_next is not None else 0,
+                                  ptr(gates), gates.stride(0), ptr(c_prev), c_prev.stride(0), ptr(c_new),
+                                  c_new.stride(0), B, H, ptr(dg), 4 * H, ptr(dcp), H, stream_ptr()),
+          'gvd_lstm_cell_bwd')
+    return dg, dcp
+
+
+def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None):
+    """One attention side, one step.  side: dict like attention_step's (feats, p_feats, q, w, alpha_bias
+    [, att_mask, pnt_mask]).  Returns de [B,N], d_q [B,A], d_w [B,A] (per-sample partial of the alpha_net weight
+    gradient), d_alpha_bias [B]."""
+    f = side['feats']
+    B, N, H = f.shape
+    A = side['p_feats'].shape[-1]
+    require_cuda_f32(f, alpha, ctx, d_ctx, d_logits)
+    s = _side(**{k: v for k, v in side.items() if k not in ('logits_out', 'scores_out')})
+    d_ctx = d_ctx if (d_ctx.stride(-1) == 1 and d_ctx.data_ptr() % 16 == 0 and d_ctx.stride(0) % 4 == 0) else d_ctx.contiguous()
+    if d_logits is not None and d_logits.stride(-1) != 1:
+        d_logits = d_logits.contiguous()
+    assert alpha.stride(-1) == 1 and ctx.stride(-1) == 1
+    nc = lib().gvd_attn_bwd_chunks(N, B)
+    de = torch.empty(B, N, device=f.device, dtype=torch.float32)
+    dq = torch.empty(B, nc, A, device=f.device, dtype=torch.float32)
+    dw = torch.empty(B, nc, A, device=f.device, dtype=torch.float32)
+    dab = torch.empty(B, nc, device=f.device, dtype=torch.float32)
+    check(lib().gvd_attn_bwd_step(C.byref(s), B, A, H, ptr(alpha), alpha.stride(0), ptr(ctx), ctx.stride(0),
+                                  ptr(d_ctx), d_ctx.stride(0), ptr(d_logits),
+                                  d_logits.stride(0) if d_logits is not None else 0, ptr(de), N, ptr(dq), ptr(dw),
+                                  ptr(dab), stream_ptr()), 'gvd_attn_bwd_step')
+    return de, dq.sum(1), dw.sum(1), dab.sum(1)
+
+
+def attn_bwd_pfeats(p_feats, q_all, de_all, w):
+    """d_p_feats [B,N,A] = sum_t de_all[t,b,n] * w * (1 - tanh^2(p_feats[b,n] + q_all[t,b])).
+    q_all: [Lc,B,A] view (inner stride 1); de_all: [Lc,B,N] contiguous."""
+    require_cuda_f32(p_feats, q_all, de_all, w)
+    B, N, A = p_feats.shape
+    Lc = q_all.shape[0]
+    assert q_all.stride(-1) == 1 and de_all.is_contiguous() and p_feats.is_contiguous()
+    out = torch.empty_like(p_feats)
+    check(lib().gvd_attn_bwd_pfeats(ptr(p_feats), B, N, A, ptr(q_all), q_all.stride(0), q_all.stride(1), ptr(de_all),
+                                    de_all.stride(0), de_all.stride(1), ptr(w), Lc, ptr(out), stream_ptr()),
+          'gvd_attn_bwd_pfeats')
+    return out

@@ -1,0 +1,59 @@
+"""One optimisation step with the reference's recipe (main.train, main.py:234-266, 660-677):
+loss = (lm + w_att2*att2 + w_grd*grd + w_cls*cls) / n_replicas, clip_grad_norm_(0.1), Adam(lr 5e-4; x0.1
+for the fc7 / vis_embed parameters).  Under torch.distributed the gradients are averaged over ranks
+(dist.GradAllReducer) between backward and the clip, which is exactly the reference's DataParallel
+semantics."""
+import torch
+import torch.nn as nn
+
+from . import dist as gdist
+
+
+def build_optimizer(model, opt):
+    """main.py:660-677: two learning-rate groups keyed on the parameter name."""
+    groups = []
+    for key, value in dict(model.named_parameters()).items():
+        if not value.requires_grad:
+            continue
+        lr = opt.learning_rate * (0.1 if ('ctx2pool_grd' in key or 'vis_embed' in key) else 1.0)
+        groups.append({'params': [value], 'lr': lr, 'weight_decay': opt.weight_decay,
+                       'betas': (opt.optim_alpha, opt.optim_beta)})
+    if opt.optim == 'adam':
+        return torch.optim.Adam(groups)
+    if opt.optim == 'sgd':
+        return torch.optim.SGD(groups, momentum=0.9)
+    if opt.optim == 'adamax':
+        return torch.optim.Adamax(groups)
+    raise ValueError(opt.optim)
+
+
+def combine_losses(losses, opt):
+    """main.py:238-255 for one replica (lm_loss.numel() == 1)."""
+    lm, att2, grd, cls = losses
+    loss = lm.sum()
+    if opt.w_att2:
+        loss = loss + opt.w_att2 * att2.sum()
+    if opt.w_grd:
+        loss = loss + opt.w_grd * grd.sum()
+    if opt.w_cls:
+        loss = loss + opt.w_cls * cls.sum()
+    return loss / lm.numel()
+
+
+class Trainer:
+    def __init__(self, model, opt, bucket_mb=64):
+        self.model, self.opt = model, opt
+        self.optimizer = build_optimizer(model, opt)
+        self.reducer = gdist.GradAllReducer(model, bucket_mb=bucket_mb)
+
+    def step(self, args):
+        """args: the 11 positional tensors of AttModel.forward.  Returns the 4 detached losses [4]."""
+        self.model.zero_grad(set_to_none=True)
+        self.reducer.reset()
+        losses = self.model(*args, 'MLE')
+        loss = combine_losses(losses, self.opt)
+        loss.backward()
+        self.reducer.finish()
+        nn.utils.clip_grad_norm_(self.model.parameters(), self.opt.grad_clip)
+        self.optimizer.step()
+        return torch.cat([l.detach() for l in losses])

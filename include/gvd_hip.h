@@ -122,6 +122,7 @@ typedef struct {
   const uint8_t* att_mask; int64_t ld_att_mask;   /* [B,N] or NULL */
   const uint8_t* pnt_mask; int64_t ld_pnt_mask;   /* [B,N] or NULL */
   float* logits_out; int64_t ld_logits;           /* [B,N] or NULL */
+  float* scores_out; int64_t ld_scores;           /* [B,N] or NULL: e[n] before the pnt_mask fill (kept for backward) */
   int N;
 } gvd_attn_side;
 
@@ -137,6 +138,33 @@ int gvd_attn_fwd(const gvd_attn_side* region, const gvd_attn_side* temporal, int
 int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_side* temporal, int B, int A, int H,
                       float* out_sum, int64_t ld_out, float* ctx_region, float* ctx_temporal,
                       void* workspace, gvd_prof* prof, gvd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward of the teacher-forced decoder loop (hand-scheduled BPTT; replaces autograd's per-op backward of
+ * AttModel.py:33-53,71-108,138-160).  The dX / dW products are plain library GEMMs done by the caller.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Pointwise backward of nn.LSTMCell: from dh, dc_next (nullable) and the saved post-activation gates
+ * (i,f,g,o), c_prev, c_new -> d(pre-activation gates) [B,4H] and dc_prev [B,H]. */
+int gvd_lstm_cell_bwd(const float* dh, int64_t lddh, const float* dc_next, int64_t lddc, const float* gates,
+                      int64_t ldg, const float* c_prev, int64_t ldcp, const float* c_new, int64_t ldcn, int B,
+                      int H, float* dgates, int64_t lddg, float* dc_prev, int64_t lddcp, gvd_stream_t stream);
+
+/* One attention side, one step: streams feats/p_feats once.  alpha = softmax weights of the step [B,N]
+ * (from the saved scores), ctx = the side's context [B,H], d_ctx / d_logits = incoming gradients.
+ * Writes de_out[b,n] = dLoss/d e[n] and per-chunk partial sums dq_part/dw_part [B,NC,A], dab_part [B,NC]
+ * with NC = gvd_attn_bwd_chunks(N, B) (deterministic: the caller sums over NC). */
+int gvd_attn_bwd_chunks(int N, int B);
+int gvd_attn_bwd_step(const gvd_attn_side* side, int B, int A, int H, const float* alpha, int64_t ld_alpha,
+                      const float* ctx, int64_t ld_ctx, const float* d_ctx, int64_t ld_dctx,
+                      const float* d_logits, int64_t ld_dlogits, float* de_out, int64_t ld_de, float* dq_part,
+                      float* dw_part, float* dab_part, gvd_stream_t stream);
+
+/* After the loop: d_p_feats[b,n,:] = sum_t de_all[t][b,n] * w * (1 - tanh^2(p_feats[b,n,:] + q_all[t][b,:])).
+ * q_all + t*q_step_stride + b*ldq, de_all + t*de_step_stride + b*ld_de + n.  Lc <= 40. */
+int gvd_attn_bwd_pfeats(const float* p_feats, int B, int N, int A, const float* q_all, int64_t q_step_stride,
+                        int64_t ldq, const float* de_all, int64_t de_step_stride, int64_t ld_de, const float* w,
+                        int Lc, float* d_p_feats, gvd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Vocabulary head

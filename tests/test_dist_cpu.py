@@ -1,0 +1,100 @@
+"""world_size=2 gloo tests (CPU) of the data-parallel path: bucketed/overlapped gradient averaging equals
+the mean of per-rank gradients, for a toy module and for the real loss (oracle) evaluated shard-by-shard —
+the reference's DataParallel semantics (mean over replicas of per-replica means)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import gvd_amd
+from gvd_amd import dist as gdist, synth
+from oracle import gvd_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _ParamBag(torch.nn.Module):
+    def __init__(self, sd):
+        super().__init__()
+        self.names = [k for k, v in sd.items() if v.is_floating_point() and 'running' not in k]
+        self.p = torch.nn.ParameterList([torch.nn.Parameter(sd[k].clone()) for k in self.names])
+        self.rest = {k: v for k, v in sd.items() if k not in self.names}
+
+    def weights(self):
+        W = dict(self.rest)
+        W.update({k: p for k, p in zip(self.names, self.p)})
+        return W
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    gdist.init_from_env('gloo')
+    # (1) toy module, tiny buckets -> many collectives, one parameter without gradient
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
+    gdist.broadcast_parameters(m)
+    red = gdist.GradAllReducer(m, bucket_mb=0.0002)
+    x = torch.randn(5, 8, generator=torch.Generator().manual_seed(10 + rank))
+    m[2](torch.relu(m[0](x))).pow(2).mean().backward()          # m[3] unused -> no grad
+    local = [None if p.grad is None else p.grad.clone() for p in m.parameters()]
+    red.finish()
+    avg = [p.grad.clone() for p in m.parameters()]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    ok = True
+    for i, a in enumerate(avg):
+        want = sum((g[i] if g[i] is not None else torch.zeros_like(a)) for g in gathered) / world
+        ok &= torch.allclose(a, want, atol=1e-7)
+    # (2) the real loss on this rank's shard of a batch (oracle), averaged grads == mean of shard grads
+    opt = gvd_amd.opts.default_opt(vocab_size=120, t_attn_size=6)
+    sd = synth.init_state_dict(opt, seed=4)
+    full = synth.trim_to_batch(synth.make_inputs(opt, 2 * world, seed=4, train=True))
+    mine = synth.shard(full, rank, world)
+    bag = _ParamBag(sd)
+    red2 = gdist.GradAllReducer(bag, bucket_mb=8)
+    lm, a2, gl, cl, _ = O.forward_train(bag.weights(), opt, *[mine[k] for k in synth.FORWARD_ORDER])
+    (lm + 0.05 * a2 + 0.1 * cl).backward()
+    local_losses = torch.stack([lm, a2, gl, cl]).detach()
+    local_g = {n: (None if p.grad is None else p.grad.clone()) for n, p in zip(bag.names, bag.p)}
+    red2.finish()
+    out = dict(rank=rank, ok_toy=bool(ok), losses=local_losses,
+               local=local_g, avg={n: p.grad.clone() for n, p in zip(bag.names, bag.p)})
+    torch.save(out, os.path.join(outdir, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gradient_averaging(tmp_path):
+    world = 2
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=500)
+        assert p.exitcode == 0
+    res = [torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r), weights_only=False) for r in range(world)]
+    res.sort(key=lambda r: r['rank'])
+    assert all(r['ok_toy'] for r in res)
+    names = list(res[0]['avg'])
+    for n in names:
+        l0, l1 = res[0]['local'][n], res[1]['local'][n]
+        a = res[0]['avg'][n]
+        want = ((l0 if l0 is not None else torch.zeros_like(a)) + (l1 if l1 is not None else torch.zeros_like(a))) / 2
+        assert torch.allclose(a, want, rtol=1e-6, atol=1e-8), n
+        assert torch.equal(res[0]['avg'][n], res[1]['avg'][n]), n        # replicas stay in lock-step
+    # the two shards really are different work
+    assert not torch.allclose(res[0]['losses'], res[1]['losses'])

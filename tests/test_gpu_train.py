@@ -1,0 +1,122 @@
+"""-m gpu: backward kernels against their torch stand-ins, the model's MLE gradients against the
+reference's gradient norms (tests/golden), and the optimisation step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gvd_amd
+from gvd_amd import att_model, ops, synth, train
+from oracle import cases
+from tests import torch_backend as TB
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def test_lstm_cell_bwd_kernel():
+    g = _g(1)
+    B, H = 37, 1024
+    gates = torch.cat([torch.rand(B, H, generator=g), torch.rand(B, H, generator=g),
+                       torch.rand(B, H, generator=g) * 2 - 1, torch.rand(B, H, generator=g)], 1)
+    dh, dc, cp, cn = (torch.randn(B, H, generator=g) for _ in range(4))
+    rdg, rdc = TB.lstm_cell_bwd(dh, dc, gates, cp, cn)
+    dg, dcp = ops.lstm_cell_bwd(dh.cuda(), dc.cuda(), gates.cuda(), cp.cuda(), cn.cuda())
+    np.testing.assert_allclose(dg.cpu().numpy(), rdg.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dcp.cpu().numpy(), rdc.numpy(), rtol=1e-5, atol=1e-6)
+    dg2, _ = ops.lstm_cell_bwd(dh.cuda(), None, gates.cuda(), cp.cuda(), cn.cuda())
+    np.testing.assert_allclose(dg2.cpu().numpy(), TB.lstm_cell_bwd(dh, None, gates, cp, cn)[0].numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('B,N,masked', [(3, 1000, True), (2, 10, False), (33, 1000, True)])
+def test_attn_bwd_kernels(B, N, masked):
+    g = _g(B + N)
+    H, A, Lc = 1024, 512, 3
+    feats, p_feats = torch.randn(B, N, H, generator=g), torch.randn(B, N, A, generator=g)
+    w = torch.randn(A, generator=g) * 0.2
+    ab = torch.zeros(1)
+    am = pm = None
+    if masked:
+        am = (torch.rand(B, N, generator=g) < 0.2).to(torch.uint8)
+        pm = (torch.rand(B, N, generator=g) < 0.4).to(torch.uint8) | am
+        am[0] = 1
+        pm[0] = 1
+    q_all = torch.randn(Lc, B, 2 * A, generator=g)
+    de_all_ref, de_all = [], torch.empty(Lc, B, N, device='cuda')
+    dev = lambda t: None if t is None else t.cuda()
+    for t in range(Lc):
+        q = q_all[t][:, A:]
+        side = dict(feats=feats, p_feats=p_feats, q=q, w=w, alpha_bias=ab, att_mask=am, pnt_mask=pm)
+        e = torch.tanh(p_feats + q.unsqueeze(1)) @ w
+        if am is not None:
+            e = e.masked_fill(am.bool(), -1e8)
+        alpha = torch.softmax(e, 1)
+        ctx = torch.bmm(alpha.unsqueeze(1), feats).squeeze(1)
+        d_ctx, d_logits = torch.randn(B, H, generator=g), torch.randn(B, N, generator=g)
+        r_de, r_dq, r_dw, r_dab = TB.attn_bwd_step(side, alpha, ctx, d_ctx, d_logits)
+        dside = {k: dev(v) for k, v in side.items()}
+        dside['q'] = q_all.cuda()[t][:, A:]
+        de, dq, dw, dab = ops.attn_bwd_step(dside, alpha.cuda(), ctx.cuda(), d_ctx.cuda(), d_logits.cuda())
+        np.testing.assert_allclose(de.cpu().numpy(), r_de.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(dq.cpu().numpy(), r_dq.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(dw.cpu().numpy(), r_dw.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(dab.cpu().numpy(), r_dab.numpy(), rtol=1e-4, atol=1e-4)
+        de_all_ref.append(r_de)
+        de_all[t].copy_(de)
+    ref = TB.attn_bwd_pfeats(p_feats, q_all[:, :, A:], torch.stack(de_all_ref), w)
+    out = ops.attn_bwd_pfeats(p_feats.cuda(), q_all.cuda()[:, :, A:], de_all, w.cuda())
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+
+
+GRAD_CASES = [n for n, s in cases.CASES.items() if s['mode'] == 'MLE' and s['B'] <= 8]
+
+
+@pytest.mark.parametrize('name', GRAD_CASES)
+def test_mle_gradients_match_reference(name, golden_dir):
+    """Eval-mode (dropout off, BN running stats) gradients of lm + w_att2*att2 + w_grd*grd + w_cls*cls: every
+    parameter's gradient L2 norm vs the reference's (oracle/make_golden.py), plus the 4 losses."""
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    opt, sd, inp = cases.build_case(name)
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    lm, a2, gl, cl = model(*synth.as_args(inp, 'cuda'), 'MLE')
+    np.testing.assert_allclose(np.array([float(lm), float(a2), float(gl), float(cl)]), g['losses'], atol=1e-4)
+    w = cases.GRAD_WEIGHTS
+    (lm.sum() + w['w_att2'] * a2.sum() + w['w_grd'] * gl.sum() + w['w_cls'] * cl.sum()).backward()
+    ref = dict(zip([str(n) for n in g['grad_names']], g['grad_norms']))
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for n, want in ref.items():
+        p = params[n]
+        assert p.grad is not None, n
+        got = float(p.grad.double().norm())
+        rel = abs(got - want) / max(want, 1e-6)
+        worst = max(worst, rel)
+        assert rel < 2e-3, '%s: |grad| %.6g vs reference %.6g' % (n, got, want)
+    for n in ('core.i2h_2.weight', 'core.h2h_2.weight'):
+        assert params[n].grad is None or float(params[n].grad.abs().sum()) == 0.0
+    print('worst relative grad-norm error', worst)
+
+
+def test_train_steps_reduce_loss():
+    """Three optimisation steps (train mode: dropout + BN batch stats; Adam, clip 0.1) on one fixed batch."""
+    opt = gvd_amd.opts.default_opt(vocab_size=1000, t_attn_size=10)
+    torch.manual_seed(0)
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(synth.init_state_dict(opt, seed=0))
+    model = model.cuda().train()
+    tr = train.Trainer(model, opt)
+    inp = synth.trim_to_batch(synth.make_inputs(opt, 8, seed=0, train=True))
+    args = synth.as_args(inp, 'cuda')
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    hist = [tr.step(args).cpu() for _ in range(4)]
+    assert all(torch.isfinite(h).all() for h in hist)
+    assert float(hist[-1][0]) < float(hist[0][0])          # LM loss goes down on the repeated batch
+    moved = [n for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n])]
+    assert 'core.att_lstm.weight_hh' in moved and 'ctx2pool_grd.0.weight' in moved and 'logit.weight' in moved
+    assert 'core.i2h_2.weight' not in moved

@@ -32,7 +32,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=256, help='segments per GPU per step')
+    ap.add_argument('--mode', choices=['sample', 'train'], default='sample',
+                    help="sample: greedy decode captions/s (headline); train: 'MLE' fwd+bwd+Adam step segments/s")
+    ap.add_argument('--batch', type=int, default=None, help='segments per GPU per step (default 256 sample / 64 train)')
     ap.add_argument('--t-attn', type=int, default=10, help='temporal positions Ft (BASELINE: [B,10,3072]; reference default 480)')
     ap.add_argument('--vocab', type=int, default=5000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -76,6 +78,45 @@ def cpu_baseline(opt, sd, seconds):
                       % (n, opt.t_attn_size, opt.vocab_size, dt)}
 
 
+def bench_train(args, opt, sd, model, B, rank, world, dev):
+    """BASELINE configs[2]/[3]: one optimisation step = 'MLE' forward (LM + attention + grounding + cls losses),
+    hand-scheduled BPTT, RCCL gradient all-reduce (N>1), clip 0.1, Adam.  Train mode (dropout, BN batch stats)."""
+    from gvd_amd import dist as gdist, synth, train
+    model.train()
+    gdist.broadcast_parameters(model)
+    tr = train.Trainer(model, opt)
+    inp = synth.trim_to_batch(synth.make_inputs(opt, B, seed=200 + rank, train=True))
+    a = synth.as_args(inp, dev)
+    for _ in range(args.warmup):
+        tr.step(a)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = tr.step(a)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    if rank == 0:
+        print(json.dumps({
+            'metric': "train segments/sec ('MLE' fwd + BPTT + grad all-reduce + clip + Adam)",
+            'value': round(world * B * args.steps / elapsed, 2), 'unit': 'segments/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'train step, %d segments/GPU, L=20, 10x100 regions, Ft=%d, V=%d, w_att2=%.2f '
+                                   'w_grd=%.2f w_cls=%.2f' % (B, args.t_attn, args.vocab, opt.w_att2, opt.w_grd, opt.w_cls),
+                       'batch_per_gpu': B, 'parallelism': 'dp%d (RCCL bucketed grad all-reduce)' % world},
+            'losses_last': [round(float(x), 5) for x in losses], 'roofline': None, 'cpu_baseline': None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -95,7 +136,9 @@ def main():
     model = att_model.TopDownModel(opt)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
-    B = args.batch
+    B = args.batch or (256 if args.mode == 'sample' else 64)
+    if args.mode == 'train':
+        return bench_train(args, opt, sd, model, B, rank, world, dev)
     inp = synth.make_inputs(opt, B, seed=100 + rank, train=False)     # each rank: its own shard of segments
     keys = ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')
     dinp = [inp[k].to(dev) for k in keys]

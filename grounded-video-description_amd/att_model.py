@@ -226,7 +226,12 @@ class TopDownModel(nn.Module):
         c = torch.cat([self._drop(F.relu(self.att_embed[0][0](segs_feat[:, :, :2048]))),
                        self._drop(F.relu(self.att_embed[1][0](segs_feat[:, :, 2048:])))], dim=2)
         c = self.att_embed_aux(c.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
-        c = self.context_enc(c)[0]
+        if torch.is_grad_enabled() and not self.training:
+            # MIOpen's fused RNN has no backward in eval mode; the native GRU does (parity tests differentiate in eval)
+            with torch.backends.cudnn.flags(enabled=False):
+                c = self.context_enc(c)[0]
+        else:
+            c = self.context_enc(c)[0]
         t = torch.arange(Ft, device=c.device).view(1, Ft)
         keep = (t >= sample_idx[:, 0:1]) & (t < sample_idx[:, 1:2])           # model.py:303-305
         conv = c.masked_fill(~keep.unsqueeze(-1), 0).contiguous()

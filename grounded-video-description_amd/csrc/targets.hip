@@ -31,9 +31,12 @@ __global__ void iou_kernel(const float* __restrict__ ppls, int ppl_ld, const flo
   // no fp contraction: the reference evaluates (a_area + g_area) - iw*ih and (iw*ih)/ua with separate roundings
   const float inter = __fmul_rn(iw, ih);
   const float ua = __fsub_rn(__fadd_rn(a_area, g_area), inter);
-  // fp32 '/' on gfx950 is not correctly rounded by default; an fp64 divide rounded to fp32 is
-  // (53 >= 2*24+2 bits), which is what the CPU reference computes.
-  float ov = (float)((double)inter / (double)ua);
+  // The CPU reference divides with IEEE-correct rounding; hipcc's fp32 '/' expansion was measured 1 ulp off.
+  // Divide in fp64 (correctly rounded, and 53 >= 2*24+2 bits makes the double->float rounding exact); the
+  // empty asm keeps LLVM from folding fptrunc(fdiv(fpext, fpext)) back into an fp32 divide.
+  double qd = (double)inter / (double)ua;
+  asm volatile("" : "+v"(qd));
+  float ov = (float)qd;
   const bool masked = frm_mask[idx] | pnt_mask[(int64_t)b * (R + 1) + 1 + r];
   ov = ov * (masked ? 0.f : 1.f);
   if (gx == 1.f && gy == 1.f) ov = 0.f;

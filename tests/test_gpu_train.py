@@ -95,7 +95,9 @@ def test_mle_gradients_match_reference(name, golden_dir):
         p = params[n]
         assert p.grad is not None, n
         got = float(p.grad.double().norm())
-        rel = abs(got - want) / max(want, 1e-6)
+        # absolute floor: alpha_net.bias of a softmax attention has an exactly-zero true gradient (shift
+        # invariance); both sides only hold ~1e-8 rounding noise there
+        rel = abs(got - want) / max(want, 1e-3)
         worst = max(worst, rel)
         assert rel < 2e-3, '%s: |grad| %.6g vs reference %.6g' % (n, got, want)
     for n in ('core.i2h_2.weight', 'core.h2h_2.weight'):

@@ -23,14 +23,21 @@ __global__ void iou_kernel(const float* __restrict__ ppls, int ppl_ld, const flo
   const float* g = gt + ((int64_t)b * K + k) * gt_ld;
   const float gx = g[2] - g[0] + 1.f, gy = g[3] - g[1] + 1.f;
   const float ax = a[2] - a[0] + 1.f, ay = a[3] - a[1] + 1.f;
-  const float g_area = gx * gy, a_area = ax * ay;
+  // opaque barriers: each product is rounded on its own like the reference's tensor ops (no fma fusion
+  // with the following add/sub, whatever -ffp-contract says)
+  float g_area = gx * gy, a_area = ax * ay;
+  asm volatile("" : "+v"(g_area));
+  asm volatile("" : "+v"(a_area));
   float iw = fminf(a[2], g[2]) - fmaxf(a[0], g[0]) + 1.f;
   if (iw < 0.f) iw = 0.f;
   float ih = fminf(a[3], g[3]) - fmaxf(a[1], g[1]) + 1.f;
   if (ih < 0.f) ih = 0.f;
   // no fp contraction: the reference evaluates (a_area + g_area) - iw*ih and (iw*ih)/ua with separate roundings
-  const float inter = __fmul_rn(iw, ih);
-  const float ua = __fsub_rn(__fadd_rn(a_area, g_area), inter);
+  float inter = iw * ih;
+  asm volatile("" : "+v"(inter));
+  float ua = a_area + g_area;
+  asm volatile("" : "+v"(ua));
+  ua = ua - inter;
   // The CPU reference divides with IEEE-correct rounding; hipcc's fp32 '/' expansion was measured 1 ulp off.
   // Divide in fp64 (correctly rounded, and 53 >= 2*24+2 bits makes the double->float rounding exact); the
   // empty asm keeps LLVM from folding fptrunc(fdiv(fpext, fpext)) back into an fp32 divide.

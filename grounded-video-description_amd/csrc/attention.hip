@@ -35,7 +35,7 @@ struct SideDev {
   const uint8_t* pnt_mask; int64_t ld_pnt_mask;
   float* logits_out; int64_t ld_logits;
   float* scores_out; int64_t ld_scores;
-  int N, chunk, nchunks;
+  int N, chunk, nchunks, group;
 };
 
 struct FwdParams {
@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   const f32x4 w0 = *reinterpret_cast<const f32x4*>(S.w + 4 * lane);
   const f32x4 w1 = *reinterpret_cast<const f32x4*>(S.w + 256 + 4 * lane);
   const float ab = *S.alpha_bias;
-  const float* pf = S.p_feats + ((int64_t)b * S.N + n0) * ATT_A;
+  const int fbi = S.group > 1 ? b / S.group : b;   // beams of one sample share its features
+  const float* pf = S.p_feats + ((int64_t)fbi * S.N + n0) * ATT_A;
   const uint8_t* am = S.att_mask ? S.att_mask + (int64_t)b * S.ld_att_mask + n0 : nullptr;
   const uint8_t* pm = S.pnt_mask ? S.pnt_mask + (int64_t)b * S.ld_pnt_mask + n0 : nullptr;
   float* lo = S.logits_out ? S.logits_out + (int64_t)b * S.ld_logits + n0 : nullptr;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   __syncthreads();
 
   // ---- phase 2: partial context.  thread owns columns [4*tid, 4*tid+4) of H = 1024
-  const float* fb = S.feats + ((int64_t)b * S.N + n0) * ATT_H + 4 * tid;
+  const float* fb = S.feats + ((int64_t)fbi * S.N + n0) * ATT_H + 4 * tid;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   int r = 0;
   for (; r + 8 <= rows; r += 8) {
@@ -205,7 +206,7 @@ void fill_side(SideDev& d, const gvd_attn_side* s, int B) {
   d.alpha_bias = s->alpha_bias; d.att_mask = s->att_mask; d.ld_att_mask = s->ld_att_mask;
   d.pnt_mask = s->pnt_mask; d.ld_pnt_mask = s->ld_pnt_mask; d.logits_out = s->logits_out;
   d.ld_logits = s->ld_logits; d.scores_out = s->scores_out; d.ld_scores = s->ld_scores;
-  d.N = s->N; d.chunk = pick_chunk(s->N, B);
+  d.N = s->N; d.group = s->group; d.chunk = pick_chunk(s->N, B);
   d.nchunks = (s->N + d.chunk - 1) / d.chunk;
 }
 

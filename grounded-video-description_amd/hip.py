@@ -54,7 +54,7 @@ class AttnSide(C.Structure):
                 ('pnt_mask', c_u8p), ('ld_pnt_mask', C.c_int64),
                 ('logits_out', c_f32p), ('ld_logits', C.c_int64),
                 ('scores_out', c_f32p), ('ld_scores', C.c_int64),
-                ('N', C.c_int)]
+                ('N', C.c_int), ('group', C.c_int)]
 
 
 class GreedyArgs(C.Structure):

@@ -96,7 +96,8 @@ def lstm_cell(xs, ws, h_prev, w_hh, b_ih, b_hh, c_prev, rowbias=None, gates_out=
     return h, c
 
 
-def _side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, logits_out=None, scores_out=None):
+def _side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, logits_out=None, scores_out=None,
+          group=0):
     s = AttnSide()
     assert feats.is_contiguous() and p_feats.is_contiguous() and q.stride(-1) == 1
     s.feats, s.p_feats = ptr(feats), ptr(p_feats)
@@ -115,6 +116,7 @@ def _side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, logits
         assert scores_out.stride(-1) == 1
         s.scores_out = ptr(scores_out); s.ld_scores = scores_out.stride(0)
     s.N = feats.shape[1]
+    s.group = group
     return s
 
 
@@ -136,7 +138,9 @@ def attention_step(region, temporal, want_separate=False):
     region / temporal: dicts(feats, p_feats, q, w, alpha_bias[, att_mask, pnt_mask, logits_out]).
     Returns att+att2 [B,H] (and the two contexts when want_separate)."""
     f = region['feats']
-    B, Nr, H = f.shape
+    Nr, H = f.shape[1], f.shape[2]
+    B = region['q'].shape[0]                      # rows (= feats.shape[0] * group)
+    assert B == f.shape[0] * max(region.get('group', 0), 1)
     A = region['p_feats'].shape[-1]
     require_cuda_f32(f, region['p_feats'], region['q'])
     sr = _side(**region)

@@ -124,6 +124,8 @@ typedef struct {
   float* logits_out; int64_t ld_logits;           /* [B,N] or NULL */
   float* scores_out; int64_t ld_scores;           /* [B,N] or NULL: e[n] before the pnt_mask fill (kept for backward) */
   int N;
+  int group;   /* 0/1: feats/p_feats have one entry per row b.  K>1: rows b share entry b/K (the K beams of a
+                  sample attend over ONE copy of its features: feats/p_feats are [B/K,N,*]) */
 } gvd_attn_side;
 
 /* Both attentions of one decoder step in one pass over HBM.

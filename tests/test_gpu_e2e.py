@@ -121,3 +121,23 @@ def test_decode_round_trip_properties():
     picked_masked = pm.view(96, 1, T, P).expand(96, 20, T, P).gather(3, idx.unsqueeze(-1)).squeeze(-1)
     frame_has_free = (~pm.view(96, T, P)).any(-1).unsqueeze(1).expand(96, 20, T)
     assert not (picked_masked & frame_has_free).any()
+
+
+@pytest.mark.parametrize('B,K,seed', [(2, 3, 0), (3, 5, 1)])
+def test_beam_search_matches_oracle(B, K, seed):
+    """Beam search (BASELINE configs[4]).  PARITY UNPINNED: the reference's beam path raises,
+    so the checker is the oracle's minimally-repaired restatement of CaptionModelBU.py:24-185."""
+    opt = gvd_amd.opts.default_opt(vocab_size=1000, t_attn_size=10)
+    sd = synth.init_state_dict(opt, seed=seed, profile='trained_like')
+    inp = synth.make_inputs(opt, B, seed=seed, train=False)
+    a = [inp[k] for k in ('segs_feat', 'num', 'ppls', 'ppls_feat', 'sample_idx', 'pnt_mask')]
+    with torch.no_grad():
+        oseq, olps, oatt, _ = O.sample_beam(sd, opt, *a, beam_size=K)
+        model = _model(opt, sd)
+        seq, att2, sim = model(*synth.as_args(inp, 'cuda'), 'sample', {'sample_max': 1, 'beam_size': K})
+        _, lps, _, _ = model._sample(*[inp[k].cuda() for k in ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx',
+                                                              'pnt_mask')], {'beam_size': K})
+    assert seq.dtype == torch.int64 and tuple(seq.shape) == (B, opt.seq_length)
+    assert torch.equal(seq.cpu(), oseq), 'beam token ids differ from the oracle restatement'
+    assert torch.equal(att2.cpu(), oatt), 'beam attended-region indices differ'
+    np.testing.assert_allclose(lps.cpu().numpy(), olps.numpy(), atol=2e-4)

@@ -90,16 +90,17 @@ def bench_train(args, opt, sd, model, B, rank, world, dev):
     for _ in range(args.warmup):
         tr.step(a)
     torch.cuda.synchronize()
-    if world > 1:
+    use_dist = dist.is_initialized()
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = tr.step(a)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -113,7 +114,7 @@ def bench_train(args, opt, sd, model, B, rank, world, dev):
                                    'w_grd=%.2f w_cls=%.2f' % (B, args.t_attn, args.vocab, opt.w_att2, opt.w_grd, opt.w_cls),
                        'batch_per_gpu': B, 'parallelism': 'dp%d (RCCL bucketed grad all-reduce)' % world},
             'losses_last': [round(float(x), 5) for x in losses], 'roofline': None, 'cpu_baseline': None}))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -122,11 +123,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    torch.cuda.set_device(local)
+    use_dist = 'RANK' in os.environ        # launched by torch.distributed.run (also for a single rank)
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
-    torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
     import gvd_amd  # noqa: F401
@@ -146,7 +149,7 @@ def main():
     model.kernel_timer = None
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     with torch.no_grad():
@@ -163,7 +166,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -205,7 +208,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

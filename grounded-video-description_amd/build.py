@@ -11,14 +11,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libgvd_hip.so')
 STAMP = LIB + '.srchash'
-SOURCES = ['gemm_f32.hip', 'attention.hip', 'vocab.hip', 'decode.hip', 'targets.hip', 'prof.hip', 'backward.hip']
+SOURCES = ['gemm_f32.hip', 'gemv_f32.hip', 'attention.hip', 'vocab.hip', 'decode.hip', 'targets.hip', 'prof.hip', 'backward.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-gpu-rdc',
          '-Wno-unused-result']
 
 
 def _source_hash():
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'gvd_common.h'),
+    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'gvd_common.h'), os.path.join(CSRC, 'gemv_f32.h'),
                                                        os.path.join(HERE, '..', 'include', 'gvd_hip.h')]
     for f in files:
         with open(f, 'rb') as fh:

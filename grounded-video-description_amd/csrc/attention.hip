@@ -156,21 +156,51 @@ struct CombParams {
   float* ctx_out[2];   // optional, [B,H] each
 };
 
+constexpr int MAX_NC = 512;   // chunks per side the combine kernel can merge
+
 __global__ __launch_bounds__(256) void attn_combine_kernel(const CombParams p) {
+  __shared__ float s_sc[MAX_NC];
+  __shared__ float s_red[8];
   const int b = blockIdx.x, tid = threadIdx.x;
   f32x4 total = {0.f, 0.f, 0.f, 0.f};
   int c0 = 0;
   for (int s = 0; s < p.nside; ++s) {
     const int nc = p.nc[s];
     const float* ml = p.part_ml + ((int64_t)b * p.nctot + c0) * 2;
-    float M = -INFINITY;
-    for (int c = 0; c < nc; ++c) M = fmaxf(M, ml[2 * c]);
-    float L = 0.f;
+    // all (m, l) pairs in parallel: global max, rescale factors exp(m_c - M) into LDS, normaliser L
+    float m_loc = -INFINITY;
+    for (int c = tid; c < nc; c += 256) m_loc = fmaxf(m_loc, ml[2 * c]);
+    m_loc = wave_max(m_loc);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = m_loc;
+    __syncthreads();
+    const float M = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float l_loc = 0.f;
+    for (int c = tid; c < nc; c += 256) {
+      const float sc = expf(ml[2 * c] - M);
+      s_sc[c] = sc;
+      l_loc = fmaf(sc, ml[2 * c + 1], l_loc);
+    }
+    l_loc = wave_sum(l_loc);
+    if ((tid & 63) == 0) s_red[4 + (tid >> 6)] = l_loc;
+    __syncthreads();
+    const float L = s_red[4] + s_red[5] + s_red[6] + s_red[7];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float* pc = p.part_ctx + ((int64_t)b * p.nctot + c0) * ATT_H + 4 * tid;
-    for (int c = 0; c < nc; ++c) {
-      const float sc = expf(ml[2 * c] - M);
-      L = fmaf(sc, ml[2 * c + 1], L);
+    int c = 0;
+    for (; c + 4 <= nc; c += 4) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(pc + (int64_t)(c + u) * ATT_H);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float sc = s_sc[c + u];
+        acc[0] = fmaf(sc, v[u][0], acc[0]); acc[1] = fmaf(sc, v[u][1], acc[1]);
+        acc[2] = fmaf(sc, v[u][2], acc[2]); acc[3] = fmaf(sc, v[u][3], acc[3]);
+      }
+    }
+    for (; c < nc; ++c) {
+      const float sc = s_sc[c];
       const f32x4 v = *reinterpret_cast<const f32x4*>(pc + (int64_t)c * ATT_H);
       acc[0] = fmaf(sc, v[0], acc[0]); acc[1] = fmaf(sc, v[1], acc[1]);
       acc[2] = fmaf(sc, v[2], acc[2]); acc[3] = fmaf(sc, v[3], acc[3]);
@@ -180,14 +210,15 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const CombParams p) {
     if (p.ctx_out[s]) *reinterpret_cast<f32x4*>(p.ctx_out[s] + (int64_t)b * ATT_H + 4 * tid) = acc;
     total[0] += acc[0]; total[1] += acc[1]; total[2] += acc[2]; total[3] += acc[3];
     c0 += nc;
+    __syncthreads();   // s_sc / s_red reused by the next side
   }
   if (p.out_sum) *reinterpret_cast<f32x4*>(p.out_sum + (int64_t)b * p.ld_out + 4 * tid) = total;
 }
 
-// rows per chunk: keep >= ~1024 workgroups in flight when the batch is small, 50-row chunks otherwise
+// rows per chunk: 50; halved (not below 13) while fewer than ~512 workgroups would exist (small batches)
 int pick_chunk(int N, int B) {
   int chunk = 50;
-  while (chunk > 10 && (long)B * ((N + chunk - 1) / chunk) < 1024) chunk = (chunk + 1) / 2;
+  while (chunk > 20 && (long)B * ((N + chunk - 1) / chunk) < 512) chunk = (chunk + 1) / 2;
   if (chunk > MAX_CHUNK) chunk = MAX_CHUNK;
   if (chunk > N) chunk = N;
   if (chunk < 1) chunk = 1;
@@ -228,6 +259,7 @@ extern "C" int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_sid
   p.nside = 1;
   if (temporal) { fill_side(p.side[1], temporal, B); p.nside = 2; }
   p.nctot = p.side[0].nchunks + (temporal ? p.side[1].nchunks : 0);
+  if (p.side[0].nchunks > MAX_NC || (temporal && p.side[1].nchunks > MAX_NC)) return GVD_EINVAL;
   p.part_ctx = reinterpret_cast<float*>(workspace);
   p.part_ml = p.part_ctx + (int64_t)B * p.nctot * ATT_H;
   hipStream_t st = gvd_s(stream);

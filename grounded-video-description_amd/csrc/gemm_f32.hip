@@ -16,6 +16,7 @@
 // global traffic hide completely behind the matrix pipe.  Workgroup ids are remapped XCD-aware so the
 // tiles that share an A panel land on one XCD's L2.
 #include "gvd_common.h"
+#include "gemv_f32.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -272,6 +273,16 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
   p.C = a->C; p.ldc = a->ldc; p.cbs = a->c_batch_stride;
   p.M = a->M; p.N = a->N; p.act = a->act;
   hipStream_t st = gvd_s(stream);
+  if (a->M <= 16 && a->batch == 1 && !a->mbias && !a->mask) {   // decode batch: weight-streaming skinny kernel
+    GemvParams v = {};
+    v.nseg = a->nseg;
+    for (int s = 0; s < a->nseg; ++s) {
+      v.A[s] = a->seg[s].A; v.lda[s] = a->seg[s].lda; v.W[s] = a->seg[s].W; v.ldw[s] = a->seg[s].ldw; v.K[s] = a->seg[s].K;
+    }
+    v.nbias = a->nbias; v.nbias2 = a->nbias2; v.rowbias = a->rowbias; v.rowbias_ld = a->rowbias_ld;
+    v.C = a->C; v.ldc = a->ldc; v.M = a->M; v.N = a->N; v.act = a->act;
+    return gvd_gemv_plain(v, st);
+  }
   if (a->M <= 32) return launch<32, 128, 1, 4, false>(p, a->batch, st);
   const long big = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
   if (big >= 256) return launch<128, 128, 2, 2, false>(p, a->batch, st);
@@ -298,6 +309,18 @@ extern "C" int gvd_lstm_cell_fwd(const gvd_lstm_args* a, gvd_stream_t stream) {
   p.c_out = a->c_out; p.ldco = a->ldc_out;
   p.gates_out = a->gates_out; p.ldg = a->ldg;
   hipStream_t st = gvd_s(stream);
+  if (a->B <= 16) {
+    GemvParams v = {};
+    v.nseg = a->nseg;
+    for (int s = 0; s < a->nseg; ++s) {
+      v.A[s] = a->seg[s].A; v.lda[s] = a->seg[s].lda; v.W[s] = a->seg[s].W; v.ldw[s] = a->seg[s].ldw; v.K[s] = a->seg[s].K;
+    }
+    v.nbias = a->b_ih; v.nbias2 = a->b_hh; v.rowbias = a->rowbias; v.rowbias_ld = a->rowbias_ld;
+    v.M = a->B; v.N = 4 * a->H; v.H = a->H;
+    v.c_prev = a->c_prev; v.ldcp = a->ldc_prev; v.h_out = a->h_out; v.ldh = a->ldh;
+    v.c_out = a->c_out; v.ldco = a->ldc_out; v.gates_out = a->gates_out; v.ldg = a->ldg;
+    return gvd_gemv_lstm(v, st);
+  }
   if (a->B <= 32) return launch<32, 128, 1, 4, true>(p, 1, st);
   return launch<64, 64, 2, 2, true>(p, 1, st);
 }

@@ -75,7 +75,9 @@ class GradAllReducer:
                 self.where[id(p)] = bi
         self._handles = []
         self._hooks = []
-        if self.world > 1:
+        # GVD_DP_FORCE=1: run the hook/bucket/all-reduce machinery even on a 1-rank group (single-GPU test of the path)
+        self.active = self.world > 1 or (os.environ.get('GVD_DP_FORCE') == '1' and dist.is_initialized())
+        if self.active:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.reset()
@@ -113,7 +115,7 @@ class GradAllReducer:
 
     def finish(self):
         """Call after loss.backward(): completes every bucket and writes the averaged gradients back."""
-        if self.world == 1:
+        if not self.active:
             return
         for bi in range(len(self.buckets)):
             if not self._launched[bi]:          # buckets holding parameters that got no gradient

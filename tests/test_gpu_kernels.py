@@ -26,7 +26,10 @@ def test_cpu_tensor_fails_loudly():
 
 
 @pytest.mark.parametrize('M,N,K,act', [(4, 1024, 1024, 0), (32, 4096, 1536, 0), (256, 5000, 1024, 0),
-                                       (70, 433, 2048, 1), (4000, 2048, 2048, 1), (640, 512, 1024, 0)])
+                                       (70, 433, 2048, 1), (4000, 2048, 2048, 1), (640, 512, 1024, 0),
+                                       # M <= 16: the weight-streaming skinny kernel (all MB / RPW variants)
+                                       (1, 5000, 1024, 0), (8, 5000, 1024, 0), (16, 4096, 2048, 1), (13, 1001, 512, 1),
+                                       (3, 1024, 1024, 0), (7, 512, 2048, 0)])
 def test_gemm_nt(M, N, K, act):
     g = _g(M + N)
     A = torch.randn(M, K, generator=g)
@@ -61,7 +64,7 @@ def test_grounder_batched_masked():
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize('B', [4, 64, 200])
+@pytest.mark.parametrize('B', [1, 4, 7, 16, 17, 64, 200])
 def test_lstm_cell(B):
     g = _g(B)
     H, E = 1024, 512

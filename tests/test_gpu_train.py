@@ -122,3 +122,20 @@ def test_train_steps_reduce_loss():
     moved = [n for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n])]
     assert 'core.att_lstm.weight_hh' in moved and 'ctx2pool_grd.0.weight' in moved and 'logit.weight' in moved
     assert 'core.i2h_2.weight' not in moved
+
+
+@pytest.mark.parametrize('mode', ['sample', 'train'])
+def test_bench_under_torchrun_single_rank(mode):
+    """bench.py launched exactly like the driver launches it (torch.distributed.run, one rank per GPU): RCCL
+    init, barrier, MAX all-reduce and (train) the bucketed gradient all-reduce all run on this 1-GPU box."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GVD_DP_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+           '127.0.0.1', '--master-port', '29617', os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2',
+           '--warmup', '1', '--batch', '8', '--vocab', '1000', '--no-cpu-baseline', '--mode', mode]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    j = json.loads(line)
+    assert j['n_gpus'] == 1 and j['value'] > 0 and j['steps'] == 2

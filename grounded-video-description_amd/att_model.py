@@ -182,9 +182,15 @@ class TopDownModel(nn.Module):
         for lay in self.obj_interact.encoder.layers:
             sa = lay.selfattn.layer
             q, k, v = sa.wq(x), sa.wk(x), sa.wv(x)
+            # the reference divides the [B,R,R] score maps by sqrt(d_model) = 32 (transformer.py:92,104); scaling the
+            # [B,R,171] queries instead is bitwise identical when the scale is a power of two and 5.8x less traffic
+            exact = scale == 2.0 ** round(math.log2(scale))
+            if exact:
+                q = q / scale
             heads = []
             for qh, kh, vh in zip(q.chunk(6, -1), k.chunk(6, -1), v.chunk(6, -1)):
-                w = F.softmax(torch.matmul(qh, kh.transpose(1, 2)) / scale, dim=-1)
+                dots = torch.matmul(qh, kh.transpose(1, 2))
+                w = F.softmax(dots if exact else dots / scale, dim=-1)
                 heads.append(torch.matmul(F.dropout(w, 0.2, self.training), vh))
             att = sa.wo(torch.cat(heads, -1))
             x = lay.selfattn.layernorm(x + F.dropout(att, 0.2, self.training))
@@ -226,7 +232,10 @@ class TopDownModel(nn.Module):
         c = torch.cat([self._drop(F.relu(self.att_embed[0][0](segs_feat[:, :, :2048]))),
                        self._drop(F.relu(self.att_embed[1][0](segs_feat[:, :, 2048:])))], dim=2)
         c = self.att_embed_aux(c.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
-        if torch.is_grad_enabled() and not self.training:
+        if not torch.is_grad_enabled():
+            # inference: persistent cooperative HIP GRU (one launch per layer instead of ~6 per step/direction)
+            c = ops.gru_bidir_2layer(c, self.context_enc)
+        elif not self.training:
             # MIOpen's fused RNN has no backward in eval mode; the native GRU does (parity tests differentiate in eval)
             with torch.backends.cudnn.flags(enabled=False):
                 c = self.context_enc(c)[0]

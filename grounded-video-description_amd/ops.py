@@ -419,3 +419,26 @@ def attn_bwd_pfeats(p_feats, q_all, de_all, w):
                                     de_all.stride(0), de_all.stride(1), ptr(w), Lc, ptr(out), stream_ptr()),
           'gvd_attn_bwd_pfeats')
     return out
+
+
+def gru_bidir_2layer(x, gru):
+    """Inference forward of the frame encoder nn.GRU(1024, 512, 2, bidirectional, batch_first) (model.py:399):
+    per layer one MFMA GEMM for both directions' input projections + one persistent cooperative kernel for the
+    recurrence (gvd_gru_bidir_layer).  x [B,T,1024] -> [B,T,1024]."""
+    require_cuda_f32(x)
+    B, T, _ = x.shape
+    Hh = gru.hidden_size
+    inp = x.contiguous()
+    for l in range(gru.num_layers):
+        g = lambda n: getattr(gru, '%s_l%d' % (n, l)).detach()
+        gr = lambda n: getattr(gru, '%s_l%d_reverse' % (n, l)).detach()
+        w_ih = torch.cat([g('weight_ih'), gr('weight_ih')], 0)
+        b_ih = torch.cat([g('bias_ih'), gr('bias_ih')], 0)
+        gi = gemm_nt(inp.view(B * T, -1), w_ih, b_ih)                      # [B*T, 6*Hh]
+        out = torch.empty(B, T, 2 * Hh, device=x.device, dtype=torch.float32)
+        w_f, w_b = g('weight_hh').contiguous(), gr('weight_hh').contiguous()
+        b_f, b_b = g('bias_hh').contiguous(), gr('bias_hh').contiguous()
+        check(lib().gvd_gru_bidir_layer(ptr(gi), ptr(w_f), ptr(b_f), ptr(w_b), ptr(b_b), ptr(out), B, T, Hh,
+                                        stream_ptr()), 'gvd_gru_bidir_layer')
+        inp = out
+    return inp

@@ -142,6 +142,15 @@ int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_side* temporal
                       void* workspace, gvd_prof* prof, gvd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Frame-wise context encoder: one bidirectional GRU layer as a persistent cooperative kernel
+ * (nn.GRU(1024, 512, 2, bidirectional, batch_first), model.py:150-154,399; gate order r,z,n).
+ * gi [B,T,2,3*Hh] = X [W_ih_fw ; W_ih_bw]^T + [b_ih_fw ; b_ih_bw] (one gvd_gemm_nt_f32 call, N = 6*Hh);
+ * out [B,T,2*Hh] = [h_fw | h_bw] exactly like torch's batch_first bidirectional output.  Hh must be 512.
+ * ------------------------------------------------------------------------------------------- */
+int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const float* b_hh_fw, const float* w_hh_bw,
+                        const float* b_hh_bw, float* out, int B, int T, int Hh, gvd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Backward of the teacher-forced decoder loop (hand-scheduled BPTT; replaces autograd's per-op backward of
  * AttModel.py:33-53,71-108,138-160).  The dX / dW products are plain library GEMMs done by the caller.
  * ------------------------------------------------------------------------------------------- */

@@ -179,3 +179,22 @@ def test_masked_lsm_loss():
     ref = -torch.masked_select(torch.log_softmax(x, 2), lab.bool()).mean()
     out, _ = ops.masked_lsm_loss(x.cuda(), lab.cuda())
     assert abs(float(out) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+
+
+@pytest.mark.parametrize('B,T', [(3, 10), (2, 480), (40, 37), (70, 12), (257, 5)])
+def test_gru_persistent_kernel(B, T):
+    """Persistent cooperative bi-GRU (2 layers) vs the oracle's explicit time-loop GRU; repeated launches must
+    be bitwise repeatable (a cross-workgroup visibility race would show up as run-to-run differences)."""
+    opt = gvd_amd.opts.default_opt(vocab_size=10)
+    sd = gvd_amd.synth.init_state_dict(opt, seed=5)
+    gru = torch.nn.GRU(1024, 512, 2, dropout=0.2, bidirectional=True, batch_first=True)
+    gru.load_state_dict({k[len('context_enc.'):]: v for k, v in sd.items() if k.startswith('context_enc.')})
+    x = torch.randn(B, T, 1024, generator=_g(B * T))
+    with torch.no_grad():
+        ref = O.gru_bidir_2layer_loop(x, sd)
+        gru = gru.cuda().eval()
+        xc = x.cuda()
+        outs = [ops.gru_bidir_2layer(xc, gru) for _ in range(3)]
+        torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=5e-5)

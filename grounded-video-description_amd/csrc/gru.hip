@@ -72,32 +72,58 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? step : T - 1 - step;
     const int tp = dir == 0 ? t - 1 : t + 1;
+    const int64_t off_t = (int64_t)t * 2 * GRU_HH + dir * GRU_HH;
+    const int64_t off_tp = (int64_t)tp * 2 * GRU_HH + dir * GRU_HH;
+
+    // (1) issue the gate-phase inputs of every batch tile now (gi_r, gi_z, gi_n, own h_{t-1}): their latency
+    //     hides behind the MFMA phase instead of being paid once per tile after each LDS reduction
+    float pre_r[MAX_TILES], pre_z[MAX_TILES], pre_n[MAX_TILES], pre_h[MAX_TILES];
+#pragma unroll
+    for (int mt = 0; mt < MAX_TILES; ++mt) {
+      pre_r[mt] = pre_z[mt] = pre_n[mt] = pre_h[mt] = 0.f;
+      const int b = mt * 32 + g_row;
+      if (mt < ntiles && b < B) {
+        const float* gip = p.gi + (int64_t)b * ld_gi + (int64_t)t * 6 * GRU_HH + dir * 3 * GRU_HH + j0 + g_jj;
+        pre_r[mt] = gip[0]; pre_z[mt] = gip[GRU_HH]; pre_n[mt] = gip[2 * GRU_HH];
+        if (step > 0) pre_h[mt] = p.out[(int64_t)b * ld_out + off_tp + j0 + g_jj];
+      }
+    }
+
+    // (2) gh partials: h_{t-1}[b, k] lives in out[b, tp, dir*Hh + k]; lane supplies A[i = col][k = 128*wave + 8*kb +
+    //     4*half + s].  The 16 x 16-byte loads of tile mt+1 are in flight while the 64 MFMAs of tile mt issue.
     f32x16 acc[MAX_TILES];
 #pragma unroll
     for (int mt = 0; mt < MAX_TILES; ++mt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
     if (step > 0) {
-      // h_{t-1}[b, k] lives in out[b, tp, dir*Hh + k]; lane supplies A[i = col][k = 128*wave + 8*kb + 4*half + s]
+      f32x4 abuf[2][16];
+      auto load_a = [&](f32x4* dst, int mt) {
+        const int b = mt * 32 + col;
+        const bool ok = b < B;
+        const float* hp = p.out + (int64_t)(ok ? b : 0) * ld_out + off_tp + wave * 128 + half * 4;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+          if (ok) a = *reinterpret_cast<const f32x4*>(hp + kb * 8);
+          dst[kb] = a;
+        }
+      };
+      load_a(abuf[0], 0);
 #pragma unroll
       for (int mt = 0; mt < MAX_TILES; ++mt) {
         if (mt < ntiles) {
-          const int b = mt * 32 + col;
-          const bool ok = b < B;
-          const float* hp = p.out + (int64_t)(ok ? b : 0) * ld_out + (int64_t)tp * 2 * GRU_HH + dir * GRU_HH + wave * 128 +
-                            half * 4;
+          if (mt + 1 < ntiles) load_a(abuf[(mt + 1) & 1], mt + 1);
 #pragma unroll
-          for (int kb = 0; kb < 16; ++kb) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            if (ok) a = *reinterpret_cast<const f32x4*>(hp + kb * 8);
+          for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-              acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wreg[kb][s], acc[mt], 0, 0, 0);
-          }
+              acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(abuf[mt & 1][kb][s], wreg[kb][s], acc[mt], 0, 0, 0);
         }
       }
     }
-    // ---- per batch tile: sum the 4 K-quarter partials through LDS, gate math, write h_t
+
+    // (3) per batch tile: sum the 4 K-quarter partials through LDS, gate math, write h_t
 #pragma unroll
     for (int mt = 0; mt < MAX_TILES; ++mt) {
       if (mt < ntiles) {
@@ -111,20 +137,18 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
         __syncthreads();
         const int b = mt * 32 + g_row;
         if (b < B) {
-          float gr = bh_r, gz = bh_z, gn = bh_n, hprev = 0.f;
+          float gr = bh_r, gz = bh_z, gn = bh_n;
           if (step > 0) {
             gr += s_part[0][g_row][g_jj] + s_part[1][g_row][g_jj] + s_part[2][g_row][g_jj] + s_part[3][g_row][g_jj];
             gz += s_part[0][g_row][GRU_HU + g_jj] + s_part[1][g_row][GRU_HU + g_jj] + s_part[2][g_row][GRU_HU + g_jj] +
                   s_part[3][g_row][GRU_HU + g_jj];
             gn += s_part[0][g_row][2 * GRU_HU + g_jj] + s_part[1][g_row][2 * GRU_HU + g_jj] +
                   s_part[2][g_row][2 * GRU_HU + g_jj] + s_part[3][g_row][2 * GRU_HU + g_jj];
-            hprev = p.out[(int64_t)b * ld_out + (int64_t)tp * 2 * GRU_HH + dir * GRU_HH + j0 + g_jj];
           }
-          const float* gip = p.gi + (int64_t)b * ld_gi + (int64_t)t * 6 * GRU_HH + dir * 3 * GRU_HH + j0 + g_jj;
-          const float r = sigmoid_f(gip[0] + gr);
-          const float z = sigmoid_f(gip[GRU_HH] + gz);
-          const float n = tanhf(gip[2 * GRU_HH] + r * gn);
-          p.out[(int64_t)b * ld_out + (int64_t)t * 2 * GRU_HH + dir * GRU_HH + j0 + g_jj] = (1.f - z) * n + z * hprev;
+          const float r = sigmoid_f(pre_r[mt] + gr);
+          const float z = sigmoid_f(pre_z[mt] + gz);
+          const float n = tanhf(pre_n[mt] + r * gn);
+          p.out[(int64_t)b * ld_out + off_t + j0 + g_jj] = (1.f - z) * n + z * pre_h[mt];
         }
         __syncthreads();
       }

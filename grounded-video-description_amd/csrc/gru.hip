@@ -28,19 +28,45 @@ namespace {
 constexpr int GRU_HH = 512;     // hidden size per direction
 constexpr int GRU_HU = 8;       // hidden units per workgroup
 constexpr int GRU_NW = GRU_HH / GRU_HU;   // workgroups per direction
-constexpr int MAX_TILES = 8;    // batch tiles of 32 rows per pass (B <= 256 per launch)
+constexpr int MAX_TILES = 8;    // batch tiles of 32 rows per launch (B <= 256 per launch)
+constexpr int LDA = GRU_HH + 4; // padded LDS row of an h tile: conflict-free ds_read_b128 over 32 rows
+constexpr unsigned SPIN_LIMIT = 4000000u;
 
 struct GruParams {
   const float* gi;       // [B, T, 2, 3*Hh]  input projections incl. b_ih (row stride = 6*Hh)
   const float* w_hh[2];  // [3*Hh, Hh] per direction
   const float* b_hh[2];  // [3*Hh]
   float* out;            // [B, T, 2*Hh]
+  unsigned* sync;        // [2]: monotonic arrival counter, error flag (zeroed by the host before the launch)
   int B, T;
 };
 
+// Grid-wide barrier, placement independent (cdna_hip_programming.md §6 Guideline 16, counter form): every wave
+// drains its own stores, one lane does the agent-scope release (L2 write-back) + arrival, polls the monotonic
+// counter relaxed with s_sleep, then ONE agent-scope acquire drops this CU's stale L1 lines; __syncthreads()
+// extends both to the workgroup.  Spins are bounded: on timeout an error flag is raised and the kernel
+// finishes (wrong values, reported by the host) instead of hanging the GPU.
+__device__ __forceinline__ void grid_barrier(unsigned* sync, unsigned target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > SPIN_LIMIT) { __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+template <bool CG_SYNC>
 __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
+  __shared__ __attribute__((aligned(16))) float s_a[2][32 * LDA];   // double-buffered h_{t-1} batch tiles
   __shared__ float s_part[4][32][33];
-  cg::grid_group grid = cg::this_grid();
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, half = lane >> 5;
   const int dir = blockIdx.x / GRU_NW;
@@ -49,8 +75,10 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
   const int ntiles = (B + 31) / 32;
   const int64_t ld_out = (int64_t)T * 2 * GRU_HH;     // batch stride of out
   const int64_t ld_gi = (int64_t)T * 6 * GRU_HH;
+  const unsigned nwg = gridDim.x;
 
-  // ---- this lane's slice of W_hh: column `col` of the tile = gate col/HU, unit j0 + col%HU (cols >= 24 unused)
+  // ---- this lane's slice of W_hh: column `col` of the tile = gate col/HU, unit j0 + col%HU (cols >= 24 unused);
+  //      register-resident for the whole sequence
   f32x4 wreg[16];
   {
     const bool used = col < 3 * GRU_HU;
@@ -68,6 +96,8 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
   const float bh_r = p.b_hh[dir][j0 + g_jj];
   const float bh_z = p.b_hh[dir][GRU_HH + j0 + g_jj];
   const float bh_n = p.b_hh[dir][2 * GRU_HH + j0 + g_jj];
+  // staging role: 16 x 16-byte pieces per thread per tile; piece i -> tile row (tid + 256 i) / 128, float4 column % 128
+  // (a wave-load covers 1 KiB contiguous of one sample's h_{t-1}: fully coalesced)
 
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? step : T - 1 - step;
@@ -75,109 +105,122 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
     const int64_t off_t = (int64_t)t * 2 * GRU_HH + dir * GRU_HH;
     const int64_t off_tp = (int64_t)tp * 2 * GRU_HH + dir * GRU_HH;
 
-    // (1) issue the gate-phase inputs of every batch tile now (gi_r, gi_z, gi_n, own h_{t-1}): their latency
-    //     hides behind the MFMA phase instead of being paid once per tile after each LDS reduction
-    float pre_r[MAX_TILES], pre_z[MAX_TILES], pre_n[MAX_TILES], pre_h[MAX_TILES];
+    f32x4 ra[16];
+    auto load_tile = [&](int mt) {
 #pragma unroll
-    for (int mt = 0; mt < MAX_TILES; ++mt) {
-      pre_r[mt] = pre_z[mt] = pre_n[mt] = pre_h[mt] = 0.f;
-      const int b = mt * 32 + g_row;
-      if (mt < ntiles && b < B) {
-        const float* gip = p.gi + (int64_t)b * ld_gi + (int64_t)t * 6 * GRU_HH + dir * 3 * GRU_HH + j0 + g_jj;
-        pre_r[mt] = gip[0]; pre_z[mt] = gip[GRU_HH]; pre_n[mt] = gip[2 * GRU_HH];
-        if (step > 0) pre_h[mt] = p.out[(int64_t)b * ld_out + off_tp + j0 + g_jj];
+      for (int i = 0; i < 16; ++i) {
+        const int idx = tid + i * 256;
+        const int b = mt * 32 + (idx >> 7);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (b < B) v = *reinterpret_cast<const f32x4*>(p.out + (int64_t)b * ld_out + off_tp + (idx & 127) * 4);
+        ra[i] = v;
       }
-    }
+    };
+    auto store_tile = [&](float* buf) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int idx = tid + i * 256;
+        *reinterpret_cast<f32x4*>(&buf[(idx >> 7) * LDA + (idx & 127) * 4]) = ra[i];
+      }
+    };
+    // gate-phase inputs (gi_r, gi_z, gi_n, own h_{t-1}) are fetched one batch tile ahead so their latency hides
+    // behind the MFMA phase of the current tile
+    float cur_r = 0.f, cur_z = 0.f, cur_n = 0.f, cur_h = 0.f, nxt_r = 0.f, nxt_z = 0.f, nxt_n = 0.f, nxt_h = 0.f;
+    auto load_gate_inputs = [&](int mt, float& r_, float& z_, float& n_, float& h_) {
+      const int b = mt * 32 + g_row;
+      r_ = z_ = n_ = h_ = 0.f;
+      if (b < B) {
+        const float* gip = p.gi + (int64_t)b * ld_gi + (int64_t)t * 6 * GRU_HH + dir * 3 * GRU_HH + j0 + g_jj;
+        r_ = gip[0]; z_ = gip[GRU_HH]; n_ = gip[2 * GRU_HH];
+        if (step > 0) h_ = p.out[(int64_t)b * ld_out + off_tp + j0 + g_jj];
+      }
+    };
+    load_gate_inputs(0, cur_r, cur_z, cur_n, cur_h);
+    if (step > 0) load_tile(0);
 
-    // (2) gh partials: h_{t-1}[b, k] lives in out[b, tp, dir*Hh + k]; lane supplies A[i = col][k = 128*wave + 8*kb +
-    //     4*half + s].  The 16 x 16-byte loads of tile mt+1 are in flight while the 64 MFMAs of tile mt issue.
-    f32x16 acc[MAX_TILES];
+    // per batch tile: stage h_{t-1} through LDS, gh partials on the MFMA (lane supplies A[i = col][k = 128*wave +
+    // 8*kb + 4*half + s]), K-quarter partials summed through LDS, gate math, write h_t
+#pragma unroll 1
+    for (int mt = 0; mt < ntiles; ++mt) {
+      if (step > 0) {
+        float* abuf = s_a[mt & 1];
+        store_tile(abuf);
+        __syncthreads();
+        if (mt + 1 < ntiles) load_tile(mt + 1);            // next tile's loads fly during this tile's MFMAs
+        f32x16 acc;
 #pragma unroll
-    for (int mt = 0; mt < MAX_TILES; ++mt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
-    if (step > 0) {
-      f32x4 abuf[2][16];
-      auto load_a = [&](f32x4* dst, int mt) {
-        const int b = mt * 32 + col;
-        const bool ok = b < B;
-        const float* hp = p.out + (int64_t)(ok ? b : 0) * ld_out + off_tp + wave * 128 + half * 4;
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const float* ap = abuf + col * LDA + wave * 128 + half * 4;
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) {
-          f32x4 a = {0.f, 0.f, 0.f, 0.f};
-          if (ok) a = *reinterpret_cast<const f32x4*>(hp + kb * 8);
-          dst[kb] = a;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kb * 8);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wreg[kb][s], acc, 0, 0, 0);
         }
-      };
-      load_a(abuf[0], 0);
 #pragma unroll
-      for (int mt = 0; mt < MAX_TILES; ++mt) {
-        if (mt < ntiles) {
-          if (mt + 1 < ntiles) load_a(abuf[(mt + 1) & 1], mt + 1);
-#pragma unroll
-          for (int kb = 0; kb < 16; ++kb)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-              acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(abuf[mt & 1][kb][s], wreg[kb][s], acc[mt], 0, 0, 0);
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+          s_part[wave][row][col] = acc[e];
         }
       }
-    }
-
-    // (3) per batch tile: sum the 4 K-quarter partials through LDS, gate math, write h_t
-#pragma unroll
-    for (int mt = 0; mt < MAX_TILES; ++mt) {
-      if (mt < ntiles) {
+      if (mt + 1 < ntiles) load_gate_inputs(mt + 1, nxt_r, nxt_z, nxt_n, nxt_h);
+      __syncthreads();
+      const int b = mt * 32 + g_row;
+      if (b < B) {
+        float gr = bh_r, gz = bh_z, gn = bh_n;
         if (step > 0) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-            s_part[wave][row][col] = acc[mt][e];
-          }
+          gr += s_part[0][g_row][g_jj] + s_part[1][g_row][g_jj] + s_part[2][g_row][g_jj] + s_part[3][g_row][g_jj];
+          gz += s_part[0][g_row][GRU_HU + g_jj] + s_part[1][g_row][GRU_HU + g_jj] + s_part[2][g_row][GRU_HU + g_jj] +
+                s_part[3][g_row][GRU_HU + g_jj];
+          gn += s_part[0][g_row][2 * GRU_HU + g_jj] + s_part[1][g_row][2 * GRU_HU + g_jj] +
+                s_part[2][g_row][2 * GRU_HU + g_jj] + s_part[3][g_row][2 * GRU_HU + g_jj];
         }
-        __syncthreads();
-        const int b = mt * 32 + g_row;
-        if (b < B) {
-          float gr = bh_r, gz = bh_z, gn = bh_n;
-          if (step > 0) {
-            gr += s_part[0][g_row][g_jj] + s_part[1][g_row][g_jj] + s_part[2][g_row][g_jj] + s_part[3][g_row][g_jj];
-            gz += s_part[0][g_row][GRU_HU + g_jj] + s_part[1][g_row][GRU_HU + g_jj] + s_part[2][g_row][GRU_HU + g_jj] +
-                  s_part[3][g_row][GRU_HU + g_jj];
-            gn += s_part[0][g_row][2 * GRU_HU + g_jj] + s_part[1][g_row][2 * GRU_HU + g_jj] +
-                  s_part[2][g_row][2 * GRU_HU + g_jj] + s_part[3][g_row][2 * GRU_HU + g_jj];
-          }
-          const float r = sigmoid_f(pre_r[mt] + gr);
-          const float z = sigmoid_f(pre_z[mt] + gz);
-          const float n = tanhf(pre_n[mt] + r * gn);
-          p.out[(int64_t)b * ld_out + off_t + j0 + g_jj] = (1.f - z) * n + z * pre_h[mt];
-        }
-        __syncthreads();
+        const float r = sigmoid_f(cur_r + gr);
+        const float z = sigmoid_f(cur_z + gz);
+        const float n = tanhf(cur_n + r * gn);
+        p.out[(int64_t)b * ld_out + off_t + j0 + g_jj] = (1.f - z) * n + z * cur_h;
       }
+      cur_r = nxt_r; cur_z = nxt_z; cur_n = nxt_n; cur_h = nxt_h;
+      // s_part is rewritten only after the next tile's staging barrier (or the grid barrier); s_a[mt&1] is rewritten
+      // two tiles later, i.e. after two more barriers: no extra barrier needed here.  For step == 0 (no staging
+      // barrier) s_part is not used at all.
     }
-    // every storing wave drains its own stores before the barrier inside grid.sync(): the sync's leader lane
-    // issues the agent-scope release (buffer_wbl2), which only covers stores that already reached L2
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    grid.sync();   // h_t of every slice visible to every workgroup before step t+1 reads it
+    // (3) publish h_t grid-wide before step t+1 reads it
+    if (CG_SYNC) {
+      // every storing wave drains its own stores: the library sync's leader lane issues the agent-scope release
+      // (buffer_wbl2), which only covers stores that already reached L2
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      cg::this_grid().sync();
+    } else {
+      grid_barrier(p.sync, (unsigned)(step + 1) * nwg);
+    }
   }
 }
 
 }  // namespace
 
 extern "C" int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const float* b_hh_fw, const float* w_hh_bw,
-                                   const float* b_hh_bw, float* out, int B, int T, int Hh, gvd_stream_t stream) {
+                                   const float* b_hh_bw, float* out, int B, int T, int Hh, void* sync_ws,
+                                   gvd_stream_t stream) {
   if (!gi || !w_hh_fw || !b_hh_fw || !w_hh_bw || !b_hh_bw || !out || B <= 0 || T <= 0 || Hh != GRU_HH) return GVD_EINVAL;
   if (!gvd_aligned16(gi) || !gvd_aligned16(w_hh_fw) || !gvd_aligned16(w_hh_bw) || !gvd_aligned16(out)) return GVD_EINVAL;
   hipStream_t st = gvd_s(stream);
+  const int nslices = (B + MAX_TILES * 32 - 1) / (MAX_TILES * 32);
   // batches beyond MAX_TILES*32 rows run as consecutive launches over batch slices (samples are independent)
-  for (int b0 = 0; b0 < B; b0 += MAX_TILES * 32) {
+  for (int si = 0; si < nslices; ++si) {
+    const int b0 = si * MAX_TILES * 32;
     GruParams p;
     const int nb = (B - b0 < MAX_TILES * 32) ? (B - b0) : MAX_TILES * 32;
     p.gi = gi + (int64_t)b0 * T * 6 * GRU_HH;
     p.w_hh[0] = w_hh_fw; p.w_hh[1] = w_hh_bw; p.b_hh[0] = b_hh_fw; p.b_hh[1] = b_hh_bw;
     p.out = out + (int64_t)b0 * T * 2 * GRU_HH;
     p.B = nb; p.T = T;
+    p.sync = sync_ws ? reinterpret_cast<unsigned*>(sync_ws) + 2 * si : nullptr;
     void* args[] = {&p};
-    hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gru_layer_kernel), dim3(2 * GRU_NW), dim3(256),
-                                              args, 0, st);
+    // cooperative launch in both modes: it validates that all 128 workgroups are co-resident
+    const void* fn = sync_ws ? reinterpret_cast<const void*>(gru_layer_kernel<false>)
+                             : reinterpret_cast<const void*>(gru_layer_kernel<true>);
+    hipError_t e = hipLaunchCooperativeKernel(fn, dim3(2 * GRU_NW), dim3(256), args, 0, st);
     if (e != hipSuccess) return (int)e;
   }
   return 0;

@@ -3,6 +3,7 @@ libgvd_hip.so (include/gvd_hip.h).  All compute happens in the HIP library; torc
 device memory and the current stream.  No CPU/eager fallback exists: non-GPU tensors raise.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -421,7 +422,10 @@ def attn_bwd_pfeats(p_feats, q_all, de_all, w):
     return out
 
 
-def gru_bidir_2layer(x, gru):
+GRU_BARRIER = os.environ.get('GVD_GRU_BARRIER', 'counter')   # 'counter' (hand-rolled) | 'cg' (library grid sync)
+
+
+def gru_bidir_2layer(x, gru, barrier=None):
     """Inference forward of the frame encoder nn.GRU(1024, 512, 2, bidirectional, batch_first) (model.py:399):
     per layer one MFMA GEMM for both directions' input projections + one persistent cooperative kernel for the
     recurrence (gvd_gru_bidir_layer).  x [B,T,1024] -> [B,T,1024]."""
@@ -429,6 +433,7 @@ def gru_bidir_2layer(x, gru):
     B, T, _ = x.shape
     Hh = gru.hidden_size
     inp = x.contiguous()
+    syncs = []
     for l in range(gru.num_layers):
         g = lambda n: getattr(gru, '%s_l%d' % (n, l)).detach()
         gr = lambda n: getattr(gru, '%s_l%d_reverse' % (n, l)).detach()
@@ -438,7 +443,12 @@ def gru_bidir_2layer(x, gru):
         out = torch.empty(B, T, 2 * Hh, device=x.device, dtype=torch.float32)
         w_f, w_b = g('weight_hh').contiguous(), gr('weight_hh').contiguous()
         b_f, b_b = g('bias_hh').contiguous(), gr('bias_hh').contiguous()
+        sync = None
+        if (barrier or GRU_BARRIER) == 'counter':
+            sync = torch.zeros(2 * ((B + 255) // 256), dtype=torch.int32, device=x.device)
+            syncs.append(sync)
         check(lib().gvd_gru_bidir_layer(ptr(gi), ptr(w_f), ptr(b_f), ptr(w_b), ptr(b_b), ptr(out), B, T, Hh,
-                                        stream_ptr()), 'gvd_gru_bidir_layer')
+                                        ptr(sync), stream_ptr()), 'gvd_gru_bidir_layer')
         inp = out
+    gru_bidir_2layer.last_sync = syncs     # tests read the timeout flags (word 1 of each pair) after a device sync
     return inp

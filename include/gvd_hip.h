@@ -147,8 +147,12 @@ int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_side* temporal
  * gi [B,T,2,3*Hh] = X [W_ih_fw ; W_ih_bw]^T + [b_ih_fw ; b_ih_bw] (one gvd_gemm_nt_f32 call, N = 6*Hh);
  * out [B,T,2*Hh] = [h_fw | h_bw] exactly like torch's batch_first bidirectional output.  Hh must be 512.
  * ------------------------------------------------------------------------------------------- */
+/* sync_ws: NULL -> grid-wide synchronisation by the HIP cooperative-groups library; otherwise a device buffer of
+ * 2*ceil(B/256) uint32 ZEROED by the caller before every call -> hand-rolled counter barrier (agent-scope
+ * release/acquire, bounded spin).  After the call word [2*i+1] != 0 means slice i timed out (results invalid). */
 int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const float* b_hh_fw, const float* w_hh_bw,
-                        const float* b_hh_bw, float* out, int B, int T, int Hh, gvd_stream_t stream);
+                        const float* b_hh_bw, float* out, int B, int T, int Hh, void* sync_ws,
+                        gvd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward of the teacher-forced decoder loop (hand-scheduled BPTT; replaces autograd's per-op backward of

@@ -181,8 +181,9 @@ def test_masked_lsm_loss():
     assert abs(float(out) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
 
 
+@pytest.mark.parametrize('barrier', ['counter', 'cg'])
 @pytest.mark.parametrize('B,T', [(3, 10), (2, 480), (40, 37), (70, 12), (257, 5)])
-def test_gru_persistent_kernel(B, T):
+def test_gru_persistent_kernel(B, T, barrier):
     """Persistent cooperative bi-GRU (2 layers) vs the oracle's explicit time-loop GRU; repeated launches must
     be bitwise repeatable (a cross-workgroup visibility race would show up as run-to-run differences)."""
     opt = gvd_amd.opts.default_opt(vocab_size=10)
@@ -194,7 +195,12 @@ def test_gru_persistent_kernel(B, T):
         ref = O.gru_bidir_2layer_loop(x, sd)
         gru = gru.cuda().eval()
         xc = x.cuda()
-        outs = [ops.gru_bidir_2layer(xc, gru) for _ in range(3)]
+        outs, flags = [], []
+        for _ in range(3):
+            outs.append(ops.gru_bidir_2layer(xc, gru, barrier=barrier))
+            flags += ops.gru_bidir_2layer.last_sync
         torch.cuda.synchronize()
+    for f in flags:                                   # counter barrier: no workgroup timed out
+        assert int(f.view(-1, 2)[:, 1].sum()) == 0
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     np.testing.assert_allclose(outs[0].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=5e-5)

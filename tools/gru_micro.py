@@ -13,7 +13,9 @@ def timeit(f, n):
 for B, T, n in ((4, 480, 5), (4, 10, 20), (32, 480, 5), (256, 480, 3), (256, 10, 10)):
     x = torch.randn(B, T, 1024, device='cuda')
     with torch.no_grad():
-        a = timeit(lambda: ops.gru_bidir_2layer(x, gru), n)
+        a = timeit(lambda: ops.gru_bidir_2layer(x, gru, barrier='counter'), n)
+        c = timeit(lambda: ops.gru_bidir_2layer(x, gru, barrier='cg'), n)
         b = timeit(lambda: gru(x)[0], n)
-        d = (ops.gru_bidir_2layer(x, gru) - gru(x)[0]).abs().max().item()
-    print('B=%d T=%d: hip %.2f ms (%.1f us/step/layer), miopen %.2f ms, maxdiff %.2e' % (B, T, a, a * 1e3 / (2 * T), b, d))
+        d = (ops.gru_bidir_2layer(x, gru, barrier='counter') - gru(x)[0]).abs().max().item()
+    print('B=%d T=%d: hip counter-barrier %.2f ms (%.1f us/step/layer), cg-sync %.2f ms, miopen %.2f ms, maxdiff %.2e'
+          % (B, T, a, a * 1e3 / (2 * T), c, b, d))

@@ -142,9 +142,21 @@ def main():
     B = args.batch or (256 if args.mode == 'sample' else 64)
     if args.mode == 'train':
         return bench_train(args, opt, sd, model, B, rank, world, dev)
-    inp = synth.make_inputs(opt, B, seed=100 + rank, train=False)     # each rank: its own shard of segments
+    # each rank: its own shard of segments.  The CPU generator is slow for 2 GB of features, so a 32-segment base
+    # batch is generated from the seed and tiled (with a per-copy perturbation of the float features) up to B
+    base_n = min(B, 32)
+    inp = synth.make_inputs(opt, base_n, seed=100 + rank, train=False)
     keys = ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')
-    dinp = [inp[k].to(dev) for k in keys]
+    reps = (B + base_n - 1) // base_n
+    dinp = []
+    for k in keys:
+        t = inp[k].to(dev)
+        if reps > 1:
+            t = t.repeat(reps, *([1] * (t.dim() - 1)))[:B].contiguous()
+            if k in ('segs_feat', 'ppls_feat'):
+                scale = 1.0 + 0.01 * torch.arange(B, device=dev, dtype=torch.float32).div(base_n, rounding_mode='floor')
+                t = t * scale.view(B, *([1] * (t.dim() - 1)))
+        dinp.append(t)
     timer = hip.KernelTimer(max_pairs=opt.seq_length * max(args.steps, 1))
     model.kernel_timer = None
 

@@ -4,7 +4,8 @@ set -u
 R=$PWD
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/test.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/test.log
+(timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"); tail -2 gpurun_out/smoke.log
+timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/test.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/test.log
 timeout 600 python bench.py --steps 10 --warmup 2 > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -2 gpurun_out/bench.log
 timeout 300 python bench.py --steps 20 --warmup 3 --batch 4 --no-cpu-baseline > gpurun_out/bench_b4.log 2>&1; tail -1 gpurun_out/bench_b4.log
 cd /tmp

@@ -179,6 +179,7 @@ class TopDownModel(nn.Module):
         no padding mask, custom LayerNorm).  Library GEMMs for now."""
         d = x.shape[-1]
         scale = math.sqrt(d)
+        fused = not torch.is_grad_enabled()
         for lay in self.obj_interact.encoder.layers:
             sa = lay.selfattn.layer
             q, k, v = sa.wq(x), sa.wk(x), sa.wv(x)
@@ -193,10 +194,17 @@ class TopDownModel(nn.Module):
                 w = F.softmax(dots if exact else dots / scale, dim=-1)
                 heads.append(torch.matmul(F.dropout(w, 0.2, self.training), vh))
             att = sa.wo(torch.cat(heads, -1))
-            x = lay.selfattn.layernorm(x + F.dropout(att, 0.2, self.training))
             ff = lay.feedforward.layer
-            y = ff.linear2(F.relu(ff.linear1(x)))
-            x = lay.feedforward.layernorm(x + F.dropout(y, 0.2, self.training))
+            if fused:   # inference: residual add + custom LayerNorm as one HIP row kernel
+                ln = lay.selfattn.layernorm
+                x = ops.add_layernorm_unbiased(x.contiguous(), att, ln.gamma, ln.beta, ln.eps)
+                y = ff.linear2(F.relu(ff.linear1(x)))
+                ln = lay.feedforward.layernorm
+                x = ops.add_layernorm_unbiased(x, y, ln.gamma, ln.beta, ln.eps)
+            else:
+                x = lay.selfattn.layernorm(x + F.dropout(att, 0.2, self.training))
+                y = ff.linear2(F.relu(ff.linear1(x)))
+                x = lay.feedforward.layernorm(x + F.dropout(y, 0.2, self.training))
         return x
 
     def _preamble(self, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask):
@@ -212,16 +220,24 @@ class TopDownModel(nn.Module):
         fc = torch.cat([F.layer_norm(fc, [fc.shape[-1]]), F.layer_norm(seg_info, [self.seg_info_size])], dim=-1)
         # fc7 over the raw fc6 region features: MFMA GEMM + fused bias/ReLU (model.py:311-313)
         g_pool = self._drop(self._lin(ppls_feat, self.ctx2pool_grd[0], act=1))
-        # region-class similarity: batched grounder GEMM with fused bias + proposal mask (model.py:321-340)
         vis_word = self._drop(F.relu(self.vis_embed[0].weight))
-        sim_logits = ops.grounder(vis_word, g_pool, pm[:, 1:], mbias=self.vis_classifiers_bias, xt_shared=True)
-        sim_mat = F.softmax(sim_logits, dim=1)
-        # location / class-distribution features (model.py:357-364)
         loc_in = torch.cat([ppls[:, :, :4] / 720., (ppls[:, :, 4] * 1. / self.num_sampled_frm).unsqueeze(-1)], dim=2)
         loc = F.dropout(F.relu(self.loc_fc[0](loc_in)), 0.5, self.training)
-        label = sim_mat.permute(0, 2, 1)
-        pool = torch.cat([F.layer_norm(g_pool, [g_pool.shape[-1]]), F.layer_norm(loc, [300]),
-                          F.layer_norm(label, [D1])], dim=2)
+        if not torch.is_grad_enabled():
+            # inference: class-last similarity logits from ONE plain MFMA GEMM (the visual words are shared by the
+            # batch), then mask + class softmax + the three layer norms + concat as one HIP row kernel
+            # (model.py:321-340,357-364)
+            logits_t = ops.gemm_nt(g_pool, vis_word.detach(), self.vis_classifiers_bias.detach())     # [B,R,D1]
+            pool, sim_t = ops.region_feature_rows(g_pool, loc.contiguous(), logits_t, pm)
+            sim_mat = sim_t.transpose(1, 2)          # [B,D1,R] view (the reference returns this layout)
+        else:
+            # region-class similarity: batched grounder GEMM with fused bias + proposal mask (model.py:321-340)
+            sim_logits = ops.grounder(vis_word, g_pool, pm[:, 1:], mbias=self.vis_classifiers_bias, xt_shared=True)
+            sim_mat = F.softmax(sim_logits, dim=1)
+            # location / class-distribution features (model.py:357-364)
+            label = sim_mat.permute(0, 2, 1)
+            pool = torch.cat([F.layer_norm(g_pool, [g_pool.shape[-1]]), F.layer_norm(loc, [300]),
+                              F.layer_norm(label, [D1])], dim=2)
         fc = self._drop(F.relu(self.fc_embed[0](fc)))
         pool = self._drop(F.relu(self.pool_embed[0](pool)))
         if self.has_obj_interact:

@@ -19,6 +19,7 @@
 // (m, l, ctx) partials of both attentions and emits att+att2 for the language LSTM.
 // Algorithmic bytes per sample-call: N*(A+H)*4 (+2N mask bytes) — SURVEY.md §8d.
 #include "gvd_common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -47,6 +48,12 @@ struct FwdParams {
 };
 
 // workgroup (chunk c of side s, sample b)
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T* ptr, bool nt) {
+  return nt ? __builtin_nontemporal_load(ptr) : *ptr;
+}
+
+template <bool NT>
 __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   __shared__ float s_score[MAX_CHUNK];
   __shared__ float s_red[8];
@@ -78,10 +85,10 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
     const bool two = (r + 1) < rows;
     const float* p0 = pf + (int64_t)r * ATT_A;
     const float* p1 = two ? p0 + ATT_A : p0;
-    f32x4 x00 = *reinterpret_cast<const f32x4*>(p0 + 4 * lane);
-    f32x4 x01 = *reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane);
-    f32x4 x10 = *reinterpret_cast<const f32x4*>(p1 + 4 * lane);
-    f32x4 x11 = *reinterpret_cast<const f32x4*>(p1 + 256 + 4 * lane);
+    f32x4 x00 = ld_stream(reinterpret_cast<const f32x4*>(p0 + 4 * lane), NT);
+    f32x4 x01 = ld_stream(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane), NT);
+    f32x4 x10 = ld_stream(reinterpret_cast<const f32x4*>(p1 + 4 * lane), NT);
+    f32x4 x11 = ld_stream(reinterpret_cast<const f32x4*>(p1 + 256 + 4 * lane), NT);
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   for (; r + 8 <= rows; r += 8) {
     f32x4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(fb + (int64_t)(r + u) * ATT_H);
+    for (int u = 0; u < 8; ++u) v[u] = ld_stream(reinterpret_cast<const f32x4*>(fb + (int64_t)(r + u) * ATT_H), NT);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float pw = s_score[r + u];
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
     }
   }
   for (; r < rows; ++r) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(fb + (int64_t)r * ATT_H);
+    const f32x4 v = ld_stream(reinterpret_cast<const f32x4*>(fb + (int64_t)r * ATT_H), NT);
     const float pw = s_score[r];
     acc[0] = fmaf(pw, v[0], acc[0]); acc[1] = fmaf(pw, v[1], acc[1]);
     acc[2] = fmaf(pw, v[2], acc[2]); acc[3] = fmaf(pw, v[3], acc[3]);
@@ -216,8 +223,13 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const CombParams p) {
 }
 
 // rows per chunk: 50; halved (not below 13) while fewer than ~512 workgroups would exist (small batches)
+int tune_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 int pick_chunk(int N, int B) {
-  int chunk = 50;
+  int chunk = tune_int("GVD_ATTN_CHUNK", 50);   // tuning knob (rows per workgroup), default measured best
   while (chunk > 20 && (long)B * ((N + chunk - 1) / chunk) < 512) chunk = (chunk + 1) / 2;
   if (chunk > MAX_CHUNK) chunk = MAX_CHUNK;
   if (chunk > N) chunk = N;
@@ -264,7 +276,10 @@ extern "C" int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_sid
   p.part_ml = p.part_ctx + (int64_t)B * p.nctot * ATT_H;
   hipStream_t st = gvd_s(stream);
   gvd_prof_begin(prof, st);
-  hipLaunchKernelGGL(attn_partial_kernel, dim3((unsigned)p.nctot, (unsigned)B), dim3(256), 0, st, p);
+  if (tune_int("GVD_ATTN_NT", 0))
+    hipLaunchKernelGGL(attn_partial_kernel<true>, dim3((unsigned)p.nctot, (unsigned)B), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(attn_partial_kernel<false>, dim3((unsigned)p.nctot, (unsigned)B), dim3(256), 0, st, p);
   gvd_prof_end(prof, st);
   GVD_CHECK_LAUNCH();
   CombParams c = {};

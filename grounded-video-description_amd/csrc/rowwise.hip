@@ -1,0 +1,197 @@
+// Fused row kernels of the per-segment preamble (inference path), one 64-lane wave per row, no LDS:
+//
+//  gvd_add_layernorm_unbiased   out = gamma * (s - mean(s)) / (std_unbiased(s) + eps) + beta,  s = x + y
+//      = ResidualBlock + the encoder's custom LayerNorm (transformer.py:66-88: unbiased std, eps added to std)
+//      which the reference runs as ~8 separate [B,R,1024] elementwise/reduce ATen ops, 4x per forward.
+//  gvd_region_feature_rows      per proposal row (model.py:336-364):
+//      p = softmax_classes(sim_logits_row  (filled with -1e8 when the proposal is masked))   -> sim_out row
+//      out = [ layer_norm(g_pool_row, 2048) | layer_norm(loc_row, 300) | layer_norm(p, D1) ]      -> [2781]
+//      i.e. `_grounder` mask + F.softmax(dim=1) + permute + 3x F.layer_norm + torch.cat in ONE pass
+//      (reads 11 KB, writes 13 KB per row instead of ~8 passes over [B,R,2781]-sized tensors).
+// HBM-bound streaming kernels; values stay in registers between the statistics and the normalisation pass.
+#include "gvd_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <int D>   // D = 64 * 4 * NV
+__global__ __launch_bounds__(256) void add_ln_unbiased_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ out,
+                                                              int64_t rows, float eps) {
+  constexpr int NV = D / 256;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * D;
+  const float* yr = y ? y + row * D : nullptr;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + 4 * lane);
+    if (yr) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(yr + i * 256 + 4 * lane);
+      v[i][0] += w[0]; v[i][1] += w[1]; v[i][2] += w[2]; v[i][3] += w[3];
+    }
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q = fmaf(d, d, q); }
+  const float stdv = sqrtf(wave_sum(q) / (D - 1));
+  const float inv = 1.0f / (stdv + eps);
+  float* o = out + row * D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i * 256 + 4 * lane);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + i * 256 + 4 * lane);
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = g[k] * (v[i][k] - mean) * inv + b[k];
+    *reinterpret_cast<f32x4*>(o + i * 256 + 4 * lane) = r;
+  }
+}
+
+constexpr int RF_G = 2048;   // fc7 feature size
+constexpr int RF_MAXC = 8;   // per-lane slots for the loc (<= 512) and class (<= 512) segments
+
+__global__ __launch_bounds__(256) void region_feature_rows_kernel(const float* __restrict__ g_pool,
+                                                                  const float* __restrict__ loc, int n_loc,
+                                                                  const float* __restrict__ logits, int n_cls,
+                                                                  const uint8_t* __restrict__ row_mask,
+                                                                  int64_t mask_row_div, int64_t mask_ld,
+                                                                  float* __restrict__ out, float* __restrict__ sim_out,
+                                                                  int64_t rows, float ln_eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int out_ld = RF_G + n_loc + n_cls;
+  float* o = out + row * out_ld;
+
+  // ---- segment 1: F.layer_norm over the 2048 fc7 features (biased variance, eps inside the sqrt, no affine)
+  {
+    const float* gr = g_pool + row * RF_G;
+    f32x4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] = *reinterpret_cast<const f32x4*>(gr + i * 256 + 4 * lane);
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mean = wave_sum(s) / RF_G;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q = fmaf(d, d, q); }
+    const float rstd = rsqrtf(wave_sum(q) / RF_G + ln_eps);
+    // output rows are 2781 floats: not 16-byte aligned -> scalar stores, lane-contiguous (coalesced)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[i * 256 + 4 * lane + k] = (v[i][k] - mean) * rstd;
+  }
+  // ---- segment 2: layer_norm over the location embedding (n_loc = 300)
+  {
+    const float* lr = loc + row * n_loc;
+    float v[RF_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int c = i * 64 + lane;
+      v[i] = c < n_loc ? lr[c] : 0.f;
+      s += v[i];
+    }
+    const float mean = wave_sum(s) / n_loc;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int c = i * 64 + lane;
+      if (c < n_loc) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / n_loc + ln_eps);
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int c = i * 64 + lane;
+      if (c < n_loc) o[RF_G + c] = (v[i] - mean) * rstd;
+    }
+  }
+  // ---- segment 3: class softmax of the (masked) similarity logits, then layer_norm of the distribution
+  {
+    const float* sr = logits + row * n_cls;
+    const bool masked = row_mask && row_mask[(row / mask_row_div) * mask_ld + (row % mask_row_div)];
+    float v[RF_MAXC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int c = i * 64 + lane;
+      v[i] = c < n_cls ? (masked ? GVD_MIN_VALUE : sr[c]) : -INFINITY;
+      mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int c = i * 64 + lane;
+      v[i] = c < n_cls ? expf(v[i] - mx) : 0.f;
+      se += v[i];
+    }
+    const float inv = 1.0f / wave_sum(se);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) { v[i] *= inv; s += v[i]; }
+    if (sim_out) {
+#pragma unroll
+      for (int i = 0; i < RF_MAXC; ++i) {
+        const int c = i * 64 + lane;
+        if (c < n_cls) sim_out[row * n_cls + c] = v[i];
+      }
+    }
+    const float mean = wave_sum(s) / n_cls;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int c = i * 64 + lane;
+      if (c < n_cls) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / n_cls + ln_eps);
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int c = i * 64 + lane;
+      if (c < n_cls) o[RF_G + n_loc + c] = (v[i] - mean) * rstd;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int gvd_add_layernorm_unbiased(const float* x, const float* y, const float* gamma, const float* beta,
+                                          float* out, int64_t rows, int D, float eps, gvd_stream_t stream) {
+  if (!x || !gamma || !beta || !out || rows <= 0 || D != 1024) return GVD_EINVAL;
+  if (!gvd_aligned16(x) || (y && !gvd_aligned16(y)) || !gvd_aligned16(out) || !gvd_aligned16(gamma) || !gvd_aligned16(beta))
+    return GVD_EINVAL;
+  hipLaunchKernelGGL(add_ln_unbiased_kernel<1024>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, gvd_s(stream), x, y,
+                     gamma, beta, out, rows, eps);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gvd_region_feature_rows(const float* g_pool, const float* loc, int n_loc, const float* sim_logits,
+                                       int n_cls, const uint8_t* row_mask, int64_t mask_rows_per_batch,
+                                       int64_t mask_ld, float* out, float* sim_out, int64_t rows, int G, float ln_eps,
+                                       gvd_stream_t stream) {
+  if (!g_pool || !loc || !sim_logits || !out || rows <= 0 || G != RF_G || n_loc <= 0 || n_loc > 64 * RF_MAXC ||
+      n_cls <= 0 || n_cls > 64 * RF_MAXC || !gvd_aligned16(g_pool))
+    return GVD_EINVAL;
+  if (row_mask && mask_rows_per_batch <= 0) return GVD_EINVAL;
+  hipLaunchKernelGGL(region_feature_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, gvd_s(stream), g_pool,
+                     loc, n_loc, sim_logits, n_cls, row_mask, row_mask ? mask_rows_per_batch : 1, mask_ld, out, sim_out,
+                     rows, ln_eps);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}

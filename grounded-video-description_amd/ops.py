@@ -452,3 +452,33 @@ def gru_bidir_2layer(x, gru, barrier=None):
         inp = out
     gru_bidir_2layer.last_sync = syncs     # tests read the timeout flags (word 1 of each pair) after a device sync
     return inp
+
+
+def add_layernorm_unbiased(x, y, gamma, beta, eps=1e-6):
+    """gamma * (s - mean) / (std_unbiased + eps) + beta, s = x + y: residual + the encoder LayerNorm in one pass."""
+    require_cuda_f32(x, y, gamma, beta)
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    y2 = y.reshape(-1, D) if y is not None else None
+    assert x2.is_contiguous() and (y2 is None or y2.is_contiguous())
+    out = torch.empty_like(x2)
+    check(lib().gvd_add_layernorm_unbiased(ptr(x2), ptr(y2), ptr(gamma), ptr(beta), ptr(out), x2.shape[0], D, eps,
+                                           stream_ptr()), 'gvd_add_layernorm_unbiased')
+    return out.view_as(x)
+
+
+def region_feature_rows(g_pool, loc, sim_logits_t, pnt_mask, ln_eps=1e-5):
+    """[LN(g_pool) | LN(loc) | LN(softmax_classes(masked sim logits))] per proposal (model.py:336-364) in one pass.
+    g_pool [B,R,2048], loc [B,R,n_loc], sim_logits_t [B,R,D1] (class-last), pnt_mask u8 [B,R+1].
+    Returns pool_in [B,R,2048+n_loc+D1] and the class distribution sim_t [B,R,D1]."""
+    require_cuda_f32(g_pool, loc, sim_logits_t)
+    B, R, G = g_pool.shape
+    n_loc, n_cls = loc.shape[-1], sim_logits_t.shape[-1]
+    assert g_pool.is_contiguous() and loc.is_contiguous() and sim_logits_t.is_contiguous()
+    assert pnt_mask.dtype == torch.uint8 and pnt_mask.is_contiguous() and pnt_mask.shape == (B, R + 1)
+    out = torch.empty(B, R, G + n_loc + n_cls, device=g_pool.device, dtype=torch.float32)
+    sim = torch.empty(B, R, n_cls, device=g_pool.device, dtype=torch.float32)
+    mask_ptr = C.c_void_p(pnt_mask.data_ptr() + 1)              # skip the legacy pad column (main.py:227)
+    check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(sim_logits_t), n_cls, mask_ptr, R, R + 1,
+                                        ptr(out), ptr(sim), B * R, G, ln_eps, stream_ptr()), 'gvd_region_feature_rows')
+    return out, sim

@@ -142,6 +142,24 @@ int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_side* temporal
                       void* workspace, gvd_prof* prof, gvd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused row kernels of the per-segment preamble (inference path)
+ * ------------------------------------------------------------------------------------------- */
+
+/* out[row,:] = gamma * (s - mean(s)) / (std_unbiased(s) + eps) + beta with s = x[row,:] + y[row,:] (y may be NULL):
+ * ResidualBlock + the encoder's custom LayerNorm (transformer.py:66-88).  D must be 1024. */
+int gvd_add_layernorm_unbiased(const float* x, const float* y, const float* gamma, const float* beta, float* out,
+                               int64_t rows, int D, float eps, gvd_stream_t stream);
+
+/* Per proposal row (model.py:336-364): p = softmax over the n_cls similarity logits (all -1e8 when the row is
+ * masked: row_mask[(row / mask_rows_per_batch) * mask_ld + row % mask_rows_per_batch] != 0), written to sim_out
+ * [rows,n_cls] (optional); out[row] = [layer_norm(g_pool row, G=2048) | layer_norm(loc row, n_loc) |
+ * layer_norm(p, n_cls)] with out leading dimension G + n_loc + n_cls.  F.layer_norm semantics (biased variance,
+ * eps inside the sqrt, no affine). */
+int gvd_region_feature_rows(const float* g_pool, const float* loc, int n_loc, const float* sim_logits, int n_cls,
+                            const uint8_t* row_mask, int64_t mask_rows_per_batch, int64_t mask_ld, float* out,
+                            float* sim_out, int64_t rows, int G, float ln_eps, gvd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Frame-wise context encoder: one bidirectional GRU layer as a persistent cooperative kernel
  * (nn.GRU(1024, 512, 2, bidirectional, batch_first), model.py:150-154,399; gate order r,z,n).
  * gi [B,T,2,3*Hh] = X [W_ih_fw ; W_ih_bw]^T + [b_ih_fw ; b_ih_bw] (one gvd_gemm_nt_f32 call, N = 6*Hh);

@@ -204,3 +204,32 @@ def test_gru_persistent_kernel(B, T, barrier):
         assert int(f.view(-1, 2)[:, 1].sum()) == 0
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     np.testing.assert_allclose(outs[0].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=5e-5)
+
+
+def test_add_layernorm_unbiased():
+    g = _g(11)
+    x, y = torch.randn(777, 1024, generator=g), torch.randn(777, 1024, generator=g) * 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(1024, generator=g), 0.1 * torch.randn(1024, generator=g)
+    ref = O.custom_layernorm(x + y, gamma, beta)
+    out = ops.add_layernorm_unbiased(x.cuda(), y.cuda(), gamma.cuda(), beta.cuda(), 1e-6).cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    out = ops.add_layernorm_unbiased(x.cuda(), None, gamma.cuda(), beta.cuda(), 1e-6).cpu()
+    np.testing.assert_allclose(out.numpy(), O.custom_layernorm(x, gamma, beta).numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_region_feature_rows():
+    """mask + class softmax + 3 layer norms + concat (model.py:336-364) in one kernel vs the op-by-op composition."""
+    g = _g(12)
+    B, R, D1 = 3, 203, 433
+    g_pool = torch.relu(torch.randn(B, R, 2048, generator=g))
+    loc = torch.relu(torch.randn(B, R, 300, generator=g))
+    logits = torch.randn(B, D1, R, generator=g) * 3                 # reference layout [B,D1,R]
+    pm = (torch.rand(B, R + 1, generator=g) < 0.3).to(torch.uint8)
+    ml = logits.masked_fill(pm[:, 1:].bool().unsqueeze(1), O.MIN_VALUE)
+    sim = torch.softmax(ml, dim=1)
+    F = torch.nn.functional
+    ref = torch.cat([F.layer_norm(g_pool, [2048]), F.layer_norm(loc, [300]),
+                     F.layer_norm(sim.permute(0, 2, 1).contiguous(), [D1])], 2)
+    out, sim_t = ops.region_feature_rows(g_pool.cuda(), loc.cuda(), logits.permute(0, 2, 1).contiguous().cuda(), pm.cuda())
+    np.testing.assert_allclose(sim_t.cpu().numpy(), sim.permute(0, 2, 1).numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-4)

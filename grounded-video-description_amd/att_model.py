@@ -295,6 +295,38 @@ class TopDownModel(nn.Module):
                                                     prof=getattr(self, 'kernel_timer', None))
         return seq, lps, att2, pre['sim_mat_static']
 
+    def sample_pipelined(self, batches, eval_opt={}):
+        """Greedy-decode a sequence of independent batches with two HIP streams: the per-segment preamble (fp32-MFMA
+        bound) of batch i+1 is enqueued on one stream while the token loop (HBM-bound attention streaming +
+        weight-bound LSTMs) of batch i runs on the other, so the two kinds of kernels share the CUs.  `batches`:
+        iterable of (segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask) tuples already on the GPU.  Returns a
+        list of (seq, seqLogprobs, att2_weights, sim_mat) — identical values to `_sample` on each batch."""
+        assert eval_opt.get('beam_size', 1) == 1 and eval_opt.get('sample_max', 1)
+        cur = torch.cuda.current_stream()
+        if not hasattr(self, '_streams'):
+            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        s_pre, s_dec = self._streams
+        s_pre.wait_stream(cur)
+        s_dec.wait_stream(cur)
+        outs, keep = [], []
+        P = {k: v.detach() for k, v in self._decode_params().items()}
+        with torch.no_grad():
+            for b in batches:
+                with torch.cuda.stream(s_pre):
+                    pre = self._preamble(b[0], b[2], b[1], b[3], b[4], b[5])
+                    ev = torch.cuda.Event()
+                    ev.record(s_pre)
+                with torch.cuda.stream(s_dec):
+                    s_dec.wait_event(ev)
+                    seq, lps, att2 = ops.greedy_decode(pre, P, pre['pnt_mask'], self.seq_length, self.unk_idx,
+                                                       prof=getattr(self, 'kernel_timer', None))
+                keep.append(pre)                      # features stay alive until the decode stream is joined below
+                outs.append((seq, lps, att2, pre['sim_mat_static']))
+        cur.wait_stream(s_pre)
+        cur.wait_stream(s_dec)
+        self._pipeline_keepalive = keep              # released on the next call, after the streams were joined
+        return outs
+
     # ------------------------------------------------------------------ 'MLE' / 'GRD' (model.py:283-489)
     def _forward_train(self, segs_feat, input_seq, gt_seq, ppls, gt_boxes, mask_boxes, num, ppls_feat,
                        frm_mask, sample_idx, pnt_mask, eval_obj_ground):

@@ -141,3 +141,23 @@ def test_beam_search_matches_oracle(B, K, seed):
     assert torch.equal(seq.cpu(), oseq), 'beam token ids differ from the oracle restatement'
     assert torch.equal(att2.cpu(), oatt), 'beam attended-region indices differ'
     np.testing.assert_allclose(lps.cpu().numpy(), olps.numpy(), atol=2e-4)
+
+
+def test_pipelined_sampler_equals_serial():
+    """Two-stream overlap (preamble of batch i+1 || token loop of batch i) returns exactly the serial results."""
+    opt = gvd_amd.opts.default_opt(vocab_size=1000, t_attn_size=10)
+    sd = synth.init_state_dict(opt, seed=2, profile='trained_like')
+    model = _model(opt, sd)
+    keys = ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')
+    batches = []
+    for i, B in enumerate((5, 3, 8, 2)):
+        inp = synth.make_inputs(opt, B, seed=20 + i, train=False)
+        batches.append([inp[k].cuda() for k in keys])
+    with torch.no_grad():
+        serial = [model._sample(*b) for b in batches]
+        piped = model.sample_pipelined(batches)
+        piped2 = model.sample_pipelined(batches)
+    torch.cuda.synchronize()
+    for a, b, c in zip(serial, piped, piped2):
+        for x, y, z in zip(a, b, c):
+            assert torch.equal(x, y) and torch.equal(x, z)

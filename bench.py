@@ -38,8 +38,10 @@ def parse():
     ap.add_argument('--t-attn', type=int, default=10, help='temporal positions Ft (BASELINE: [B,10,3072]; reference default 480)')
     ap.add_argument('--vocab', type=int, default=5000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-overlap', action='store_true',
-                    help='run every step strictly serially (default: preamble of step i+1 overlaps the token loop of step i on a second HIP stream)')
+    ap.add_argument('--overlap', action='store_true',
+                    help='pipeline the K steps on two HIP streams (preamble of step i+1 || token loop of step i). Off by '
+                         'default: co-scheduling stretches the attention kernel, so its live roofline figure would not '
+                         'describe the kernel (measured gains: +2.5%% at B=256, +14%% at B=32, +19%% at B=4)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     return ap.parse_args()
 
@@ -175,7 +177,7 @@ def main():
         timer.reset()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if args.no_overlap:
+        if not args.overlap:
             for _ in range(args.steps):
                 seq, lps, att2, sim = model._sample(*dinp)
         else:
@@ -216,7 +218,7 @@ def main():
                                    "T x P = 10 x 100 regions [B,1000,2048] fc6 + [B,%d,3072] frame feats, V=%d, "
                                    "obj_interact on; random-init weights (trained_like profile)" % (B, Ft, args.vocab),
                        'batch_per_gpu': B, 'parallelism': 'batch-sharded replicas x%d (no data-path collective)' % world,
-                       'overlap': 'off' if args.no_overlap else 'preamble(i+1) || token-loop(i) on 2 HIP streams'},
+                       'overlap': 'preamble(i+1) || token-loop(i) on 2 HIP streams' if args.overlap else 'off (steps run serially)'},
             'roofline': {'bound': 'hbm', 'kernel': 'attn_partial_kernel (region+temporal additive attention)',
                          'achieved': None if achieved is None else round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),

@@ -17,6 +17,7 @@
 // tiles that share an A panel land on one XCD's L2.
 #include "gvd_common.h"
 #include "gemv_f32.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -45,7 +46,7 @@ struct KParams {
   int ntn, ntm;
 };
 
-template <int BM, int BN, int WGM, int WGN, bool LSTM>
+template <int BM, int BN, int WGM, int WGN, bool LSTM, int NBUF = 2>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;   // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;     // MFMA tiles per wave
@@ -53,9 +54,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
   constexpr int HU = BN / 4;                      // LSTM: hidden units per tile
   static_assert(WGM * WGN == 4, "4 waves");
   static_assert(TM >= 1 && TN >= 1, "tile");
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
+  // NBUF = 2: double-buffered operand tiles (one barrier per k-tile); NBUF = 1: single buffer + register prefetch
+  // (two barriers per k-tile, half the LDS -> one more workgroup per CU)
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * LDK];
   float* As = smem;
-  float* Ws = smem + 2 * BM * LDK;
+  float* Ws = smem + NBUF * BM * LDK;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -161,9 +164,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nkt) store_tile(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+    if (NBUF == 2) {
+      if (kt + 1 < nkt) store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    } else {
+      __syncthreads();                 // every wave finished reading the tile
+      if (kt + 1 < nkt) store_tile(0);
+      __syncthreads();
+    }
   }
 
   if (!LSTM) {
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
   } else {
     // gates -> LDS tile G[BM][BN+1] (columns grouped i|f|g|o, HU units each), then the pointwise cell.
     constexpr int LDG = BN + 1;
-    static_assert(BM * LDG <= 2 * (BM + BN) * LDK, "G tile fits");
+    static_assert(!LSTM || BM * LDG <= NBUF * (BM + BN) * LDK, "G tile fits");
     float* G = smem;   // all waves passed the loop's final barrier: operand tiles are dead
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -244,12 +253,12 @@ bool seg_ok(const gvd_gemm_seg& s) {
          (s.lda % 4) == 0 && (s.ldw % 4) == 0 && (s.a_batch_stride % 4) == 0 && (s.w_batch_stride % 4) == 0;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool LSTM>
+template <int BM, int BN, int WGM, int WGN, bool LSTM, int NBUF = 2>
 int launch(KParams& p, int batch, hipStream_t st) {
   p.ntm = (p.M + BM - 1) / BM;
   p.ntn = LSTM ? p.H / (BN / 4) : (p.N + BN - 1) / BN;
   dim3 grid((unsigned)(p.ntm * p.ntn), (unsigned)batch);
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, WGN, LSTM>), grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, WGN, LSTM, NBUF>), grid, dim3(256), 0, st, p);
   GVD_CHECK_LAUNCH();
   return 0;
 }
@@ -285,7 +294,13 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
   }
   if (a->M <= 32) return launch<32, 128, 1, 4, false>(p, a->batch, st);
   const long big = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
-  if (big >= 256) return launch<128, 128, 2, 2, false>(p, a->batch, st);
+  if (big >= 256) {
+    // default: single LDS buffer + register prefetch (36.9 KB -> 3 workgroups/CU): measured 126.6 vs 122.8 TF/s for
+    // the double-buffered form on the fc7 shape (tools/gemm_micro.py); GVD_GEMM_VARIANT=0 selects the latter
+    static const int variant = getenv("GVD_GEMM_VARIANT") ? atoi(getenv("GVD_GEMM_VARIANT")) : 1;
+    if (variant == 0) return launch<128, 128, 2, 2, false, 2>(p, a->batch, st);
+    return launch<128, 128, 2, 2, false, 1>(p, a->batch, st);
+  }
   return launch<64, 64, 2, 2, false>(p, a->batch, st);
 }
 

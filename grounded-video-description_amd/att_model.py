@@ -18,6 +18,7 @@ Supported configuration = the reference's README recipe (att_model='topdown', at
 region_attn_mode='mix', transfer_mode='cls', t_attn_mode='bigru', seq_per_img=1, enable_BUTD=False).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -149,6 +150,7 @@ class TopDownModel(nn.Module):
         self.ctx2pool_grd = nn.Sequential(nn.Linear(self.att_feat_size, self.vis_encoding_size), nn.ReLU(),
                                           nn.Dropout(p))
         self.core = _Core(opt)
+        self.flash_obj_interact = os.environ.get('GVD_FLASH', '1') == '1'   # inference: fused attention kernel
 
     # ------------------------------------------------------------------ API (model.py:227-234)
     def forward(self, segs_feat, seq, gt_seq, num, ppls, gt_boxes, mask_boxes, ppls_feat, frm_mask,
@@ -188,12 +190,17 @@ class TopDownModel(nn.Module):
             exact = scale == 2.0 ** round(math.log2(scale))
             if exact:
                 q = q / scale
-            heads = []
-            for qh, kh, vh in zip(q.chunk(6, -1), k.chunk(6, -1), v.chunk(6, -1)):
-                dots = torch.matmul(qh, kh.transpose(1, 2))
-                w = F.softmax(dots if exact else dots / scale, dim=-1)
-                heads.append(torch.matmul(F.dropout(w, 0.2, self.training), vh))
-            att = sa.wo(torch.cat(heads, -1))
+            if fused and exact and self.flash_obj_interact:
+                # inference: all 6 heads in one flash-style fp32-MFMA kernel, no [B,R,R] score maps in HBM
+                sizes = [t.shape[-1] for t in q[:1, :1].chunk(6, -1)]
+                heads = [ops.flash_attn_heads(q.contiguous(), k.contiguous(), v.contiguous(), sizes)]
+            else:
+                heads = []
+                for qh, kh, vh in zip(q.chunk(6, -1), k.chunk(6, -1), v.chunk(6, -1)):
+                    dots = torch.matmul(qh, kh.transpose(1, 2))
+                    w = F.softmax(dots if exact else dots / scale, dim=-1)
+                    heads.append(torch.matmul(F.dropout(w, 0.2, self.training), vh))
+            att = sa.wo(heads[0] if len(heads) == 1 else torch.cat(heads, -1))
             ff = lay.feedforward.layer
             if fused:   # inference: residual add + custom LayerNorm as one HIP row kernel
                 ln = lay.selfattn.layernorm

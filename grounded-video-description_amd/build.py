@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libgvd_hip.so')
 STAMP = LIB + '.srchash'
-SOURCES = ['gemm_f32.hip', 'gemv_f32.hip', 'attention.hip', 'vocab.hip', 'decode.hip', 'targets.hip', 'prof.hip', 'backward.hip', 'gru.hip', 'rowwise.hip']
+SOURCES = ['gemm_f32.hip', 'gemv_f32.hip', 'attention.hip', 'vocab.hip', 'decode.hip', 'targets.hip', 'prof.hip', 'backward.hip', 'gru.hip', 'rowwise.hip', 'flash_attn.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-gpu-rdc',
          '-Wno-unused-result']
 

@@ -482,3 +482,17 @@ def region_feature_rows(g_pool, loc, sim_logits_t, pnt_mask, ln_eps=1e-5):
     check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(sim_logits_t), n_cls, mask_ptr, R, R + 1,
                                         ptr(out), ptr(sim), B * R, G, ln_eps, stream_ptr()), 'gvd_region_feature_rows')
     return out, sim
+
+
+def flash_attn_heads(q, k, v, head_sizes):
+    """o[..., head h] = softmax(q_h k_h^T) v_h for the column chunks `head_sizes` (q pre-scaled); q,k,v [B,R,D]."""
+    require_cuda_f32(q, k, v)
+    B, R, D = q.shape
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and sum(head_sizes) == D
+    o = torch.empty_like(q)
+    n = len(head_sizes)
+    c0 = (C.c_int * n)(*[sum(head_sizes[:i]) for i in range(n)])
+    w = (C.c_int * n)(*head_sizes)
+    check(lib().gvd_flash_attn_f32(ptr(q), ptr(k), ptr(v), ptr(o), B, R, D, n, c0, w, stream_ptr()),
+          'gvd_flash_attn_f32')
+    return o

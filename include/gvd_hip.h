@@ -159,6 +159,13 @@ int gvd_region_feature_rows(const float* g_pool, const float* loc, int n_loc, co
                             const uint8_t* row_mask, int64_t mask_rows_per_batch, int64_t mask_ld, float* out,
                             float* sim_out, int64_t rows, int G, float ln_eps, gvd_stream_t stream);
 
+/* Fused multi-head self-attention of the obj_interact encoder (transformer.py:90-123; heads = Tensor.chunk of the
+ * model width): o[b,:,c0_h:c0_h+w_h] = softmax(q_h k_h^T) v_h for every head h, flash-style in fp32 on the matrix
+ * cores (no [B,R,R] score maps in HBM).  q must already carry the 1/sqrt(d_model) scale.  q,k,v,o: [B,R,ld]
+ * (o may not alias them); head_col0/head_width: host arrays of n_heads (<= 8) entries, width <= 176. */
+int gvd_flash_attn_f32(const float* q, const float* k, const float* v, float* o, int B, int R, int64_t ld,
+                       int n_heads, const int* head_col0, const int* head_width, gvd_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Frame-wise context encoder: one bidirectional GRU layer as a persistent cooperative kernel
  * (nn.GRU(1024, 512, 2, bidirectional, batch_first), model.py:150-154,399; gate order r,z,n).

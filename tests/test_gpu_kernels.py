@@ -233,3 +233,20 @@ def test_region_feature_rows():
     out, sim_t = ops.region_feature_rows(g_pool.cuda(), loc.cuda(), logits.permute(0, 2, 1).contiguous().cuda(), pm.cuda())
     np.testing.assert_allclose(sim_t.cpu().numpy(), sim.permute(0, 2, 1).numpy(), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('B,R', [(2, 1000), (3, 77), (1, 128), (2, 33)])
+def test_flash_attention_heads(B, R):
+    """Fused 6-head self-attention (uneven heads 171x5+169) vs the reference's per-head bmm/softmax/bmm."""
+    g = _g(B * R)
+    D = 1024
+    q = torch.randn(B, R, D, generator=g) * 0.3
+    k = torch.randn(B, R, D, generator=g)
+    v = torch.randn(B, R, D, generator=g)
+    sizes = [t.shape[-1] for t in q[:1, :1].chunk(6, -1)]
+    heads = []
+    for qh, kh, vh in zip(q.chunk(6, -1), k.chunk(6, -1), v.chunk(6, -1)):
+        heads.append(torch.matmul(torch.softmax(torch.matmul(qh, kh.transpose(1, 2)), -1), vh))
+    ref = torch.cat(heads, -1)
+    out = ops.flash_attn_heads(q.cuda(), k.cuda(), v.cuda(), sizes).cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FaParams p) {
       const float* src = qb + (int64_t)qrow * ld + 8 * kb + 4 * half;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        if (8 * kb + 4 * half + t < dh) v[t] = src[t];
+        if (8 * kb + 4 * half + t < dh) v[t] = src[t] * 1.4426950408889634f;   // scores in the log2 domain: exp -> exp2
     }
     qreg[kb] = v;
   }
@@ -111,7 +111,6 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FaParams p) {
     const int buf = jt & 1;
     const int key0 = jt * 32;
     if (jt + 1 < ntiles) load_tile(key0 + 32);          // flies under this tile's MFMAs
-    __builtin_amdgcn_sched_barrier(0);
 
     // S^T tile: scores of this lane's query against keys (e&3) + 8*(e>>2) + 4*half of the tile.
     // LDS fragment reads run one step ahead of the MFMAs; sched barriers keep the compiler from hoisting all of them.
@@ -139,20 +138,21 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FaParams p) {
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32, GVD_WAVE));
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = expf(m_run - m_new);            // 0 on the first tile (m_run = -inf)
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // 0 on the first tile (m_run = -inf)
     float psum = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      sacc[e] = expf(sacc[e] - m_new);
+      sacc[e] = __builtin_amdgcn_exp2f(sacc[e] - m_new);
       psum += sacc[e];
     }
     l_run = l_run * alpha + psum;
     m_run = m_new;
+    if (!__all(alpha == 1.0f)) {        // exact: the rescale is the identity when no query of the wave raised its max
 #pragma unroll
-    for (int dt = 0; dt < FA_DV / 32; ++dt)
+      for (int dt = 0; dt < FA_DV / 32; ++dt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
-    __builtin_amdgcn_sched_barrier(0);
+        for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+    }
 
     // O^T += V^T P^T : step s contracts key (s&3) + 8*(s>>2) + 4*half, i.e. exactly score register s
     const float* vp = &s_v[buf][col + 4 * half * FA_VLD];

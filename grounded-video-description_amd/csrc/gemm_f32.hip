@@ -24,8 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDK = 36;  // padded LDS row (floats)
+constexpr int BK_MIN = 32;   // K granularity every segment must be a multiple of
 
 struct KParams {
   const float* A[3]; int64_t lda[3]; int64_t abs_[3];
@@ -46,11 +45,13 @@ struct KParams {
   int ntn, ntm;
 };
 
-template <int BM, int BN, int WGM, int WGN, bool LSTM, int NBUF = 2>
+template <int BM, int BN, int WGM, int WGN, bool LSTM, int NBUF = 2, int BK = 32>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
+  constexpr int LDK = BK + 4;                     // padded LDS row (floats): conflict-free ds_read_b128
+  constexpr int F4R = BK / 4;                     // float4 pieces per tile row
   constexpr int WTM = BM / WGM, WTN = BN / WGN;   // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;     // MFMA tiles per wave
-  constexpr int NA = BM / 32, NW = BN / 32;       // float4 loads per thread per k-tile
+  constexpr int NA = BM * F4R / 256, NW = BN * F4R / 256;   // float4 loads per thread per k-tile
   constexpr int HU = BN / 4;                      // LSTM: hidden units per tile
   static_assert(WGM * WGN == 4, "4 waves");
   static_assert(TM >= 1 && TN >= 1, "tile");
@@ -76,14 +77,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
   bool a_ok[NA], w_ok[NW];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    int row = (tid + i * 256) >> 3;
+    int row = (tid + i * 256) / F4R;
     int gm = m0 + row;
     a_ok[i] = gm < p.M;
     a_row[i] = a_ok[i] ? gm : 0;
   }
 #pragma unroll
   for (int i = 0; i < NW; ++i) {
-    int nl = (tid + i * 256) >> 3;
+    int nl = (tid + i * 256) / F4R;
     if (LSTM) {
       w_row[i] = (nl / HU) * p.H + tn_ * HU + (nl % HU);
       w_ok[i] = true;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
       w_row[i] = w_ok[i] ? gn : 0;
     }
   }
-  const int kq4 = (tid & 7) * 4;
+  const int kq4 = (tid % F4R) * 4;
 
   int nkt = 0;
 #pragma unroll
@@ -123,12 +124,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      int row = (tid + i * 256) >> 3;
+      int row = (tid + i * 256) / F4R;
       *reinterpret_cast<f32x4*>(&As[(buf * BM + row) * LDK + kq4]) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-      int row = (tid + i * 256) >> 3;
+      int row = (tid + i * 256) / F4R;
       *reinterpret_cast<f32x4*>(&Ws[(buf * BN + row) * LDK + kq4]) = rw[i];
     }
   };
@@ -249,16 +250,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
 }
 
 bool seg_ok(const gvd_gemm_seg& s) {
-  return s.A && s.W && s.K > 0 && (s.K % BK) == 0 && gvd_aligned16(s.A) && gvd_aligned16(s.W) &&
+  return s.A && s.W && s.K > 0 && (s.K % BK_MIN) == 0 && gvd_aligned16(s.A) && gvd_aligned16(s.W) &&
          (s.lda % 4) == 0 && (s.ldw % 4) == 0 && (s.a_batch_stride % 4) == 0 && (s.w_batch_stride % 4) == 0;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool LSTM, int NBUF = 2>
+template <int BM, int BN, int WGM, int WGN, bool LSTM, int NBUF = 2, int BK = 32>
 int launch(KParams& p, int batch, hipStream_t st) {
   p.ntm = (p.M + BM - 1) / BM;
   p.ntn = LSTM ? p.H / (BN / 4) : (p.N + BN - 1) / BN;
   dim3 grid((unsigned)(p.ntm * p.ntn), (unsigned)batch);
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, WGN, LSTM, NBUF>), grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, WGN, LSTM, NBUF, BK>), grid, dim3(256), 0, st, p);
   GVD_CHECK_LAUNCH();
   return 0;
 }
@@ -299,6 +300,11 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
     // the double-buffered form on the fc7 shape (tools/gemm_micro.py); GVD_GEMM_VARIANT=0 selects the latter
     static const int variant = getenv("GVD_GEMM_VARIANT") ? atoi(getenv("GVD_GEMM_VARIANT")) : 1;
     if (variant == 0) return launch<128, 128, 2, 2, false, 2>(p, a->batch, st);
+    if (variant == 2) {      // 64-deep K tiles (half the barriers per flop); needs every segment K % 64 == 0
+      bool ok64 = true;
+      for (int s = 0; s < a->nseg; ++s) ok64 = ok64 && (a->seg[s].K % 64) == 0;
+      if (ok64) return launch<128, 128, 2, 2, false, 1, 64>(p, a->batch, st);
+    }
     return launch<128, 128, 2, 2, false, 1>(p, a->batch, st);
   }
   return launch<64, 64, 2, 2, false>(p, a->batch, st);

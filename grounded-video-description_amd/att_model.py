@@ -342,5 +342,12 @@ class TopDownModel(nn.Module):
                                         ppls_feat, frm_mask, sample_idx, pnt_mask, eval_obj_ground)
 
 
+def attended_region_indices(att2_weights, num_sampled_frm, num_prop_per_frm):
+    """main.py:364-365: per-frame argmax over the P proposals of each of the T frames of the masked attention
+    logits returned by `'sample'` -> int64 [B,L,T] (the "attended region indices" of the parity contract)."""
+    B, L = att2_weights.shape[0], att2_weights.shape[1]
+    return att2_weights.view(B, L, num_sampled_frm, num_prop_per_frm).max(dim=-1)[1]
+
+
 class AttModel(TopDownModel):
     """Alias kept for drivers that import `misc.model.AttModel` semantics."""

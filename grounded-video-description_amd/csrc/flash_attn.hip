@@ -17,6 +17,7 @@
 // offsets are only 4-byte aligned), double-buffered: one barrier per key tile; the next tile's loads fly under the
 // 184 MFMAs of the current one.  Head widths are zero-padded to 176 (K/Q) / 192 (V) in LDS/registers only.
 #include "gvd_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -37,6 +38,7 @@ struct FaParams {
   int dh[FA_MAXH];       // width of each head (<= 176)
 };
 
+template <bool GLDS>
 __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FaParams p) {
   __shared__ __attribute__((aligned(16))) float s_k[2][32 * FA_KLD];
   __shared__ float s_v[2][32 * FA_VLD];
@@ -95,6 +97,32 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FaParams p) {
     }
   };
 
+  // GLDS variant: the tiles go global -> LDS by asynchronous DMA (global_load_lds_dword: LDS address = wave-uniform
+  // base + 4*lane, exactly the lane-contiguous row pieces staged above) — no staging registers, no ds_write pass.
+  // Masked lanes (columns >= head width, keys >= R) do not write: the pad columns are zeroed once below; rows of
+  // invalid keys keep finite stale data whose scores are set to -inf / whose probabilities are exactly 0.
+  auto stage_async = [&](int key0, int buf) {
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int key = key0 + wave * 8 + rr;
+      if (key < R) {
+        const float* kr = kb_ + (int64_t)key * ld + lane;
+        const float* vr = vb + (int64_t)key * ld + lane;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (lane + 64 * c < dh) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kr + 64 * c),
+                                             (__attribute__((address_space(3))) void*)&s_k[buf][(wave * 8 + rr) * FA_KLD + 64 * c],
+                                             4, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vr + 64 * c),
+                                             (__attribute__((address_space(3))) void*)&s_v[buf][(wave * 8 + rr) * FA_VLD + 64 * c],
+                                             4, 0, 0);
+          }
+        }
+      }
+    }
+  };
+
   f32x16 oacc[FA_DV / 32];
 #pragma unroll
   for (int dt = 0; dt < FA_DV / 32; ++dt)
@@ -103,14 +131,23 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FaParams p) {
   float m_run = -INFINITY, l_run = 0.f;
 
   const int ntiles = (R + 31) / 32;
-  load_tile(0);
-  store_tile(0);
+  if (GLDS) {
+    for (int i = tid; i < 2 * 32 * FA_KLD; i += 256) (&s_k[0][0])[i] = 0.f;
+    for (int i = tid; i < 2 * 32 * FA_VLD; i += 256) (&s_v[0][0])[i] = 0.f;
+    __syncthreads();
+    stage_async(0, 0);
+  } else {
+    load_tile(0);
+    store_tile(0);
+  }
   __syncthreads();
 #pragma unroll 1
   for (int jt = 0; jt < ntiles; ++jt) {
     const int buf = jt & 1;
     const int key0 = jt * 32;
-    if (jt + 1 < ntiles) load_tile(key0 + 32);          // flies under this tile's MFMAs
+    if (jt + 1 < ntiles) {                              // next tile's transfer flies under this tile's MFMAs
+      if (GLDS) stage_async(key0 + 32, buf ^ 1); else load_tile(key0 + 32);
+    }
 
     // S^T tile: scores of this lane's query against keys (e&3) + 8*(e>>2) + 4*half of the tile.
     // LDS fragment reads run one step ahead of the MFMAs; sched barriers keep the compiler from hoisting all of them.
@@ -126,6 +163,10 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FaParams p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], qreg[kb][t], sacc, 0, 0, 0);
       a_cur = a_nxt;
+      // issue order inside the step: MFMA, then the next fragment's LDS read in its shadow, then the other MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     // online softmax (per lane = per query row)
@@ -172,11 +213,16 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FaParams p) {
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v_cur[dt], sacc[s], oacc[dt], 0, 0, 0);
 #pragma unroll
       for (int dt = 0; dt < FA_DV / 32; ++dt) v_cur[dt] = v_nxt[dt];
+#pragma unroll
+      for (int dt = 0; dt < FA_DV / 32; ++dt) {      // MFMA / LDS-read alternation: reads ride in the MFMA shadow
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 
-    if (jt + 1 < ntiles) store_tile(buf ^ 1);
-    __syncthreads();
+    if (!GLDS && jt + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();     // (GLDS: the compiler drains the DMA with vmcnt(0) ahead of this barrier)
   }
 
   // ---- normalise and write O[q][d] = O^T[d][q] / l  (lane = query row; d = 32*dt + (e&3) + 8*(e>>2) + 4*half)
@@ -208,7 +254,9 @@ extern "C" int gvd_flash_attn_f32(const float* q, const float* k, const float* v
     p.c0[h] = head_col0[h]; p.dh[h] = head_width[h];
   }
   dim3 grid((unsigned)((R + 127) / 128), (unsigned)n_heads, (unsigned)B);
-  hipLaunchKernelGGL(flash_attn_kernel, grid, dim3(256), 0, gvd_s(stream), p);
+  static const int glds = getenv("GVD_FLASH_GLDS") ? atoi(getenv("GVD_FLASH_GLDS")) : 0;   // tuning knob
+  if (glds) hipLaunchKernelGGL(flash_attn_kernel<true>, grid, dim3(256), 0, gvd_s(stream), p);
+  else hipLaunchKernelGGL(flash_attn_kernel<false>, grid, dim3(256), 0, gvd_s(stream), p);
   GVD_CHECK_LAUNCH();
   return 0;
 }

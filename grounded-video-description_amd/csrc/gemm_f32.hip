@@ -297,7 +297,9 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
   const long big = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
   if (big >= 256) {
     // default: single LDS buffer + register prefetch (36.9 KB -> 3 workgroups/CU): measured 126.6 vs 122.8 TF/s for
-    // the double-buffered form on the fc7 shape (tools/gemm_micro.py); GVD_GEMM_VARIANT=0 selects the latter
+    // the double-buffered form on the fc7 shape (tools/gemm_micro.py); GVD_GEMM_VARIANT=0 selects the latter.
+    // Tried and rejected: 64-deep K tiles (variant 2: no change, barriers are not the limit) and a 256x128 tile
+    // (272 registers -> 1 wave/SIMD: 116 TF/s).  PMC: 81 % MFMA-busy vs rocBLAS 95 % with one pipelined wave/SIMD.
     static const int variant = getenv("GVD_GEMM_VARIANT") ? atoi(getenv("GVD_GEMM_VARIANT")) : 1;
     if (variant == 0) return launch<128, 128, 2, 2, false, 2>(p, a->batch, st);
     if (variant == 2) {      // 64-deep K tiles (half the barriers per flop); needs every segment K % 64 == 0

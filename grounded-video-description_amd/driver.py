@@ -1,0 +1,132 @@
+"""Driver-side contract of main.py around the model: what `train()` / `eval()` do with the
+model's inputs and outputs, without the dataset / metric submodules that are out of scope.
+
+  decode_sequence        utils.py:90-106   token ids -> sentences (stops at the first END = 0)
+  grounding_boxes        main.py:364-368   per-frame attended proposal boxes for every generated word
+  collect_predictions    main.py:370-400   the `predictions` / `grd_output` dictionaries main.py dumps as JSON
+  save_checkpoint / load_checkpoint   main.py:622-652, 702-743   model.pth / model-best.pth + infos_<id>.pkl +
+                         histories_<id>.pkl, interchangeable with the reference (same state_dict keys and shapes)
+  train_epoch            main.py:197-311   loss bookkeeping around Trainer.step
+"""
+import os
+import pickle
+from collections import defaultdict
+
+import torch
+
+
+def decode_sequence(itow, seq):
+    """utils.decode_sequence (utils.py:90-106): words joined by ' ', stop at token 0; itow maps str(id) -> word."""
+    out = []
+    for row in seq.tolist():
+        txt = ''
+        for j, ix in enumerate(row):
+            if j >= 1:
+                txt = txt + ' '
+            if ix == 0:
+                break
+            txt = txt + itow[str(ix)]
+        out.append(txt)
+    return out
+
+
+def grounding_boxes(att2_weights, ppls, num_sampled_frm, num_prop_per_frm):
+    """main.py:364-368.  att2_weights [B,L,R] (masked logits from 'sample'), ppls [B,R,7] ->
+    (att2_ind i64 [B,L,T], obj_bbox_att2 f32 [B,L,T,7]): for every word and frame the attended proposal."""
+    B, L = att2_weights.shape[0], att2_weights.shape[1]
+    T, P = num_sampled_frm, num_prop_per_frm
+    att2_ind = att2_weights.view(B, L, T, P).max(dim=-1)[1]
+    boxes = torch.gather(ppls.view(-1, T, P, ppls.shape[-1]).permute(0, 2, 1, 3).contiguous(), 1,
+                         att2_ind.unsqueeze(-1).expand(B, L, T, ppls.shape[-1]))
+    return att2_ind, boxes
+
+
+def collect_predictions(seq, seg_ids, itow, timestamps=None, att2_weights=None, ppls=None, opt=None,
+                        wtol=None, lemma_det_dict=None, itod=None, predictions=None, grd_output=None):
+    """main.py:370-400 for one batch: appends {'sentence', 'timestamp'} per segment to predictions[vid] and, when
+    grounding evaluation is on (att2_weights given), {'clss','idx_in_sent','bbox_for_all_frames'} to
+    grd_output[vid][seg].  seg_ids: '<vid>_segment_<k>' strings."""
+    predictions = defaultdict(list) if predictions is None else predictions
+    grd_output = defaultdict(dict) if grd_output is None else grd_output
+    seq_cpu = seq.cpu()
+    if att2_weights is not None:
+        _, boxes = grounding_boxes(att2_weights, ppls, opt.num_sampled_frm, opt.num_prop_per_frm)
+        boxes = boxes.cpu()
+        for i in range(seq_cpu.shape[0]):
+            vid_id, seg_idx = seg_ids[i].split('_segment_')
+            seg_idx = str(int(seg_idx))
+            tmp = {'clss': [], 'idx_in_sent': [], 'bbox_for_all_frames': []}
+            for j in range(seq_cpu.shape[1]):
+                tok = int(seq_cpu[i, j])
+                if tok == 0:
+                    break
+                lemma = wtol[itow[str(tok)]]
+                if lemma in lemma_det_dict:
+                    tmp['bbox_for_all_frames'].append(boxes[i, j, :, :4].tolist())
+                    tmp['clss'].append(itod[lemma_det_dict[lemma]])
+                    tmp['idx_in_sent'].append(j)
+            grd_output[vid_id][seg_idx] = tmp
+    for k, sent in enumerate(decode_sequence(itow, seq_cpu)):
+        vid_idx, seg_idx = seg_ids[k].split('_segment_')
+        seg_idx = str(int(seg_idx))
+        entry = {'sentence': sent}
+        if timestamps is not None:
+            entry['timestamp'] = [round(t, 2) for t in timestamps[vid_idx][seg_idx]]
+        predictions[vid_idx].append(entry)
+    return predictions, grd_output
+
+
+def save_checkpoint(model, opt, checkpoint_path, infos=None, histories=None, best=False, itow=None):
+    """main.py:702-743: model.pth (+ model-best.pth), infos_<id>.pkl (+ -best), histories_<id>.pkl.
+    The optimizer state is not saved (main.py:715-716 keeps it commented out)."""
+    os.makedirs(checkpoint_path, exist_ok=True)
+    module = model.module if hasattr(model, 'module') else model
+    sd = {k: v.detach().cpu() for k, v in module.state_dict().items()}
+    infos = dict(infos or {})
+    infos.setdefault('iter', 0)
+    infos.setdefault('epoch', 0)
+    infos.setdefault('best_val_score', None)
+    infos['opt'] = opt
+    infos['vocab'] = itow
+    torch.save(sd, os.path.join(checkpoint_path, 'model.pth'))
+    with open(os.path.join(checkpoint_path, 'infos_' + opt.id + '.pkl'), 'wb') as f:
+        pickle.dump(infos, f)
+    with open(os.path.join(checkpoint_path, 'histories_' + opt.id + '.pkl'), 'wb') as f:
+        pickle.dump(histories or {}, f)
+    if best:
+        torch.save(sd, os.path.join(checkpoint_path, 'model-best.pth'))
+        with open(os.path.join(checkpoint_path, 'infos_' + opt.id + '-best.pkl'), 'wb') as f:
+            pickle.dump(infos, f)
+
+
+def load_checkpoint(model, start_from, run_id, load_best_score=0, map_location='cpu'):
+    """main.py:622-652: returns (infos, histories); the model gets the saved state_dict (strict)."""
+    tag = '-best' if load_best_score == 1 else ''
+    model_path = os.path.join(start_from, 'model-best.pth' if load_best_score == 1 else 'model.pth')
+    with open(os.path.join(start_from, 'infos_' + run_id + tag + '.pkl'), 'rb') as f:
+        infos = pickle.load(f, encoding='latin1')
+    module = model.module if hasattr(model, 'module') else model
+    module.load_state_dict(torch.load(model_path, map_location=map_location))
+    histories = {}
+    hp = os.path.join(start_from, 'histories_' + run_id + '.pkl')
+    if os.path.isfile(hp):
+        with open(hp, 'rb') as f:
+            histories = pickle.load(f, encoding='latin1')
+    return infos, histories
+
+
+def train_epoch(trainer, batches, opt, log=None):
+    """main.py:197-311: one pass over `batches` (iterables of the 11 positional model inputs); returns the running
+    means main.py prints (train loss, lm, att2, ground, cls)."""
+    trainer.model.train()
+    sums = torch.zeros(5)
+    n = 0
+    for step, args in enumerate(batches):
+        losses = trainer.step(args).float().cpu()         # lm, att2, ground, cls (each already / n_replicas = 1)
+        total = losses[0] + opt.w_att2 * losses[1] + opt.w_grd * losses[2] + opt.w_cls * losses[3]
+        sums += torch.cat([total.view(1), losses[0:1], opt.w_att2 * losses[1:2], opt.w_grd * losses[2:3],
+                           opt.w_cls * losses[3:4]])
+        n += 1
+        if log is not None and step % max(getattr(opt, 'disp_interval', 100), 1) == 0:
+            log('step %d: train_loss %.4f (lm %.4f att2 %.4f grd %.4f cls %.4f)' % ((step,) + tuple((sums / n).tolist())))
+    return (sums / max(n, 1)).tolist()

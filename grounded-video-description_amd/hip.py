@@ -127,9 +127,16 @@ def lib():
     global _lib
     if _lib is None:
         path = _build.library_path()
-        if not os.path.exists(path):
-            raise GvdHipError('libgvd_hip.so not built (%s): run `python __graft_entry__.py build`; '
-                              'there is no CPU/eager fallback for the hot path' % path)
+        if not _build.is_fresh():
+            # not built yet (or sources changed): compile the HIP sources in-tree now.  This is still the HIP path —
+            # there is no CPU/eager fallback; without hipcc the call below raises.
+            try:
+                _build.build_library(force=False, verbose=False)
+            except Exception as e:
+                if not os.path.exists(path):
+                    raise GvdHipError('libgvd_hip.so not built (%s) and building it failed (%s): run '
+                                      '`python __graft_entry__.py build`; there is no CPU/eager fallback for the '
+                                      'hot path' % (path, e))
         try:
             l = C.CDLL(path)
         except OSError as e:   # e.g. libamdhip64 missing

@@ -37,6 +37,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=None, help='segments per GPU per step (default 256 sample / 64 train)')
     ap.add_argument('--t-attn', type=int, default=10, help='temporal positions Ft (BASELINE: [B,10,3072]; reference default 480)')
     ap.add_argument('--vocab', type=int, default=5000)
+    ap.add_argument('--beam', type=int, default=1, help='beam size (1 = greedy; 5 = BASELINE configs[4])')
+    ap.add_argument('--frames', type=int, default=10, help='sampled frames T (regions R = 100*T; configs[4] uses 20)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--overlap', action='store_true',
                     help='pipeline the K steps on two HIP streams (preamble of step i+1 || token loop of step i). Off by '
@@ -141,12 +143,12 @@ def main():
 
     import gvd_amd  # noqa: F401
     from gvd_amd import att_model, hip, opts, synth
-    opt = opts.default_opt(vocab_size=args.vocab, t_attn_size=args.t_attn)
+    opt = opts.default_opt(vocab_size=args.vocab, t_attn_size=args.t_attn, num_sampled_frm=args.frames)
     sd = synth.init_state_dict(opt, seed=0, profile='trained_like')
     model = att_model.TopDownModel(opt)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
-    B = args.batch or (256 if args.mode == 'sample' else 64)
+    B = args.batch or ((256 if args.beam == 1 else 64) if args.mode == 'sample' else 64)
     if args.mode == 'train':
         return bench_train(args, opt, sd, model, B, rank, world, dev)
     # each rank: its own shard of segments.  The CPU generator is slow for 2 GB of features, so a 32-segment base
@@ -173,7 +175,7 @@ def main():
 
     with torch.no_grad():
         for _ in range(args.warmup):
-            model._sample(*dinp)
+            model._sample(*dinp, {'beam_size': args.beam})
         torch.cuda.synchronize()
         barrier()
         model.kernel_timer = timer
@@ -207,6 +209,9 @@ def main():
                 comp.wait_event(ready[k])
                 seq, lps, att2, sim = model._sample(*dev_sets[k])
                 done[k].record(comp)
+        elif args.beam > 1:
+            for _ in range(args.steps):
+                seq, lps, att2, sim = model._sample(*dinp, {'beam_size': args.beam})
         elif not args.overlap:
             for _ in range(args.steps):
                 seq, lps, att2, sim = model._sample(*dinp)
@@ -228,7 +233,7 @@ def main():
         A, H, Ft = opt.att_hid_size, opt.rnn_size, args.t_attn
         bytes_per_launch = B * (R + Ft) * (A + H) * 4          # algorithmic bytes
         avg_s = (attn_ms / max(attn_n, 1)) * 1e-3
-        achieved = bytes_per_launch / avg_s / 1e9 if attn_n else None
+        achieved = bytes_per_launch / avg_s / 1e9 if attn_n else None   # (beam mode does not attach the event timer)
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'attn_traffic.json')
         if os.path.exists(tpath):
@@ -237,16 +242,18 @@ def main():
             if tj.get('batch') == B and tj.get('t_attn') == Ft:
                 traffic = tj.get('hbm_bytes_per_launch')
         out = {
-            'metric': 'captions/sec (seq_len=20, 10x100 regions), greedy decode',
+            'metric': 'captions/sec (seq_len=20, %dx100 regions), %s' % (args.frames, 'greedy decode' if args.beam == 1
+                                                                         else 'beam-search decode (beam=%d)' % args.beam),
             'value': round(world * B * args.steps / elapsed, 2),
             'unit': 'captions/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': "greedy 'sample' (preamble + 20-token loop), %d segments/GPU/step, L=20, "
-                                   "T x P = 10 x 100 regions [B,1000,2048] fc6 + [B,%d,3072] frame feats, V=%d, "
-                                   "obj_interact on; random-init weights (trained_like profile)" % (B, Ft, args.vocab),
+            'config': {'workload': "%s 'sample' (preamble + 20-token loop), %d segments/GPU/step, L=20, "
+                                   "T x P = %d x 100 regions [B,%d,2048] fc6 + [B,%d,3072] frame feats, V=%d, "
+                                   "obj_interact on; random-init weights (trained_like profile)"
+                                   % ('greedy' if args.beam == 1 else 'beam=%d' % args.beam, B, args.frames, R, Ft, args.vocab),
                        'batch_per_gpu': B, 'parallelism': 'batch-sharded replicas x%d (no data-path collective)' % world,
                        'overlap': 'preamble(i+1) || token-loop(i) on 2 HIP streams' if args.overlap else 'off (steps run serially)',
                        'inputs': 'copied from pinned host memory every step (PCIe-inclusive)' if args.h2d else 'resident in HBM'},

@@ -263,6 +263,21 @@ def main():
                          'traffic': traffic, 'bytes_per_launch': bytes_per_launch,
                          'avg_launch_us': round(avg_s * 1e6, 2), 'launches_timed': attn_n},
         }
+        if world == 1 and args.beam == 1 and B != 4 and not args.h2d:
+            # BASELINE configs[1] shape (batch_size=4 eval) next to the headline batch: the latency-bound case
+            model.kernel_timer = None
+            small = [t[:4].contiguous() for t in dinp]
+            with torch.no_grad():
+                for _ in range(3):
+                    model._sample(*small)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    model._sample(*small)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 20
+            out['config']['configs1_b4'] = {'batch': 4, 'ms_per_call': round(1e3 * dt, 3),
+                                            'captions_per_s': round(4 / dt, 1), 'calls_timed': 20}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(opt, sd, args.cpu_seconds)
         else:

@@ -34,10 +34,6 @@ class _Holder(nn.Module):
     """Plain parameter container (keeps the reference's dotted state_dict names)."""
 
 
-def _linear_params(out_f, in_f, bias=True):
-    return nn.Linear(in_f, out_f, bias=bias)
-
-
 class _EncLayerNorm(nn.Module):
     """transformer.py:66-77 (unbiased std, eps on std)."""
 

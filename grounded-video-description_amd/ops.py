@@ -7,7 +7,6 @@ import os
 
 import torch
 
-from . import hip
 from .hip import AttnSide, GemmArgs, GemmSeg, GreedyArgs, LstmArgs, check, lib, ptr, require_cuda_f32, stream_ptr
 
 

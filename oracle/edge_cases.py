@@ -1,0 +1,109 @@
+"""Edge-shape cases for the greedy path (TEST INFRASTRUCTURE, like the rest of oracle/).
+
+Shapes the reference's own runs hit at the margins (last partial batch of one segment, frames whose proposals
+are all below prop_thresh, captions that end at once) plus sizes that are not multiples of any tile/chunk the
+HIP kernels use.  tests/test_oracle_vs_reference.py pins the oracle on every case against the real reference
+(bitwise, in the build container); tests/test_gpu_e2e.py then checks the HIP path against the oracle.
+"""
+import torch
+
+import gvd_amd
+from gvd_amd import synth
+
+
+def _mask_rows(inp, b, lo, hi):
+    """Mark proposals [lo,hi) of sample b as below-threshold, the way dataloader_anet.py:343-344 leaves them."""
+    inp['ppls'][b, lo:hi] = 0.0
+    inp['ppls_feat'][b, lo:hi] = 0.0
+    inp['pnt_mask'][b, 1 + lo:1 + hi] = 1
+
+
+def _default(seed, B, **over):
+    kw = dict(vocab_size=600, t_attn_size=12)
+    kw.update(over)
+    opt = gvd_amd.opts.default_opt(**kw)
+    sd = synth.init_state_dict(opt, seed=seed, profile='trained_like')
+    inp = synth.make_inputs(opt, B, seed=seed, train=False)
+    return opt, sd, inp
+
+
+def single_segment():
+    return _default(21, 1)
+
+
+def ragged_sizes():
+    # R = 3 x 37 = 111 regions, Ft = 7, V = 1003, L = 9: nothing divides a tile, a chunk or a wave
+    return _default(22, 3, num_sampled_frm=3, num_prop_per_frm=37, t_attn_size=7, vocab_size=1003, seq_length=9)
+
+
+def masked_frames():
+    # sample 0: frame 2 has no proposal above threshold; sample 1: NO proposal at all; sample 2: untouched
+    opt, sd, inp = _default(23, 3)
+    P = opt.num_prop_per_frm
+    _mask_rows(inp, 0, 2 * P, 3 * P)
+    _mask_rows(inp, 1, 0, opt.num_sampled_frm * P)
+    return opt, sd, inp
+
+
+def immediate_end():
+    # the end token (id 0) wins every step: model.py:585-590 stops after the first step with all-zero ids
+    opt, sd, inp = _default(24, 2)
+    sd['logit.bias'] = sd['logit.bias'].clone()
+    sd['logit.bias'][0] += 80.0
+    return opt, sd, inp
+
+
+def one_frame():
+    return _default(25, 2, num_sampled_frm=1, t_attn_size=3)
+
+
+EDGE_CASES = {
+    'single_segment': single_segment,
+    'ragged_sizes': ragged_sizes,
+    'masked_frames': masked_frames,
+    'immediate_end': immediate_end,
+    'one_frame': one_frame,
+}
+
+GREEDY_KEYS = ('segs_feat', 'num', 'ppls', 'ppls_feat', 'sample_idx', 'pnt_mask')
+
+
+def oracle_greedy(opt, sd, inp):
+    from oracle import gvd_oracle as O
+    with torch.no_grad():
+        return O.sample_greedy(sd, opt, *[inp[k] for k in GREEDY_KEYS])
+
+
+# ---- training ('MLE') edge shapes -------------------------------------------------------------------------
+def _train(seed, B, max_boxes=8, **over):
+    kw = dict(vocab_size=600, t_attn_size=12)
+    kw.update(over)
+    opt = gvd_amd.opts.default_opt(**kw)
+    sd = synth.init_state_dict(opt, seed=seed, profile='trained_like')
+    inp = synth.trim_to_batch(synth.make_inputs(opt, B, seed=seed, train=True, max_boxes=max_boxes))
+    return opt, sd, inp
+
+
+def train_single_segment():
+    return _train(31, 1)
+
+
+def train_ragged_sizes():
+    return _train(32, 3, max_boxes=4, num_sampled_frm=3, num_prop_per_frm=37, t_attn_size=7, vocab_size=1003,
+                  seq_length=9)
+
+
+def train_masked_frame():
+    # the frame holding sample 0's first annotated box loses every proposal (all below prop_thresh)
+    opt, sd, inp = _train(33, 3)
+    P = opt.num_prop_per_frm
+    f = int(inp['gt_boxes'][0, 0, 4])
+    _mask_rows(inp, 0, f * P, (f + 1) * P)
+    return opt, sd, inp
+
+
+TRAIN_EDGE_CASES = {
+    'train_single_segment': train_single_segment,
+    'train_ragged_sizes': train_ragged_sizes,
+    'train_masked_frame': train_masked_frame,
+}

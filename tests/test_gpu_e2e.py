@@ -11,7 +11,7 @@ import torch
 
 import gvd_amd
 from gvd_amd import att_model, synth
-from oracle import cases, gvd_oracle as O
+from oracle import cases, edge_cases, gvd_oracle as O
 
 pytestmark = pytest.mark.gpu
 
@@ -53,6 +53,27 @@ def test_greedy_matches_reference(name, golden_dir):
     np.testing.assert_allclose(sim[:, :, ::97].cpu().numpy(), g['sim_sub'], rtol=0, atol=1e-5)
     if 'att2_weights' in g:
         np.testing.assert_allclose(att2.numpy(), g['att2_weights'], rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('name', sorted(edge_cases.EDGE_CASES))
+def test_greedy_edge_shapes_match_oracle(name):
+    """Edge shapes (oracle/edge_cases.py: one segment, sizes no tile divides, frames / samples with every proposal
+    masked, captions ending at step 0, a single frame).  The oracle is pinned bitwise to the reference on these
+    same cases by tests/test_oracle_vs_reference.py; here: ids and attended regions bit-exact, shapes equal."""
+    opt, sd, inp = edge_cases.EDGE_CASES[name]()
+    oseq, olps, oatt2, osim = edge_cases.oracle_greedy(opt, sd, inp)
+    model = _model(opt, sd)
+    with torch.no_grad():
+        seq, lps, att2, sim = model._sample(*[inp[k].cuda() for k in ('segs_feat', 'ppls', 'num', 'ppls_feat',
+                                                                      'sample_idx', 'pnt_mask')])
+    torch.cuda.synchronize()
+    seq, lps, att2, sim = seq.cpu(), lps.cpu(), att2.cpu(), sim.cpu()
+    assert tuple(seq.shape) == tuple(oseq.shape) and tuple(att2.shape) == tuple(oatt2.shape)
+    assert torch.equal(seq, oseq), 'greedy ids differ from the oracle'
+    assert torch.equal(O.attended_region_indices(att2, opt), O.attended_region_indices(oatt2, opt))
+    np.testing.assert_allclose(lps.numpy(), olps.numpy(), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(sim.numpy(), osim.numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(att2.numpy(), oatt2.numpy(), rtol=1e-4, atol=2e-4)
 
 
 def test_forward_api_sample(golden_dir):

@@ -8,7 +8,7 @@ import torch
 
 import gvd_amd
 from gvd_amd import att_model, ops, synth, train
-from oracle import cases
+from oracle import cases, edge_cases, gvd_oracle as O
 from tests import torch_backend as TB
 
 pytestmark = pytest.mark.gpu
@@ -103,6 +103,30 @@ def test_mle_gradients_match_reference(name, golden_dir):
     for n in ('core.i2h_2.weight', 'core.h2h_2.weight'):
         assert params[n].grad is None or float(params[n].grad.abs().sum()) == 0.0
     print('worst relative grad-norm error', worst)
+
+
+@pytest.mark.parametrize('name', sorted(edge_cases.TRAIN_EDGE_CASES))
+def test_mle_edge_shapes_match_oracle(name):
+    """Training edge shapes (oracle/edge_cases.py: one segment, sizes no tile divides, an annotated frame with every
+    proposal masked): 4 losses within 1e-4 of the oracle (itself pinned to the reference on these cases by
+    tests/test_oracle_vs_reference.py), every parameter's gradient norm vs the oracle's autograd."""
+    opt, sd, inp = edge_cases.TRAIN_EDGE_CASES[name]()
+    W = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v)
+         for k, v in sd.items()}
+    w = cases.GRAD_WEIGHTS
+    olm, oa2, ogl, ocl, _ = O.forward_train(W, opt, *[inp[k] for k in synth.FORWARD_ORDER])
+    (olm + w['w_att2'] * oa2 + w['w_grd'] * ogl + w['w_cls'] * ocl).backward()
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    lm, a2, gl, cl = model(*synth.as_args(inp, 'cuda'), 'MLE')
+    np.testing.assert_allclose(np.array([float(lm), float(a2), float(gl), float(cl)]),
+                               np.array([olm.item(), oa2.item(), ogl.item(), ocl.item()]), atol=1e-4)
+    (lm.sum() + w['w_att2'] * a2.sum() + w['w_grd'] * gl.sum() + w['w_cls'] * cl.sum()).backward()
+    for n, p in model.named_parameters():
+        want = 0.0 if W[n].grad is None else float(W[n].grad.double().norm())
+        got = 0.0 if p.grad is None else float(p.grad.double().norm())
+        assert abs(got - want) / max(want, 1e-3) < 2e-3, '%s: |grad| %.6g vs oracle %.6g' % (n, got, want)
 
 
 def test_train_steps_reduce_loss():

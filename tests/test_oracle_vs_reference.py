@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import gvd_amd
-from oracle import gvd_oracle as O, ref_harness
+from oracle import edge_cases, gvd_oracle as O, ref_harness
 
 pytestmark = pytest.mark.skipif(not ref_harness.reference_available(), reason='no /root/reference here')
 
@@ -57,3 +57,29 @@ def test_reference_beam_is_broken(setup):
     inp = gvd_amd.synth.make_inputs(opt, 1, seed=5, train=False)
     with torch.no_grad(), pytest.raises(Exception):
         ref(*gvd_amd.synth.as_args(inp), 'sample', {'sample_max': 1, 'beam_size': 3})
+
+
+@pytest.mark.parametrize('name', sorted(edge_cases.EDGE_CASES))
+def test_greedy_edge_shapes_bitwise(name):
+    """Pins the oracle on the edge shapes of oracle/edge_cases.py (the GPU test then compares HIP vs oracle)."""
+    opt, sd, inp = edge_cases.EDGE_CASES[name]()
+    ref = ref_harness.build_reference_model(opt, sd).eval()
+    with torch.no_grad():
+        seq, att2, sim = ref(*gvd_amd.synth.as_args(inp), 'sample', {'sample_max': 1, 'beam_size': 1})
+    oseq, _, oatt2, osim = edge_cases.oracle_greedy(opt, sd, inp)
+    assert torch.equal(seq, oseq) and torch.equal(att2, oatt2) and torch.equal(sim, osim)
+    if name == 'immediate_end':
+        assert int(seq.abs().sum()) == 0
+
+
+@pytest.mark.parametrize('name', sorted(edge_cases.TRAIN_EDGE_CASES))
+def test_mle_edge_shapes(name):
+    opt, sd, inp = edge_cases.TRAIN_EDGE_CASES[name]()
+    ref = ref_harness.build_reference_model(opt, sd).eval()
+    args = gvd_amd.synth.as_args(inp)
+    with torch.no_grad():
+        r = ref(*args, 'MLE')
+        o = O.forward_train(sd, opt, *args)
+    for a, b in zip(r, o[:4]):
+        assert torch.isfinite(a).all()
+        assert abs(a.item() - b.item()) <= 1e-6

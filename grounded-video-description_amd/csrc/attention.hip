@@ -165,10 +165,16 @@ struct CombParams {
 
 constexpr int MAX_NC = 512;   // chunks per side the combine kernel can merge
 
-__global__ __launch_bounds__(256) void attn_combine_kernel(const CombParams p) {
+// NG groups of 256 threads: each group merges every NG-th chunk (the per-thread chain of dependent-latency partial
+// reads is NG x shorter), group 0 adds the groups up through LDS.  NG = 4 for decode batches, where this kernel is
+// a latency chain in the token loop; NG = 1 when there are enough rows to fill the chip anyway.
+template <int NG>
+__global__ __launch_bounds__(256 * NG) void attn_combine_kernel(const CombParams p) {
+  constexpr int NW = 4 * NG;
   __shared__ float s_sc[MAX_NC];
-  __shared__ float s_red[8];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ float s_red[2 * NW];
+  __shared__ f32x4 s_acc[NG > 1 ? (NG - 1) * 256 : 1];
+  const int b = blockIdx.x, tid = threadIdx.x, grp = tid >> 8, t = tid & 255, wave = tid >> 6;
   f32x4 total = {0.f, 0.f, 0.f, 0.f};
   int c0 = 0;
   for (int s = 0; s < p.nside; ++s) {
@@ -176,50 +182,67 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const CombParams p) {
     const float* ml = p.part_ml + ((int64_t)b * p.nctot + c0) * 2;
     // all (m, l) pairs in parallel: global max, rescale factors exp(m_c - M) into LDS, normaliser L
     float m_loc = -INFINITY;
-    for (int c = tid; c < nc; c += 256) m_loc = fmaxf(m_loc, ml[2 * c]);
+    for (int c = tid; c < nc; c += 256 * NG) m_loc = fmaxf(m_loc, ml[2 * c]);
     m_loc = wave_max(m_loc);
     __syncthreads();
-    if ((tid & 63) == 0) s_red[tid >> 6] = m_loc;
+    if ((tid & 63) == 0) s_red[wave] = m_loc;
     __syncthreads();
-    const float M = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float M = s_red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, s_red[w]);
     float l_loc = 0.f;
-    for (int c = tid; c < nc; c += 256) {
+    for (int c = tid; c < nc; c += 256 * NG) {
       const float sc = expf(ml[2 * c] - M);
       s_sc[c] = sc;
       l_loc = fmaf(sc, ml[2 * c + 1], l_loc);
     }
     l_loc = wave_sum(l_loc);
-    if ((tid & 63) == 0) s_red[4 + (tid >> 6)] = l_loc;
+    if ((tid & 63) == 0) s_red[NW + wave] = l_loc;
     __syncthreads();
-    const float L = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) L += s_red[NW + w];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* pc = p.part_ctx + ((int64_t)b * p.nctot + c0) * ATT_H + 4 * tid;
-    int c = 0;
-    for (; c + 4 <= nc; c += 4) {
+    const float* pc = p.part_ctx + ((int64_t)b * p.nctot + c0) * ATT_H + 4 * t;
+    int c = grp;
+    for (; c + 3 * NG < nc; c += 4 * NG) {
       f32x4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(pc + (int64_t)(c + u) * ATT_H);
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(pc + (int64_t)(c + u * NG) * ATT_H);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float sc = s_sc[c + u];
+        const float sc = s_sc[c + u * NG];
         acc[0] = fmaf(sc, v[u][0], acc[0]); acc[1] = fmaf(sc, v[u][1], acc[1]);
         acc[2] = fmaf(sc, v[u][2], acc[2]); acc[3] = fmaf(sc, v[u][3], acc[3]);
       }
     }
-    for (; c < nc; ++c) {
+    for (; c < nc; c += NG) {
       const float sc = s_sc[c];
       const f32x4 v = *reinterpret_cast<const f32x4*>(pc + (int64_t)c * ATT_H);
       acc[0] = fmaf(sc, v[0], acc[0]); acc[1] = fmaf(sc, v[1], acc[1]);
       acc[2] = fmaf(sc, v[2], acc[2]); acc[3] = fmaf(sc, v[3], acc[3]);
     }
-    const float inv = 1.0f / L;
-    acc[0] *= inv; acc[1] *= inv; acc[2] *= inv; acc[3] *= inv;
-    if (p.ctx_out[s]) *reinterpret_cast<f32x4*>(p.ctx_out[s] + (int64_t)b * ATT_H + 4 * tid) = acc;
-    total[0] += acc[0]; total[1] += acc[1]; total[2] += acc[2]; total[3] += acc[3];
+    if (NG > 1) {
+      if (grp > 0) s_acc[(grp - 1) * 256 + t] = acc;
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int g = 0; g < NG - 1; ++g) {
+          const f32x4 o = s_acc[g * 256 + t];
+          acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3];
+        }
+      }
+    }
+    if (grp == 0) {
+      const float inv = 1.0f / L;
+      acc[0] *= inv; acc[1] *= inv; acc[2] *= inv; acc[3] *= inv;
+      if (p.ctx_out[s]) *reinterpret_cast<f32x4*>(p.ctx_out[s] + (int64_t)b * ATT_H + 4 * t) = acc;
+      total[0] += acc[0]; total[1] += acc[1]; total[2] += acc[2]; total[3] += acc[3];
+    }
     c0 += nc;
-    __syncthreads();   // s_sc / s_red reused by the next side
+    __syncthreads();   // s_sc / s_red / s_acc reused by the next side
   }
-  if (p.out_sum) *reinterpret_cast<f32x4*>(p.out_sum + (int64_t)b * p.ld_out + 4 * tid) = total;
+  if (grp == 0 && p.out_sum) *reinterpret_cast<f32x4*>(p.out_sum + (int64_t)b * p.ld_out + 4 * t) = total;
 }
 
 // rows per chunk: 50; halved (not below 13) while fewer than ~512 workgroups would exist (small batches)
@@ -286,7 +309,10 @@ extern "C" int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_sid
   c.part_ctx = p.part_ctx; c.part_ml = p.part_ml; c.nside = p.nside; c.nctot = p.nctot;
   c.nc[0] = p.side[0].nchunks; c.nc[1] = temporal ? p.side[1].nchunks : 0;
   c.out_sum = out_sum; c.ld_out = ld_out; c.ctx_out[0] = ctx_region; c.ctx_out[1] = ctx_temporal;
-  hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)B), dim3(256), 0, st, c);
+  if (B <= 64)
+    hipLaunchKernelGGL(attn_combine_kernel<4>, dim3((unsigned)B), dim3(1024), 0, st, c);
+  else
+    hipLaunchKernelGGL(attn_combine_kernel<1>, dim3((unsigned)B), dim3(256), 0, st, c);
   GVD_CHECK_LAUNCH();
   return 0;
 }

@@ -8,6 +8,7 @@
 // activation rows are re-read through L1, and the per-(row, m) partial sums are reduced with xor-shuffles.
 // Grid = N / (4 waves * RPW) workgroups (256 for the LSTM) so every CU streams weights.
 // Same C-ABI semantics as gemm_nt_kernel (csrc/gemm_f32.hip); called from gvd_gemm_nt_f32 / gvd_lstm_cell_fwd.
+#include <stdlib.h>
 #include "gvd_common.h"
 #include "gemv_f32.h"
 
@@ -15,21 +16,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-template <int MB, int RPW, bool LSTM>
-__global__ __launch_bounds__(256) void gemv_nt_kernel(const GemvParams p) {
+template <int MB, int RPW, int KS, bool LSTM>
+__global__ __launch_bounds__(256 * KS) void gemv_nt_kernel(const GemvParams p) {
+  // 4 column groups x KS K-slices of waves: the K-slices put KS x more weight bytes in flight per CU (the
+  // products are latency-bound otherwise: a wave only has RPW x 1 KiB outstanding per iteration) and are
+  // summed through LDS by the slice-0 waves, which also run the epilogue.
+  __shared__ float s_part[(KS > 1 ? KS - 1 : 1) * 4 * RPW * MB];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int cg = wave & 3, kq = wave >> 2;
   // weight rows of this wave
   int wrow[RPW];
   bool rok[RPW];
   int j = 0;
   if (LSTM) {
-    j = blockIdx.x * 4 + wave;                 // hidden unit; RPW == 4 gate rows
+    j = blockIdx.x * 4 + cg;                   // hidden unit; RPW == 4 gate rows
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) { wrow[r] = r * p.H + j; rok[r] = j < p.H; }
+    for (int r = 0; r < RPW; ++r) { rok[r] = j < p.H; wrow[r] = rok[r] ? r * p.H + j : 0; }
   } else {
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-      const int n = (blockIdx.x * 4 + wave) * RPW + r;
+      const int n = (blockIdx.x * 4 + cg) * RPW + r;
       rok[r] = n < p.N;
       wrow[r] = rok[r] ? n : 0;
     }
@@ -45,7 +51,7 @@ __global__ __launch_bounds__(256) void gemv_nt_kernel(const GemvParams p) {
     const float* W = p.W[s];
     const int64_t lda = p.lda[s], ldw = p.ldw[s];
     const int K = p.K[s];
-    for (int k = lane * 4; k < K; k += 256) {
+    for (int k = (kq * 64 + lane) * 4; k < K; k += 256 * KS) {
       f32x4 w[RPW];
 #pragma unroll
       for (int r = 0; r < RPW; ++r) w[r] = *reinterpret_cast<const f32x4*>(W + (int64_t)wrow[r] * ldw + k);
@@ -64,6 +70,26 @@ __global__ __launch_bounds__(256) void gemv_nt_kernel(const GemvParams p) {
   for (int r = 0; r < RPW; ++r)
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[r][m] = wave_sum(acc[r][m]);
+
+  if (KS > 1) {
+    if (kq > 0 && lane == 0) {
+      float* dst = s_part + ((kq - 1) * 4 + cg) * RPW * MB;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) dst[r * MB + m] = acc[r][m];
+    }
+    __syncthreads();
+    if (kq > 0) return;
+#pragma unroll
+    for (int q = 0; q < KS - 1; ++q) {
+      const float* src = s_part + (q * 4 + cg) * RPW * MB;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[r][m] += src[r * MB + m];
+    }
+  }
 
   if (!LSTM) {
     // lane m writes row m of the RPW columns
@@ -112,14 +138,43 @@ __global__ __launch_bounds__(256) void gemv_nt_kernel(const GemvParams p) {
   }
 }
 
-template <int MB, int RPW, bool LSTM>
-int launch(const GemvParams& p, hipStream_t st) {
+// K-slices per workgroup (GVD_GEMV_KS = 1 | 2 | 4, default 4; 1 is the single-slice form kept for A/B runs)
+int gemv_ks() {
+  static const int ks = [] {
+    const char* e = getenv("GVD_GEMV_KS");
+    const int v = e ? atoi(e) : 4;
+    return (v == 1 || v == 2) ? v : 4;
+  }();
+  return ks;
+}
+
+template <int MB, int RPW, int KS, bool LSTM>
+int launch_ks(const GemvParams& p, hipStream_t st) {
   const int cols_per_wg = 4 * (LSTM ? 1 : RPW);
   const int total = LSTM ? p.H : p.N;
   dim3 grid((unsigned)((total + cols_per_wg - 1) / cols_per_wg));
-  hipLaunchKernelGGL((gemv_nt_kernel<MB, RPW, LSTM>), grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL((gemv_nt_kernel<MB, RPW, KS, LSTM>), grid, dim3(256 * KS), 0, st, p);
   GVD_CHECK_LAUNCH();
   return 0;
+}
+
+template <int MB, int RPW, bool LSTM>
+int launch(const GemvParams& p, hipStream_t st) {
+  // 4 slices = 1024 threads = a 128-VGPR budget: only the variants with <= 16 accumulators fit without spilling
+  constexpr int KS_MAX = (RPW * MB <= 16) ? 4 : 2;
+  const int ks = gemv_ks() < KS_MAX ? gemv_ks() : KS_MAX;
+  switch (ks) {
+    case 1: return launch_ks<MB, RPW, 1, LSTM>(p, st);
+    case 2: return launch_ks<MB, RPW, 2, LSTM>(p, st);
+    default: return launch_ks<MB, RPW, KS_MAX, LSTM>(p, st);
+  }
+}
+
+template <int RPW>
+int dispatch_plain(const GemvParams& p, hipStream_t st) {
+  if (p.M <= 4) return launch<4, RPW, false>(p, st);
+  if (p.M <= 8) return launch<8, RPW, false>(p, st);
+  return launch<16, RPW, false>(p, st);
 }
 
 template <bool LSTM>
@@ -129,10 +184,10 @@ int dispatch(const GemvParams& p, hipStream_t st) {
     if (p.M <= 8) return launch<8, 4, true>(p, st);
     return launch<16, 4, true>(p, st);
   }
-  const bool wide = p.N >= 4096;     // enough columns for 4 rows per wave and still >= 256 workgroups
-  if (p.M <= 4) return wide ? launch<4, 4, false>(p, st) : launch<4, 2, false>(p, st);
-  if (p.M <= 8) return wide ? launch<8, 4, false>(p, st) : launch<8, 2, false>(p, st);
-  return wide ? launch<16, 4, false>(p, st) : launch<16, 2, false>(p, st);
+  // rows per wave: keep >= 256 workgroups (one per CU) whenever N allows it
+  if (p.N >= 4096) return dispatch_plain<4>(p, st);
+  if (p.N >= 2048) return dispatch_plain<2>(p, st);
+  return dispatch_plain<1>(p, st);
 }
 
 }  // namespace

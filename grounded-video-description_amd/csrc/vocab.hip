@@ -88,6 +88,68 @@ __global__ __launch_bounds__(256) void top2_embed_kernel(const float* __restrict
   }
 }
 
+// Same contract as top2_embed_kernel for V <= 8 * 1024: 16 waves per row, the row is read ONCE (8 independent
+// loads per lane, all in flight together) and stays in registers for the exp pass.  The per-step token rule is a
+// pure latency chain (logits -> max -> sum -> id -> embedding row), so the work is spread as wide as it goes.
+constexpr int T2W_THREADS = 1024;
+constexpr int T2W_SLOTS = 8;
+
+__global__ __launch_bounds__(T2W_THREADS) void top2_embed_wide_kernel(const float* __restrict__ logits, int64_t ld,
+                                                                      int V, int unk, int64_t* it_out,
+                                                                      int64_t it_stride, float* lp_out,
+                                                                      int64_t lp_stride,
+                                                                      const float* __restrict__ embed, int E,
+                                                                      float* xt, int64_t ld_xt) {
+  __shared__ float s_red[16];
+  __shared__ Top2 s_top[16];
+  __shared__ int s_it;
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+  const float* x = logits + (int64_t)b * ld;
+  float v[T2W_SLOTS];
+#pragma unroll
+  for (int u = 0; u < T2W_SLOTS; ++u) {
+    const int i = tid + u * T2W_THREADS;
+    v[u] = i < V ? x[i] : -INFINITY;
+  }
+  Top2 t = {-INFINITY, 0x7fffffff, -INFINITY, 0x7fffffff};
+#pragma unroll
+  for (int u = 0; u < T2W_SLOTS; ++u) {
+    const int i = tid + u * T2W_THREADS;
+    if (i < V) top2_insert(t, v[u], i);
+  }
+  t = top2_wave(t);
+  if ((tid & 63) == 0) s_top[wave] = t;
+  __syncthreads();
+  Top2 g = s_top[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) g = top2_merge(g, s_top[w]);
+  const float mx = g.v1;
+  float se = 0.f;
+#pragma unroll
+  for (int u = 0; u < T2W_SLOTS; ++u) {
+    const int i = tid + u * T2W_THREADS;
+    if (i < V) se += expf(v[u] - mx);
+  }
+  se = wave_sum(se);
+  if ((tid & 63) == 0) s_red[wave] = se;
+  const bool keep = g.i1 != unk;
+  const int it = keep ? g.i1 : g.i2;
+  // the embedding row does not depend on the sum: gather it while the reduction finishes
+  if (xt) {
+    const float* e = embed + (int64_t)it * E;
+    for (int i = tid; i < E; i += T2W_THREADS) xt[(int64_t)b * ld_xt + i] = fmaxf(e[i], 0.f);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += s_red[w];
+    const float lse = logf(tot);
+    it_out[(int64_t)b * it_stride] = it;
+    lp_out[(int64_t)b * lp_stride] = keep ? (g.v1 - mx) - lse : (g.v2 - mx) - lse;
+  }
+}
+
 __global__ __launch_bounds__(256) void embed_relu_kernel(const int64_t* it, int64_t it_stride,
                                                          const float* __restrict__ embed, int E, float* xt,
                                                          int64_t ld_xt) {
@@ -153,8 +215,12 @@ extern "C" int gvd_logsoftmax_top2_embed(const float* logits, int64_t ld_logits,
                                          const float* embed, int E, float* xt_next, int64_t ld_xt,
                                          gvd_stream_t stream) {
   if (!logits || !it_out || !lp_out || B <= 0 || V < 2 || (xt_next && !embed)) return GVD_EINVAL;
-  hipLaunchKernelGGL(top2_embed_kernel, dim3((unsigned)B), dim3(256), 0, gvd_s(stream), logits, ld_logits, V,
-                     unk_idx, it_out, it_stride, lp_out, lp_stride, embed, E, xt_next, ld_xt);
+  if (V <= T2W_SLOTS * T2W_THREADS && B <= 64)   // decode batches: one wide workgroup per row (latency chain)
+    hipLaunchKernelGGL(top2_embed_wide_kernel, dim3((unsigned)B), dim3(T2W_THREADS), 0, gvd_s(stream), logits,
+                       ld_logits, V, unk_idx, it_out, it_stride, lp_out, lp_stride, embed, E, xt_next, ld_xt);
+  else
+    hipLaunchKernelGGL(top2_embed_kernel, dim3((unsigned)B), dim3(256), 0, gvd_s(stream), logits, ld_logits, V,
+                       unk_idx, it_out, it_stride, lp_out, lp_stride, embed, E, xt_next, ld_xt);
   GVD_CHECK_LAUNCH();
   return 0;
 }

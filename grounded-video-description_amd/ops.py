@@ -444,13 +444,18 @@ def gru_bidir_2layer(x, gru, barrier=None):
         b_f, b_b = g('bias_hh').contiguous(), gr('bias_hh').contiguous()
         sync = None
         if (barrier or GRU_BARRIER) == 'counter':
-            sync = torch.zeros(2 * ((B + 255) // 256), dtype=torch.int32, device=x.device)
+            sync = torch.zeros(lib().gvd_grid_sync_words() * ((B + 255) // 256), dtype=torch.int32, device=x.device)
             syncs.append(sync)
         check(lib().gvd_gru_bidir_layer(ptr(gi), ptr(w_f), ptr(b_f), ptr(w_b), ptr(b_b), ptr(out), B, T, Hh,
                                         ptr(sync), stream_ptr()), 'gvd_gru_bidir_layer')
         inp = out
-    gru_bidir_2layer.last_sync = syncs     # tests read the timeout flags (word 1 of each pair) after a device sync
+    gru_bidir_2layer.last_sync = syncs     # tests read the timeout flags (sync_timed_out) after a device sync
     return inp
+
+
+def sync_timed_out(sync):
+    """True when any barrier object in `sync` (gvd_grid_sync_words() words each) raised its timeout word."""
+    return int(sync.view(-1, lib().gvd_grid_sync_words())[:, 32].sum()) != 0
 
 
 def add_layernorm_unbiased(x, y, gamma, beta, eps=1e-6):

@@ -172,9 +172,13 @@ int gvd_flash_attn_f32(const float* q, const float* k, const float* v, float* o,
  * gi [B,T,2,3*Hh] = X [W_ih_fw ; W_ih_bw]^T + [b_ih_fw ; b_ih_bw] (one gvd_gemm_nt_f32 call, N = 6*Hh);
  * out [B,T,2*Hh] = [h_fw | h_bw] exactly like torch's batch_first bidirectional output.  Hh must be 512.
  * ------------------------------------------------------------------------------------------- */
+/* Size (uint32 words) of one grid-barrier object used by the persistent kernels of this library. */
+int gvd_grid_sync_words(void);
+
 /* sync_ws: NULL -> grid-wide synchronisation by the HIP cooperative-groups library; otherwise a device buffer of
- * 2*ceil(B/256) uint32 ZEROED by the caller before every call -> hand-rolled counter barrier (agent-scope
- * release/acquire, bounded spin).  After the call word [2*i+1] != 0 means slice i timed out (results invalid). */
+ * gvd_grid_sync_words()*ceil(B/256) uint32 ZEROED by the caller before every call -> hand-rolled two-level counter
+ * barrier (no cache fences: the recurrent state is exchanged with agent-coherent accesses; bounded spin).  After
+ * the call word [32] of slice i's object != 0 means slice i timed out (results invalid). */
 int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const float* b_hh_fw, const float* w_hh_bw,
                         const float* b_hh_bw, float* out, int B, int T, int Hh, void* sync_ws,
                         gvd_stream_t stream);

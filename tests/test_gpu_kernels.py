@@ -201,7 +201,7 @@ def test_gru_persistent_kernel(B, T, barrier):
             flags += ops.gru_bidir_2layer.last_sync
         torch.cuda.synchronize()
     for f in flags:                                   # counter barrier: no workgroup timed out
-        assert int(f.view(-1, 2)[:, 1].sum()) == 0
+        assert not ops.sync_timed_out(f)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     np.testing.assert_allclose(outs[0].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=5e-5)
 

@@ -1,29 +1,52 @@
 """Build libgvd_hip.so (the C-ABI HIP library, include/gvd_hip.h) in-tree with hipcc for gfx950.
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
-git-ignored but travels to the GPU box with the repo snapshot.
+git-ignored but travels to the GPU box with the repo snapshot.  Every source is compiled to its own
+object (in parallel, only when it or a header changed), then linked.
 """
 import hashlib
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libgvd_hip.so')
 STAMP = LIB + '.srchash'
-SOURCES = ['gemm_f32.hip', 'gemv_f32.hip', 'attention.hip', 'vocab.hip', 'decode.hip', 'targets.hip', 'prof.hip', 'backward.hip', 'gru.hip', 'rowwise.hip', 'flash_attn.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-gpu-rdc',
-         '-Wno-unused-result']
+SOURCES = ['gemm_f32.hip', 'gemv_f32.hip', 'attention.hip', 'vocab.hip', 'decode.hip', 'decode_persistent.hip',
+           'targets.hip', 'prof.hip', 'backward.hip', 'gru.hip', 'rowwise.hip', 'flash_attn.hip']
+HEADERS = ['gvd_common.h', 'gemv_f32.h', 'top2.h', 'decode_persistent.h']
+CFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
+# decode_persistent.hip keeps ~150 weight registers per lane for the whole launch; the SLP vectorizer would pair its
+# accumulators into v_pk_fma_f32 and splat every resident weight into a register PAIR (2x the footprint -> spills)
+EXTRA = {'decode_persistent.hip': ['-fno-slp-vectorize']}
+LDFLAGS = ['--offload-arch=gfx950', '-shared', '-fPIC', '-fno-gpu-rdc']
+
+
+def _header_hash():
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, x) for x in HEADERS] + [os.path.join(HERE, '..', 'include', 'gvd_hip.h')]:
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _file_hash(src, hh):
+    h = hashlib.sha256()
+    with open(os.path.join(CSRC, src), 'rb') as fh:
+        h.update(fh.read())
+    h.update(hh.encode())
+    h.update(' '.join(CFLAGS + EXTRA.get(src, [])).encode())
+    return h.hexdigest()
 
 
 def _source_hash():
+    hh = _header_hash()
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'gvd_common.h'), os.path.join(CSRC, 'gemv_f32.h'),
-                                                       os.path.join(HERE, '..', 'include', 'gvd_hip.h')]
-    for f in files:
-        with open(f, 'rb') as fh:
-            h.update(fh.read())
-    h.update(' '.join(FLAGS).encode())
+    for s in SOURCES:
+        h.update(_file_hash(s, hh).encode())
+    h.update(' '.join(LDFLAGS).encode())
     return h.hexdigest()
 
 
@@ -42,7 +65,28 @@ def build_library(force=False, verbose=True):
     if not force and is_fresh():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+    os.makedirs(OBJ, exist_ok=True)
+    hh = _header_hash()
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, src + '.o')
+        tag = obj + '.hash'
+        want = _file_hash(src, hh)
+        if not force and os.path.exists(obj) and os.path.exists(tag):
+            with open(tag) as f:
+                if f.read().strip() == want:
+                    return obj
+        cmd = [hipcc] + CFLAGS + EXTRA.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print('[gvd build]', ' '.join(cmd))
+        subprocess.check_call(cmd)
+        with open(tag, 'w') as f:
+            f.write(want)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc] + LDFLAGS + objs + ['-o', LIB]
     if verbose:
         print('[gvd build]', ' '.join(cmd))
     subprocess.check_call(cmd)

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
   // staging role: 16 x 16-byte pieces per thread per tile; piece i -> tile row (tid + 256 i) / 128, float4 column % 128
   // (a wave-load covers 1 KiB contiguous of one sample's h_{t-1}: fully coalesced)
 
+  bool dead = false;   // latched barrier timeout (thread 0)
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? step : T - 1 - step;
     const int tp = dir == 0 ? t - 1 : t + 1;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       cg::this_grid().sync();
     } else {
-      grid_barrier_tree(p.sync, (unsigned)step, nwg);
+      grid_barrier_tree(p.sync, (unsigned)step, nwg, dead);
     }
   }
 }

@@ -78,10 +78,12 @@ __device__ __forceinline__ void st_agent_f32(__amdgpu_buffer_rsrc_t r, unsigned 
 // workgroup polls (16 pollers per 128-byte line).  Counters are monotonic over rounds.  Only sc1-coherent data is
 // ordered by this barrier.  Spins are bounded: on timeout the error word is raised and the kernel runs on (wrong
 // values, reported by the host) instead of hanging the GPU.
-__device__ __forceinline__ void grid_barrier_tree(unsigned* sync, unsigned round, unsigned nwg) {
+// `dead` (a per-thread flag, used by thread 0 only) latches a timeout: the workgroup then stops waiting at later
+// barriers, so a broken launch costs one spin limit, not one per barrier.
+__device__ __forceinline__ void grid_barrier_tree(unsigned* sync, unsigned round, unsigned nwg, bool& dead) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && !dead) {
     const unsigned g = blockIdx.x & (GVD_SYNC_GROUPS - 1);
     unsigned* rel = sync + 64 + 32 * GVD_SYNC_GROUPS + 32 * g;
     const unsigned per = nwg / GVD_SYNC_GROUPS;
@@ -100,6 +102,7 @@ __device__ __forceinline__ void grid_barrier_tree(unsigned* sync, unsigned round
       __builtin_amdgcn_s_sleep(1);
       if (++spins > GVD_SPIN_LIMIT) {
         __hip_atomic_store(sync + GVD_SYNC_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = true;
         break;
       }
     }

@@ -204,7 +204,10 @@ def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None):
     a.B, a.Ft, a.R, a.H, a.A, a.E, a.V, a.L, a.unk_idx = B, Ft, R, H, A, E, V, L, unk_idx
     a.seq, a.seq_logprobs, a.att2_weights, a.workspace = ptr(seq), ptr(lps), ptr(att2), ptr(ws)
     a.prof = prof.h if prof is not None else None
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    a.status = ptr(status)
     check(lib().gvd_greedy_decode(C.byref(a), stream_ptr()), 'gvd_greedy_decode')
+    greedy_decode.last_status = status      # 1 after a device sync = the persistent decode kernel timed out (ids are -1)
     return seq, lps, att2
 
 

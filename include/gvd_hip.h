@@ -259,7 +259,9 @@ typedef struct {
   float* seq_logprobs; /* [B,L] */
   float* att2_weights; /* [B,L,R] masked pre-softmax logits */
   void* workspace;     /* gvd_greedy_workspace_bytes(...) bytes */
-  gvd_prof* prof;      /* optional: times the attention streaming kernel of every step */
+  gvd_prof* prof;      /* optional: times the attention streaming kernel of every step (multi-kernel loop only) */
+  int* status;         /* optional device int: set to 0, or to 1 when a grid barrier of the persistent decode-batch
+                          kernel timed out (token ids are then all -1) */
 } gvd_greedy_args;
 
 size_t gvd_greedy_workspace_bytes(int B, int Ft, int R, int H, int A, int E, int V);

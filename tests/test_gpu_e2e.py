@@ -76,6 +76,42 @@ def test_greedy_edge_shapes_match_oracle(name):
     np.testing.assert_allclose(att2.numpy(), oatt2.numpy(), rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize('B,V,Ft,T', [(4, 5000, 10, 10), (1, 1000, 10, 10), (3, 1003, 7, 3), (2, 5000, 480, 10),
+                                      (4, 1000, 10, 20)])
+def test_persistent_decoder_equals_kernel_loop(B, V, Ft, T):
+    """Decode batches (B <= 4) run the token loop as ONE persistent cooperative kernel (decode_persistent.hip);
+    GVD_PERSISTENT=0 selects the multi-kernel loop.  Same ids / attended regions, log-probs within fp32 rounding,
+    no barrier timeout, repeatable."""
+    opt = gvd_amd.opts.default_opt(vocab_size=V, t_attn_size=Ft, num_sampled_frm=T)
+    sd = synth.init_state_dict(opt, seed=B + V, profile='trained_like')
+    model = _model(opt, sd)
+    inp = synth.make_inputs(opt, B, seed=B + Ft, train=False)
+    args = [inp[k].cuda() for k in ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')]
+    from gvd_amd import ops
+    old = os.environ.get('GVD_PERSISTENT')
+    try:
+        with torch.no_grad():
+            os.environ['GVD_PERSISTENT'] = '0'
+            ref = model._sample(*args)
+            os.environ['GVD_PERSISTENT'] = '1'
+            got = model._sample(*args)
+            st1 = ops.greedy_decode.last_status
+            again = model._sample(*args)
+            st2 = ops.greedy_decode.last_status
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            os.environ.pop('GVD_PERSISTENT', None)
+        else:
+            os.environ['GVD_PERSISTENT'] = old
+    assert int(st1) == 0 and int(st2) == 0, 'grid barrier timed out'
+    assert torch.equal(got[0], again[0]) and torch.equal(got[2], again[2])
+    assert torch.equal(got[0], ref[0]), 'token ids differ between the persistent kernel and the kernel loop'
+    assert torch.equal(O.attended_region_indices(got[2].cpu(), opt), O.attended_region_indices(ref[2].cpu(), opt))
+    np.testing.assert_allclose(got[1].cpu().numpy(), ref[1].cpu().numpy(), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(got[2].cpu().numpy(), ref[2].cpu().numpy(), rtol=1e-4, atol=2e-4)
+
+
 def test_forward_api_sample(golden_dir):
     """The public forward(..., 'sample', eval_opt) contract (model.py:227-234): 3 return values, dummies accepted."""
     name = 'greedy_b4_v1000_ft10_trained'

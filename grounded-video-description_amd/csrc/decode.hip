@@ -97,6 +97,7 @@ extern "C" int gvd_greedy_decode(const gvd_greedy_args* a, gvd_stream_t stream) 
     q.logit_w = a->logit_w; q.logit_b = a->logit_b;
     q.B = B; q.Ft = Ft; q.R = R; q.V = V; q.L = L; q.unk = a->unk_idx;
     q.seq = a->seq; q.seq_lp = a->seq_logprobs; q.att2_weights = a->att2_weights; q.status = a->status;
+    q.trace = reinterpret_cast<unsigned long long*>(a->trace);
     const int rc = gvd_pd_launch(q, w.pd_ws, st);
     if (rc == 0) return 0;
     (void)hipGetLastError();   // e.g. not all 256 workgroups can be co-resident here: use the multi-kernel loop

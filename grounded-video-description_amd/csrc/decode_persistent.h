@@ -22,6 +22,7 @@ struct PdParams {
   unsigned* sync;
   // outputs
   int64_t* seq; float* seq_lp; float* att2_weights; int* status;
+  unsigned long long* trace;                 // optional: 1 + 7 L phase-boundary time stamps of workgroup 0
 };
 
 bool gvd_pd_shape_ok(int B, int H, int A, int E, int V, int R, int Ft);   // pure: sizes the workspace

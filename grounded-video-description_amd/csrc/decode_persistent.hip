@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
   __shared__ __attribute__((aligned(16))) f32x4 s_half[256];
   __shared__ float s_logit[PD_MB][PD_RPW + 4];
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: row / K-half offsets become SGPR math
   const int u = wave & 3, kh = wave >> 2;
   const int wg = blockIdx.x;
   const int B = p.B, R = p.R, Ft = p.Ft, V = p.V, L = p.L;
@@ -111,23 +113,48 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
 
   // ---------------------------------------------------------------- resident weights
   const int j = 4 * wg + u;                       // hidden unit of this wave (both LSTMs)
-  f32x4 w_lang[4][6], w_att[4][3], w_q[2];
+  // LSTM weights as gate PAIRS (.x = gate 2gp, .y = gate 2gp+1) so that one v_pk_fma_f32 feeds two gate accumulators
+  // from one broadcast activation (the VALU FMA rate, not memory, bounds these products: 16 rows x 3072 x 4 samples).
+  // The language LSTM (96 registers) stays resident for the whole launch; the attention LSTM's 48 are re-fetched from
+  // L2 every step during P6 (prefetch for the next P1), which keeps them out of the register-hungry attention phase.
+  f32x2 w_lang[2][6][4], w_att[2][3][4];
+  f32x4 w_q[2];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int64_t row = (int64_t)g * PD_H + j;
+  for (int gp = 0; gp < 2; ++gp) {
+    const int64_t row0 = (int64_t)(2 * gp) * PD_H + j, row1 = row0 + PD_H;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int k = 256 * (kh * 6 + i) + 4 * lane;            // index into [att_sum | h_att | h_lang]
-      const float* src = k < 2 * PD_H ? p.lang_w_ih + row * (2 * PD_H) + k : p.lang_w_hh + row * PD_H + (k - 2 * PD_H);
-      w_lang[g][i] = *reinterpret_cast<const f32x4*>(src);
-    }
+      const float* s0 = k < 2 * PD_H ? p.lang_w_ih + row0 * (2 * PD_H) + k : p.lang_w_hh + row0 * PD_H + (k - 2 * PD_H);
+      const float* s1 = k < 2 * PD_H ? p.lang_w_ih + row1 * (2 * PD_H) + k : p.lang_w_hh + row1 * PD_H + (k - 2 * PD_H);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(s0), b = *reinterpret_cast<const f32x4*>(s1);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int k = 256 * (kh * 3 + i) + 4 * lane;            // index into [xt | h_att]
-      const float* src = k < PD_E ? p.att_w_ih + row * (PD_H + PD_E) + PD_H + k : p.att_w_hh + row * PD_H + (k - PD_E);
-      w_att[g][i] = *reinterpret_cast<const f32x4*>(src);
+      for (int c = 0; c < 4; ++c) w_lang[gp][i][c] = f32x2{a[c], b[c]};
     }
   }
+  // buffer loads with scalar row offsets: no per-lane 64-bit addresses to keep alive across the token loop
+  const __amdgpu_buffer_rsrc_t rs_wih = gvd_rsrc(p.att_w_ih), rs_whh = gvd_rsrc(p.att_w_hh);
+  auto load_w_att = [&]() {
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      const int row0 = (2 * gp) * PD_H + j, row1 = row0 + PD_H;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int k0 = 256 * (kh * 3 + i);                    // block start in [xt | h_att]  (wave-uniform)
+        f32x4 a, b;
+        if (k0 < PD_E) {
+          a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wih, 16 * lane, (row0 * (PD_H + PD_E) + PD_H + k0) * 4, 0));
+          b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wih, 16 * lane, (row1 * (PD_H + PD_E) + PD_H + k0) * 4, 0));
+        } else {
+          a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_whh, 16 * lane, (row0 * PD_H + k0 - PD_E) * 4, 0));
+          b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_whh, 16 * lane, (row1 * PD_H + k0 - PD_E) * 4, 0));
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w_att[gp][i][c] = f32x2{a[c], b[c]};
+      }
+    }
+  };
+  load_w_att();
   const int qrow = 4 * wg + u;                    // row of the stacked query projection [W_att ; W_att2]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -138,6 +165,11 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (rl < rpw && n < V) v = *reinterpret_cast<const f32x4*>(p.logit_w + (int64_t)n * PD_H + 4 * c4);
     *reinterpret_cast<f32x4*>(&s_wlog[rl][4 * c4]) = v;
+  }
+  float vb = 0.f;                                 // logit bias of the row this lane publishes in P6 (lane < 12)
+  {
+    const int rl = wave + 8 * (lane >> 2), n = wg * rpw + rl;
+    if (lane < 12 && rl < rpw && n < V) vb = p.logit_b[n];
   }
   // epilogue lanes: wave (u, kh = 0), lane m < B owns (sample m, unit j): cell states and constant gate terms
   const bool epi = kh == 0 && lane < B;
@@ -155,12 +187,17 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
   for (int idx = tid; idx < PD_MB * PD_E; idx += PD_NT) (&s_xt[0][0])[idx] = fmaxf(p.embed[idx % PD_E], 0.f);
   __syncthreads();
 
+  int n_stamp = 0;
+#define PD_STAMP() do { if (p.trace && wg == 0 && tid == 0) p.trace[n_stamp++] = wall_clock64(); } while (0)
+  PD_STAMP();
   for (int t = 0; t < L; ++t) {
     // ============================================================ P1: attention LSTM
     {
-      float acc[16];
+      f32x2 acc2[2][PD_MB];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+        for (int m = 0; m < PD_MB; ++m) acc2[gp][m] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const int kb = kh * 3 + i;                           // 256-float block of [xt | h_att]
@@ -169,9 +206,17 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
           const float* ap = kb < 2 ? &s_xt[m][256 * kb + 4 * lane] : &s_act[m][PD_H + 256 * (kb - 2) + 4 * lane];
           const f32x4 a = *reinterpret_cast<const f32x4*>(ap);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[g * 4 + m] = dot4(w_att[g][i], a, acc[g * 4 + m]);
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp)
+              acc2[gp][m] = __builtin_elementwise_fma(w_att[gp][i][c], f32x2{a[c], a[c]}, acc2[gp][m]);
         }
       }
+      float acc[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int m = 0; m < PD_MB; ++m) acc[g * 4 + m] = acc2[g >> 1][m][g & 1];
       const float r = reduce16(acc, lane);
       if (lane < 16) s_red[kh][u][lane] = r;
       __syncthreads();
@@ -186,6 +231,7 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
       }
     }
     grid_barrier_tree(p.sync, round++, PD_G, dead);
+    PD_STAMP();
 
     // ============================================================ P2: attention queries
     {
@@ -211,6 +257,7 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
       if (epi) st_agent_f32(rs_q, (unsigned)(lane * 2 * PD_A + qrow) * 4, s_red[0][u][lane] + s_red[1][u][lane] + qb);
     }
     grid_barrier_tree(p.sync, round++, PD_G, dead);
+    PD_STAMP();
 
     // ============================================================ P3: attention partials
     for (int item = wg; item < B * nct; item += PD_G) {
@@ -230,6 +277,16 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
       const f32x4 w1 = *reinterpret_cast<const f32x4*>(wv + 256 + 4 * lane);
       const uint8_t* am = tmp ? nullptr : p.pnt_mask + (int64_t)b * (R + 1) + 1 + n0;
       float* lo = tmp ? nullptr : p.att2_weights + ((int64_t)b * L + t) * R + n0;
+      // context phase role: thread = (4 columns of H = 1024, row parity).  Its first 4 feature rows do not depend on
+      // the scores: request them now so their HBM latency hides behind the scoring pass
+      const int c4 = tid & 255, par = tid >> 8;
+      const float* fb = ff + 4 * c4;
+      f32x4 v0[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        v0[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (par + 2 * x < rows) v0[x] = *reinterpret_cast<const f32x4*>(fb + (int64_t)(par + 2 * x) * PD_H);
+      }
       // scores: 8 waves x 2 rows per pass; the lane owns columns [4 lane, +4) and [256 + 4 lane, +4) of A = 512
       for (int r = wave * 2; r < rows; r += 16) {
         const bool two = (r + 1) < rows;
@@ -278,12 +335,17 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
         st_agent_f32(rs_pml, (unsigned)(b * nct + c) * 8 + 4, lsum);
       }
       __syncthreads();
-      // partial context: thread = (4 columns of H = 1024, row parity)
+      // partial context
       {
-        const int c4 = tid & 255, par = tid >> 8;
-        const float* fb = ff + 4 * c4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        int r = par;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int r0 = par + 2 * x;
+          const float pw = r0 < rows ? s_score[r0] : 0.f;
+          acc[0] = fmaf(pw, v0[x][0], acc[0]); acc[1] = fmaf(pw, v0[x][1], acc[1]);
+          acc[2] = fmaf(pw, v0[x][2], acc[2]); acc[3] = fmaf(pw, v0[x][3], acc[3]);
+        }
+        int r = par + 8;
         for (; r + 6 < rows; r += 8) {
           f32x4 v[4];
 #pragma unroll
@@ -312,12 +374,18 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
       __syncthreads();   // s_score / s_half are reused by the next item
     }
     grid_barrier_tree(p.sync, round++, PD_G, dead);
+    PD_STAMP();
 
     // ============================================================ P4: combine chunk partials -> att + att2
     {
       const int b = wg >> 6, cb = wg & 63;                     // sample, block of 16 columns
       if (b < B) {
         // per-chunk rescale factors exp(m_c - M_side) / L_side (the side's softmax normaliser folded in)
+        // thread = (column quad cq, chunk slot cs): 64-byte pieces of the partial contexts; the first piece is
+        // requested before the (m, l) round trip so that the two coherent-load latencies overlap
+        const int cq = tid & 3, cs = tid >> 2;
+        f32x4 v_first = {0.f, 0.f, 0.f, 0.f};
+        if (cs < nct) v_first = ld_agent_x4(rs_pctx, (unsigned)(((int64_t)b * nct + cs) * PD_H + 16 * cb + 4 * cq) * 4);
         float mc = -INFINITY, lc = 0.f;
         const bool has = tid < nct;
         const bool side1 = tid >= p.nch_r;
@@ -341,10 +409,12 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
         for (int w = 0; w < 8; ++w) { l0 += s_stat[w]; l1 += s_stat[8 + w]; }
         if (has) s_sc[tid] = e / (side1 ? l1 : l0);
         __syncthreads();
-        // thread = (column quad cq, chunk slot cs): 64-byte pieces of the partial contexts
-        const int cq = tid & 3, cs = tid >> 2;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int c = cs; c < nct; c += PD_NT / 4) {
+        if (cs < nct) {
+          const float sc = s_sc[cs];
+          acc[0] = sc * v_first[0]; acc[1] = sc * v_first[1]; acc[2] = sc * v_first[2]; acc[3] = sc * v_first[3];
+        }
+        for (int c = cs + PD_NT / 4; c < nct; c += PD_NT / 4) {
           const f32x4 v = ld_agent_x4(rs_pctx, (unsigned)(((int64_t)b * nct + c) * PD_H + 16 * cb + 4 * cq) * 4);
           const float sc = s_sc[c];
           acc[0] = fmaf(sc, v[0], acc[0]); acc[1] = fmaf(sc, v[1], acc[1]);
@@ -369,6 +439,7 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
       }
     }
     grid_barrier_tree(p.sync, round++, PD_G, dead);
+    PD_STAMP();
 
     // ============================================================ P5: language LSTM
     {
@@ -381,9 +452,11 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
         *reinterpret_cast<f32x4*>(&s_act[m][4 * c4]) = v;
       }
       __syncthreads();
-      float acc[16];
+      f32x2 acc2[2][PD_MB];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+        for (int m = 0; m < PD_MB; ++m) acc2[gp][m] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int kb = kh * 6 + i;
@@ -391,9 +464,18 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
         for (int m = 0; m < PD_MB; ++m) {
           const f32x4 a = *reinterpret_cast<const f32x4*>(&s_act[m][256 * kb + 4 * lane]);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[g * 4 + m] = dot4(w_lang[g][i], a, acc[g * 4 + m]);
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp)
+              acc2[gp][m] = __builtin_elementwise_fma(w_lang[gp][i][c], f32x2{a[c], a[c]}, acc2[gp][m]);
         }
+        __builtin_amdgcn_sched_barrier(0);   // one K-block at a time: 24 hoisted LDS reads would not fit next to the weights
       }
+      float acc[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int m = 0; m < PD_MB; ++m) acc[g * 4 + m] = acc2[g >> 1][m][g & 1];
       const float r = reduce16(acc, lane);
       if (lane < 16) s_red[kh][u][lane] = r;
       __syncthreads();
@@ -408,59 +490,70 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
       }
     }
     grid_barrier_tree(p.sync, round++, PD_G, dead);
+    PD_STAMP();
 
     // ============================================================ P6: vocabulary logits of this workgroup's rows
     {
+      f32x4 hv[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int idx = tid + i * PD_NT;
         const int m = idx >> 8, c4 = idx & 255;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m < B) v = ld_agent_x4(rs_hlang, (unsigned)(m * PD_H + 4 * c4) * 4);
-        *reinterpret_cast<f32x4*>(&s_act[m][2 * PD_H + 4 * c4]) = v;
+        hv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < B) hv[i] = ld_agent_x4(rs_hlang, (unsigned)(m * PD_H + 4 * c4) * 4);
+      }
+      // next step's attention-LSTM weights: requested AFTER the state loads (memory returns in order) and in flight
+      // during P6/P7
+      load_w_att();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * PD_NT;
+        *reinterpret_cast<f32x4*>(&s_act[idx >> 8][2 * PD_H + 4 * (idx & 255)]) = hv[i];
       }
       __syncthreads();
       float acc[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int rl = wave + 8 * i;                           // local vocabulary row (wave-uniform)
-        if (rl < rpw) {
+      for (int jb = 0; jb < 4; ++jb) {
+        f32x4 a[PD_MB];
 #pragma unroll
-          for (int jb = 0; jb < 4; ++jb) {
+        for (int m = 0; m < PD_MB; ++m) a[m] = *reinterpret_cast<const f32x4*>(&s_act[m][2 * PD_H + 256 * jb + 4 * lane]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int rl = wave + 8 * i;                         // local vocabulary row (wave-uniform)
+          if (rl < rpw) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(&s_wlog[rl][256 * jb + 4 * lane]);
 #pragma unroll
-            for (int m = 0; m < PD_MB; ++m)
-              acc[i * 4 + m] = dot4(w, *reinterpret_cast<const f32x4*>(&s_act[m][2 * PD_H + 256 * jb + 4 * lane]),
-                                    acc[i * 4 + m]);
-              }
+            for (int m = 0; m < PD_MB; ++m) acc[i * 4 + m] = dot4(w, a[m], acc[i * 4 + m]);
+          }
         }
       }
       const float r = reduce16(acc, lane);
       if (lane < 12) {
         const int i = lane >> 2, m = lane & 3, rl = wave + 8 * i, n = wg * rpw + rl;
-        if (rl < rpw) s_logit[m][rl] = n < V ? r + p.logit_b[n] : -INFINITY;
+        if (rl < rpw) s_logit[m][rl] = n < V ? r + vb : -INFINITY;
       }
       __syncthreads();
-      if (tid < B) {
-        // record: {max, sum exp(x - max), top-1 value, top-1 id, top-2 value, top-2 id}
-        Top2 tp = {-INFINITY, 0x7fffffff, -INFINITY, 0x7fffffff};
-        for (int rl = 0; rl < rpw; ++rl) {
-          const int n = wg * rpw + rl;
-          if (n < V) top2_insert(tp, s_logit[tid][rl], n);
+      if (wave < B) {
+        // record of sample `wave`: {max, sum exp(x - max), top-1 value, top-1 id, top-2 value, top-2 id}; lane = row
+        const int n = wg * rpw + lane;
+        const bool valid = lane < rpw && n < V;
+        const float x = valid ? s_logit[wave][lane] : -INFINITY;
+        Top2 tp = {x, valid ? n : 0x7fffffff, -INFINITY, 0x7fffffff};
+        tp = top2_wave(tp);
+        const float se = wave_sum(valid ? expf(x - tp.v1) : 0.f);
+        if (lane == 0) {
+          const f32x4 a = {tp.v1, se, tp.v1, __int_as_float(tp.i1)};
+          const f32x4 c = {tp.v2, __int_as_float(tp.i2), 0.f, 0.f};
+          const unsigned off = (unsigned)((wave * PD_G + wg) * PD_STAT) * 4;
+          st_agent_x4(rs_stats, off, a);
+          st_agent_x4(rs_stats, off + 16, c);
         }
-        float se = 0.f;
-        for (int rl = 0; rl < rpw; ++rl)
-          if (wg * rpw + rl < V) se += expf(s_logit[tid][rl] - tp.v1);
-        const f32x4 a = {tp.v1, se, tp.v1, __int_as_float(tp.i1)};
-        const f32x4 c = {tp.v2, __int_as_float(tp.i2), 0.f, 0.f};
-        const unsigned off = (unsigned)((tid * PD_G + wg) * PD_STAT) * 4;
-        st_agent_x4(rs_stats, off, a);
-        st_agent_x4(rs_stats, off + 16, c);
       }
     }
     grid_barrier_tree(p.sync, round++, PD_G, dead);
+    PD_STAMP();
 
     // ============================================================ P7: token rule + next input (no barrier needed)
     if (wave < B) {
@@ -499,7 +592,9 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
       }
     }
     __syncthreads();
+    PD_STAMP();
   }
+#undef PD_STAMP
 
   // a barrier that timed out anywhere invalidates the results: report it and poison the token ids
   if (wg == 0 && tid == 0) {

@@ -206,6 +206,11 @@ def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None):
     a.prof = prof.h if prof is not None else None
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     a.status = ptr(status)
+    trace = None
+    if os.environ.get('GVD_PD_TRACE'):        # profiling aid: phase time stamps of the persistent kernel
+        trace = torch.zeros(1 + 7 * L, dtype=torch.int64, device=dev)
+        a.trace = ptr(trace)
+    greedy_decode.last_trace = trace
     check(lib().gvd_greedy_decode(C.byref(a), stream_ptr()), 'gvd_greedy_decode')
     greedy_decode.last_status = status      # 1 after a device sync = the persistent decode kernel timed out (ids are -1)
     return seq, lps, att2

@@ -262,6 +262,8 @@ typedef struct {
   gvd_prof* prof;      /* optional: times the attention streaming kernel of every step (multi-kernel loop only) */
   int* status;         /* optional device int: set to 0, or to 1 when a grid barrier of the persistent decode-batch
                           kernel timed out (token ids are then all -1) */
+  uint64_t* trace;     /* optional device buffer of 1 + 7*L words: 100 MHz wall-clock stamps of workgroup 0 at every
+                          phase boundary of the persistent decode-batch kernel (profiling aid) */
 } gvd_greedy_args;
 
 size_t gvd_greedy_workspace_bytes(int B, int Ft, int R, int H, int A, int E, int V);

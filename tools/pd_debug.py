@@ -30,3 +30,16 @@ print('seq equal', torch.equal(a[0], b[0]))
 print(a[0][:, :10]); print(b[0][:, :10])
 print('lp maxdiff', (a[1] - b[1]).abs().max().item())
 print('att2 maxdiff', (a[2] - b[2]).abs().max().item(), 'first step', (a[2][:, 0] - b[2][:, 0]).abs().max().item())
+# phase timing of the persistent kernel (workgroup 0 stamps, 100 MHz clock)
+os.environ['GVD_PERSISTENT'] = '1'; os.environ['GVD_PD_TRACE'] = '1'
+with torch.no_grad():
+    model._sample(*args); torch.cuda.synchronize()
+tr = ops.greedy_decode.last_trace.cpu().numpy().astype('float64')
+L = opt.seq_length
+d = (tr[1:] - tr[:-1]).reshape(L, 7) * 0.01      # us
+names = ['P1 att-lstm', 'P2 queries', 'P3 attention', 'P4 combine', 'P5 lang-lstm', 'P6 logits', 'P7 token']
+print('per-phase us (median over steps, incl. the closing barrier):')
+import numpy as np
+for i, n in enumerate(names):
+    print('  %-14s %.2f' % (n, np.median(d[:, i])))
+print('  step total %.2f us;  loop total %.1f us' % (np.median(d.sum(1)), (tr[-1] - tr[0]) * 0.01))

@@ -9,7 +9,8 @@
 // which is what makes the reference-default Ft=480 configuration latency-bound.
 //
 // Decomposition (MI355X): workgroup = (direction, slice of HU=8 hidden units) -> 2*64 = 128 workgroups, one per
-// CU, all co-resident (cooperative launch).  The workgroup's 3*HU = 24 rows of W_hh are loaded ONCE and stay in
+// CU, all co-resident (cooperative launch); batches of more than 32 rows use two such groups (256 CUs), each taking
+// half of the 32-row batch tiles.  The workgroup's 3*HU = 24 rows of W_hh are loaded ONCE and stay in
 // registers for the whole sequence: wave w owns K-quarter [128w, 128w+128), lane (col = l&31, half = l>>5) holds
 // the 64 values it feeds to the 32x32x2 fp32 MFMA as the B operand.  Per step every wave multiplies all 32-row
 // batch tiles of h_{t-1} (read straight from the layer output tensor, the only state) with its K-quarter,
@@ -47,10 +48,16 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
   __shared__ float s_part[4][32][33];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, half = lane >> 5;
-  const int dir = blockIdx.x / GRU_NW;
-  const int j0 = (blockIdx.x % GRU_NW) * GRU_HU;
+  // grid = nparts x (2 directions x 64 unit slices): with more than one 32-row batch tile the batch tiles are dealt
+  // to nparts = 2 groups of 128 workgroups, so all 256 CUs work and the per-step tile loop is half as long
+  const int lid = blockIdx.x % (2 * GRU_NW), part = blockIdx.x / (2 * GRU_NW), nparts = gridDim.x / (2 * GRU_NW);
+  const int dir = lid / GRU_NW;
+  const int j0 = (lid % GRU_NW) * GRU_HU;
   const int B = p.B, T = p.T;
-  const int ntiles = (B + 31) / 32;
+  const int nt_all = (B + 31) / 32;
+  const int nt_per = (nt_all + nparts - 1) / nparts;
+  const int tile0 = part * nt_per;
+  const int ntiles = max(0, min(nt_per, nt_all - tile0));
   const int64_t ld_out = (int64_t)T * 2 * GRU_HH;     // batch stride of out
   const int64_t ld_gi = (int64_t)T * 6 * GRU_HH;
   const unsigned nwg = gridDim.x;
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int idx = tid + i * 256;
-        const int b = mt * 32 + (idx >> 7);
+        const int b = (tile0 + mt) * 32 + (idx >> 7);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (b < B) v = ld_agent_x4(out_rs, (unsigned)(((int64_t)b * ld_out + off_tp + (idx & 127) * 4) * 4));
         ra[i] = v;
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
     // behind the MFMA phase of the current tile
     float cur_r = 0.f, cur_z = 0.f, cur_n = 0.f, cur_h = 0.f, nxt_r = 0.f, nxt_z = 0.f, nxt_n = 0.f, nxt_h = 0.f;
     auto load_gate_inputs = [&](int mt, float& r_, float& z_, float& n_, float& h_) {
-      const int b = mt * 32 + g_row;
+      const int b = (tile0 + mt) * 32 + g_row;
       r_ = z_ = n_ = h_ = 0.f;
       if (b < B) {
         const float* gip = p.gi + (int64_t)b * ld_gi + (int64_t)t * 6 * GRU_HH + dir * 3 * GRU_HH + j0 + g_jj;
@@ -116,8 +123,10 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
         if (step > 0) h_ = ld_agent_f32(out_rs, (unsigned)(((int64_t)b * ld_out + off_tp + j0 + g_jj) * 4));
       }
     };
-    load_gate_inputs(0, cur_r, cur_z, cur_n, cur_h);
-    if (step > 0) load_tile(0);
+    if (ntiles > 0) {
+      load_gate_inputs(0, cur_r, cur_z, cur_n, cur_h);
+      if (step > 0) load_tile(0);
+    }
 
     // per batch tile: stage h_{t-1} through LDS, gh partials on the MFMA (lane supplies A[i = col][k = 128*wave +
     // 8*kb + 4*half + s]), K-quarter partials summed through LDS, gate math, write h_t
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
       }
       if (mt + 1 < ntiles) load_gate_inputs(mt + 1, nxt_r, nxt_z, nxt_n, nxt_h);
       __syncthreads();
-      const int b = mt * 32 + g_row;
+      const int b = (tile0 + mt) * 32 + g_row;
       if (b < B) {
         float gr = bh_r, gz = bh_z, gn = bh_n;
         if (step > 0) {
@@ -178,6 +187,16 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
   }
 }
 
+int gru_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n;
+  }();
+  return cus;
+}
+
 }  // namespace
 
 extern "C" int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const float* b_hh_fw, const float* w_hh_bw,
@@ -202,7 +221,12 @@ extern "C" int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const 
     // cooperative launch in both modes: it validates that all 128 workgroups are co-resident
     const void* fn = sync_ws ? reinterpret_cast<const void*>(gru_layer_kernel<false>)
                              : reinterpret_cast<const void*>(gru_layer_kernel<true>);
-    hipError_t e = hipLaunchCooperativeKernel(fn, dim3(2 * GRU_NW), dim3(256), args, 0, st);
+    const int nparts = (nb > 32 && gru_cus() >= 4 * GRU_NW) ? 2 : 1;
+    hipError_t e = hipLaunchCooperativeKernel(fn, dim3(nparts * 2 * GRU_NW), dim3(256), args, 0, st);
+    if (e != hipSuccess && nparts == 2) {   // 256 workgroups not co-resident here: one group of 128
+      (void)hipGetLastError();
+      e = hipLaunchCooperativeKernel(fn, dim3(2 * GRU_NW), dim3(256), args, 0, st);
+    }
     if (e != hipSuccess) return (int)e;
   }
   return 0;

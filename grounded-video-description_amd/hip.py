@@ -111,6 +111,7 @@ _SIG = {
                                       c_f32p, c_i64p, C.c_void_p]),
     'gvd_greedy_workspace_bytes': (C.c_size_t, [C.c_int] * 7),
     'gvd_greedy_decode': (C.c_int, [C.POINTER(GreedyArgs), C.c_void_p]),
+    'gvd_zero_masked_rows': (C.c_int, [c_f32p, C.c_int64, C.c_int, c_u8p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     'gvd_iou_targets': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_u8p, c_u8p, C.c_int, C.c_int, C.c_int,
                                   c_f32p, c_i64p, C.c_void_p]),
     'gvd_step_targets': (C.c_int, [c_f32p, c_u8p, c_u8p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

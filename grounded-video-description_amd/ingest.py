@@ -1,0 +1,206 @@
+"""Feature ingest for inference: from the reference's on-disk feature layout to the six
+tensors `model(..., 'sample')` receives, as a per-rank pinned-memory H2D pipeline.
+
+Contract reproduced (dataloader_anet.py:175-212,317-354 + default collate + main.py:339-347):
+  <feature_root>/<seg_id>.npy            f32 [T, P, 2048]   fc6 region features  -> ppls_feat [B, Rb, 2048]
+  <seg_feature_root>/<vid[2:]>_resnet.npy f32 [F, 2048]  +  _bn.npy f32 [F, 1024] -> segs_feat [B, Ft, 3072]
+  proposals [n, 7] (x1,y1,x2,y2,frame,cls,score; the reference reads them from an h5 file) -> ppls [B, Rb, 7]
+  pnt_mask u8 [B, Rb+1] = [0 | score <= prop_thresh (| cls == 0) | 1 beyond n], masked rows of ppls / ppls_feat zeroed,
+  Rb = max(1, max_b n_b) (main.py:339-341), frames beyond F zero, sample_idx = clip(round(F * t / dur), 0, Ft),
+  num i64 [B,7] = LongTensor copy of [1, n, 0, seg_idx, n_seg, t0/dur, t1/dur].
+
+Split of work (MI355X-first): host threads only copy the VALID raw rows of the (memory-mapped) files into pinned
+staging and make the byte masks; one async H2D per tensor slice on a copy stream; the zero padding / masked-row
+zeroing — three full passes over 8 MB per sample on the CPU in the reference — happens on the GPU in place
+(`gvd_zero_masked_rows`, touches only the rows it clears).  Staging is double-buffered so batch i+1 is read and copied
+while batch i is being decoded.  All compute is in the HIP library: there is no CPU fallback for the device half.
+"""
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def _npy_open(path):
+    """Open a .npy file and parse its header: (file positioned at the data, shape).  float32, C order only — the
+    layout the reference's feature extractors write."""
+    f = open(path, 'rb', buffering=0)
+    version = np.lib.format.read_magic(f)
+    shape, fortran, dtype = (np.lib.format.read_array_header_1_0(f) if version == (1, 0)
+                             else np.lib.format.read_array_header_2_0(f))
+    if fortran or dtype != np.float32:
+        f.close()
+        raise ValueError('%s: expected a C-ordered float32 array, got %s%s' % (path, dtype, ' (F order)' if fortran else ''))
+    return f, shape
+
+
+def _read_rows_into(path, dst, max_rows):
+    """read() the first min(rows, max_rows) rows of a [..., D] float32 .npy straight into `dst` (a C-contiguous
+    [>= rows, D] float32 view of the pinned staging buffer): one kernel copy from the page cache, no mmap page faults,
+    no intermediate array, GIL released.  Returns (rows_read, rows_in_file)."""
+    f, shape = _npy_open(path)
+    try:
+        D = shape[-1]
+        rows_file = int(np.prod(shape[:-1]))
+        rows = min(rows_file, max_rows)
+        assert dst.shape[1] == D and dst.flags['C_CONTIGUOUS']
+        if rows:
+            want = rows * D * 4
+            got = f.readinto(memoryview(dst[:rows]).cast('B'))
+            if got != want:
+                raise IOError('%s: short read (%d of %d bytes)' % (path, got, want))
+        return rows, rows_file
+    finally:
+        f.close()
+
+
+class _Slot:
+    """One set of pinned staging buffers (sized for the largest batch)."""
+
+    def __init__(self, max_batch, R, Ft, att_feat, fc_feat, pin):
+        def buf(*shape, dtype=torch.float32):
+            t = torch.empty(*shape, dtype=dtype)
+            return t.pin_memory() if pin else t
+        self.feat = buf(max_batch, R, att_feat)
+        self.segs = buf(max_batch, Ft, fc_feat)
+        self.ppls = buf(max_batch, R, 7)
+        self.mask = buf(max_batch, R + 1, dtype=torch.uint8)
+        self.fmask = buf(max_batch, Ft, dtype=torch.uint8)
+        self.num = buf(max_batch, 7, dtype=torch.int64)
+        self.sidx = buf(max_batch, 2, dtype=torch.int64)
+        self.n_pps = [0] * max_batch
+        self.n_frm = [0] * max_batch
+        self.B = 0
+        self.free = None            # event: the previous upload from this slot has finished reading it
+
+
+class InferenceIngest:
+    """records: dicts with seg_id '<vid>_segment_<k>', n_seg_in_vid, timestamps (t0, t1), duration, proposals [n,7]."""
+
+    def __init__(self, opt, feature_root, seg_feature_root, device=None, max_batch=256, exclude_bgd_det=False,
+                 workers=8, depth=2):
+        self.opt = opt
+        self.feature_root, self.seg_feature_root = feature_root, seg_feature_root
+        self.device = device
+        self.exclude_bgd_det = exclude_bgd_det
+        self.R = opt.num_sampled_frm * opt.num_prop_per_frm          # max_proposal, dataloader_anet.py:45
+        self.Ft = opt.t_attn_size
+        pin = device is not None
+        self.slots = [_Slot(max_batch, self.R, self.Ft, opt.att_feat_size, opt.fc_feat_size, pin) for _ in range(depth)]
+        self.max_batch = max_batch
+        self.pool = ThreadPoolExecutor(max_workers=workers)
+        self.copy_stream = torch.cuda.Stream(device=device) if device is not None else None
+        self._next = 0
+        self._tls = threading.local()
+
+    # ------------------------------------------------------------------ host half
+    def _stage_one(self, slot, b, rec):
+        opt = self.opt
+        seg_id = rec['seg_id']
+        vid, seg_idx = seg_id.split('_segment_')
+        props = np.asarray(rec['proposals'], dtype=np.float64)
+        n = props.shape[0]
+        n_pps, rows_file = _read_rows_into(os.path.join(self.feature_root, seg_id + '.npy'), slot.feat[b].numpy(), self.R)
+        assert n == rows_file, 'proposal count does not match the region feature file'          # l.191
+        masked = props[:, 6] <= opt.prop_thresh                                                   # l.194-196
+        if self.exclude_bgd_det:
+            masked |= props[:, 5] == 0
+        slot.ppls[b, :n_pps] = torch.from_numpy(props[:n_pps]).float()
+        m = slot.mask[b].numpy()
+        m[0] = 0                                                          # legacy pad column, main.py:345
+        m[1:1 + n_pps] = masked[:n_pps]
+        m[1 + n_pps:] = 1
+        # frame features: the two files are column blocks of one row, so they go through small contiguous scratch
+        if not hasattr(self._tls, 'rgb'):           # per-thread scratch
+            self._tls.rgb = np.empty((self.Ft, 2048), dtype=np.float32)
+            self._tls.motion = np.empty((self.Ft, opt.fc_feat_size - 2048), dtype=np.float32)
+        d_rgb, d_mot = self._tls.rgb, self._tls.motion
+        n_frm, num_frm = _read_rows_into(os.path.join(self.seg_feature_root, vid[2:] + '_resnet.npy'), d_rgb, self.Ft)
+        _read_rows_into(os.path.join(self.seg_feature_root, vid[2:] + '_bn.npy'), d_mot, self.Ft)
+        seg = slot.segs[b].numpy()
+        np.copyto(seg[:n_frm, :d_rgb.shape[1]], d_rgb[:n_frm])
+        np.copyto(seg[:n_frm, d_rgb.shape[1]:], d_mot[:n_frm])
+        fm = slot.fmask[b].numpy()
+        fm[:n_frm] = 0
+        fm[n_frm:] = 1
+        t0, t1 = rec['timestamps']
+        dur = rec['duration']
+        sidx = np.array([np.round(num_frm * t0 * 1. / dur), np.round(num_frm * t1 * 1. / dur)])   # l.207-208
+        slot.sidx[b] = torch.from_numpy(np.clip(np.round(sidx), 0, self.Ft).astype(np.int64))
+        # main.py copies the FloatTensor `num` into a LongTensor: the two time stamps truncate
+        numf = torch.FloatTensor([1, n_pps, 0, int(seg_idx), rec['n_seg_in_vid'], t0 * 1. / dur, t1 * 1. / dur])
+        slot.num[b] = numf.long()
+        slot.n_pps[b], slot.n_frm[b] = n_pps, n_frm
+
+    def stage(self, records):
+        """Fill the next staging slot from the feature files (thread pool, one task per segment)."""
+        assert 0 < len(records) <= self.max_batch
+        slot = self.slots[self._next]
+        self._next = (self._next + 1) % len(self.slots)
+        if slot.free is not None:
+            slot.free.synchronize()                 # its previous upload still reads the pinned buffers
+            slot.free = None
+        slot.B = len(records)
+        list(self.pool.map(lambda br: self._stage_one(slot, br[0], br[1]), enumerate(records)))
+        return slot
+
+    # ------------------------------------------------------------------ device half
+    def upload(self, slot):
+        """Async H2D of the valid rows + in-place zero fill on the copy stream.  Returns the dict of device tensors;
+        the calling stream is made to wait for the upload."""
+        if self.device is None:
+            raise RuntimeError('InferenceIngest.upload needs a GPU (the padding/masking half runs in the HIP library)')
+        B, dev = slot.B, self.device
+        Rb = max(max(slot.n_pps[:B]), 1)                                   # main.py:339-341
+        cur = torch.cuda.current_stream(dev)
+        feat = torch.empty(B, Rb, self.opt.att_feat_size, device=dev)
+        segs = torch.empty(B, self.Ft, self.opt.fc_feat_size, device=dev)
+        ppls = torch.empty(B, Rb, 7, device=dev)
+        mask = torch.empty(B, Rb + 1, dtype=torch.uint8, device=dev)
+        fmask = torch.empty(B, self.Ft, dtype=torch.uint8, device=dev)
+        num = torch.empty(B, 7, dtype=torch.int64, device=dev)
+        sidx = torch.empty(B, 2, dtype=torch.int64, device=dev)
+        cs = self.copy_stream
+        cs.wait_stream(cur)                        # the allocator may hand out blocks earlier kernels still use
+        with torch.cuda.stream(cs):
+            mask.copy_(slot.mask[:B, :Rb + 1], non_blocking=True)
+            fmask.copy_(slot.fmask[:B], non_blocking=True)
+            num.copy_(slot.num[:B], non_blocking=True)
+            sidx.copy_(slot.sidx[:B], non_blocking=True)
+            for b in range(B):                     # valid rows only: contiguous chunks of the pinned buffers
+                n, f = slot.n_pps[b], slot.n_frm[b]
+                if n:
+                    feat[b, :n].copy_(slot.feat[b, :n], non_blocking=True)
+                    ppls[b, :n].copy_(slot.ppls[b, :n], non_blocking=True)
+                if f:
+                    segs[b, :f].copy_(slot.segs[b, :f], non_blocking=True)
+            ops.zero_masked_rows(feat, mask, mask_off=1)
+            ops.zero_masked_rows(ppls, mask, mask_off=1)
+            ops.zero_masked_rows(segs, fmask)
+            slot.free = torch.cuda.Event()
+            slot.free.record(cs)
+        cur.wait_stream(cs)
+        return dict(segs_feat=segs, num=num, ppls=ppls, ppls_feat=feat, sample_idx=sidx, pnt_mask=mask)
+
+    def batches(self, records, batch_size):
+        """Yield (records_of_batch, tensors) with the files of batch i+1 being read while batch i is consumed."""
+        chunks = [records[i:i + batch_size] for i in range(0, len(records), batch_size)]
+        if not chunks:
+            return
+        pending = self.pool_stage(chunks[0])
+        for i, ch in enumerate(chunks):
+            slot = pending.result()
+            tensors = self.upload(slot)
+            if i + 1 < len(chunks):
+                pending = self.pool_stage(chunks[i + 1])
+            yield ch, tensors
+
+    def pool_stage(self, records):
+        # staging itself fans out over self.pool; a one-thread outer executor keeps the order of the slots
+        if not hasattr(self, '_outer'):
+            self._outer = ThreadPoolExecutor(max_workers=1)
+        return self._outer.submit(self.stage, records)

@@ -461,6 +461,17 @@ def gru_bidir_2layer(x, gru, barrier=None):
     return inp
 
 
+def zero_masked_rows(x, mask, mask_off=0):
+    """In place: zero every row x[b, r, :] whose byte mask[b, mask_off + r] is set (gvd_zero_masked_rows)."""
+    require_cuda_f32(x)
+    assert x.is_contiguous() and x.dim() == 3 and mask.dtype == torch.uint8 and mask.is_contiguous() and mask.is_cuda
+    B, N, D = x.shape
+    assert mask.shape[0] == B and mask.shape[1] >= N + mask_off
+    check(lib().gvd_zero_masked_rows(ptr(x), B * N, D, ptr(mask), N, mask.shape[1], mask_off, stream_ptr()),
+          'gvd_zero_masked_rows')
+    return x
+
+
 def sync_timed_out(sync):
     """True when any barrier object in `sync` (gvd_grid_sync_words() words each) raised its timeout word."""
     return int(sync.view(-1, lib().gvd_grid_sync_words())[:, 32].sum()) != 0

@@ -270,6 +270,16 @@ size_t gvd_greedy_workspace_bytes(int B, int Ft, int R, int H, int A, int E, int
 int gvd_greedy_decode(const gvd_greedy_args* args, gvd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Feature ingest (dataloader_anet.py:317-344: zero-padded proposal / feature rows, masked rows zeroed)
+ * ------------------------------------------------------------------------------------------- */
+
+/* In place: x[row,:] = 0 for every row whose mask byte is non-zero.  x f32 [rows, D] with rows = batch * rows_per_batch;
+ * the mask byte of row (b, r) is mask[b*mask_ld + mask_off + r] (so the model's pnt_mask [B,R+1] with its legacy pad
+ * column is passed with mask_ld = R+1, mask_off = 1).  Rows that are kept are not touched. */
+int gvd_zero_masked_rows(float* x, int64_t rows, int D, const uint8_t* mask, int64_t rows_per_batch, int64_t mask_ld,
+                         int64_t mask_off, gvd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Training targets and losses
  * ------------------------------------------------------------------------------------------- */
 

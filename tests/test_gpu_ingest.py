@@ -1,0 +1,63 @@
+"""-m gpu: the whole ingest pipeline (pinned staging -> async H2D of the valid rows -> gvd_zero_masked_rows) delivers
+byte-for-byte the tensors the restated reference dataloader + main.py hand to the model, and the model decodes them."""
+import pytest
+import torch
+
+import gvd_amd
+from gvd_amd import att_model, ingest, ops, synth
+from oracle import ingest_oracle as IO
+
+pytestmark = pytest.mark.gpu
+KEYS = ('segs_feat', 'num', 'ppls', 'ppls_feat', 'sample_idx', 'pnt_mask')
+
+
+def test_zero_masked_rows_kernel():
+    g = torch.Generator().manual_seed(0)
+    for B, N, D, off in ((3, 17, 2048, 1), (2, 5, 7, 1), (4, 9, 3072, 0), (1, 1, 5, 0)):
+        x = torch.randn(B, N, D, generator=g)
+        mask = (torch.rand(B, N + off, generator=g) < 0.4).to(torch.uint8)
+        want = x.masked_fill(mask[:, off:off + N].bool().unsqueeze(-1), 0.)
+        got = ops.zero_masked_rows(x.cuda().contiguous(), mask.cuda(), mask_off=off).cpu()
+        assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize('Ft', [480, 10])
+def test_pipeline_equals_reference_dataloader(tmp_path, Ft):
+    opt = gvd_amd.opts.default_opt(t_attn_size=Ft, vocab_size=600)
+    fr, sr, recs = IO.write_synthetic_dataset(str(tmp_path), opt, seed=7)
+    ing = ingest.InferenceIngest(opt, fr, sr, device=torch.device('cuda', 0), max_batch=4, workers=4)
+    seen = 0
+    for _ in range(2):                                   # second pass re-uses the staging slots
+        for chunk, t in ing.batches(recs, 4):
+            want = IO.assemble_batch(chunk, fr, sr, opt)
+            torch.cuda.synchronize()
+            for k in KEYS:
+                assert t[k].dtype == want[k].dtype and tuple(t[k].shape) == tuple(want[k].shape), k
+                assert torch.equal(t[k].cpu(), want[k]), k
+            seen += len(chunk)
+    assert seen == 2 * len(recs)
+    # a batch made only of the short sample is trimmed to its proposal count (main.py:339-341)
+    short = [r for r in recs if r['proposals'].shape[0] < opt.num_sampled_frm * opt.num_prop_per_frm]
+    assert short
+    t = ing.upload(ing.stage(short[:1]))
+    want = IO.assemble_batch(short[:1], fr, sr, opt)
+    assert t['ppls_feat'].shape[1] == short[0]['proposals'].shape[0]
+    for k in KEYS:
+        assert torch.equal(t[k].cpu(), want[k]), k
+
+
+def test_ingested_batch_decodes_like_the_oracle_batch(tmp_path):
+    opt = gvd_amd.opts.default_opt(t_attn_size=12, vocab_size=600)
+    fr, sr, recs = IO.write_synthetic_dataset(str(tmp_path), opt, seed=9, short_props=False)
+    sd = synth.init_state_dict(opt, seed=1, profile='trained_like')
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    ing = ingest.InferenceIngest(opt, fr, sr, device=torch.device('cuda', 0), max_batch=3)
+    chunk, t = next(iter(ing.batches(recs[:3], 3)))
+    want = IO.assemble_batch(chunk, fr, sr, opt)
+    order = ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')
+    with torch.no_grad():
+        a = model._sample(*[t[k] for k in order])
+        b = model._sample(*[want[k].cuda() for k in order])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])

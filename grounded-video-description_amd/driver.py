@@ -7,6 +7,7 @@ model's inputs and outputs, without the dataset / metric submodules that are out
   save_checkpoint / load_checkpoint   main.py:622-652, 702-743   model.pth / model-best.pth + infos_<id>.pkl +
                          histories_<id>.pkl, interchangeable with the reference (same state_dict keys and shapes)
   train_epoch            main.py:197-311   loss bookkeeping around Trainer.step
+  eval_split             main.py:313-452   inference loop over the feature-ingest pipeline + the two result JSON files
 """
 import os
 import pickle
@@ -130,3 +131,36 @@ def train_epoch(trainer, batches, opt, log=None):
         if log is not None and step % max(getattr(opt, 'disp_interval', 100), 1) == 0:
             log('step %d: train_loss %.4f (lm %.4f att2 %.4f grd %.4f cls %.4f)' % ((step,) + tuple((sums / n).tolist())))
     return (sums / max(n, 1)).tolist()
+
+
+def eval_split(model, ingest_pipeline, records, batch_size, itow, opt, eval_opt=None, timestamps=None, wtol=None,
+               lemma_det_dict=None, itod=None, out_dir=None, val_split='validation'):
+    """Inference half of main.eval (main.py:313-452) over the ingest pipeline: for every batch of segment records
+    `model(..., 'sample', eval_opt)` -> sentences (+ per-word grounding boxes when `lemma_det_dict` is given), collected
+    into the `predictions` / `grd_output` dictionaries and, with `out_dir`, written as the two JSON files main.py hands
+    to its (out-of-scope) evaluators: densecap-<split>-<id>.json (main.py:418-424) and
+    attn-gen-sent-results-<split>-<id>.json (main.py:446-449)."""
+    import json
+    eval_opt = eval_opt or {'sample_max': 1, 'beam_size': getattr(opt, 'beam_size', 1), 'inference_mode': True}
+    predictions, grd_output = defaultdict(list), defaultdict(dict)
+    grounding = lemma_det_dict is not None
+    model.eval()
+    with torch.no_grad():
+        for chunk, t in ingest_pipeline.batches(records, batch_size):
+            dummy = t['ppls'].new_zeros(t['ppls'].shape[0]).byte()                     # main.py:353
+            seq, att2_weights, sim_mat = model(t['segs_feat'], dummy, dummy, t['num'], t['ppls'], dummy, dummy,
+                                               t['ppls_feat'], dummy, t['sample_idx'], t['pnt_mask'], 'sample', eval_opt)
+            collect_predictions(seq, [r['seg_id'] for r in chunk], itow, timestamps=timestamps,
+                                att2_weights=att2_weights if grounding else None, ppls=t['ppls'], opt=opt, wtol=wtol,
+                                lemma_det_dict=lemma_det_dict, itod=itod, predictions=predictions, grd_output=grd_output)
+    if out_dir is not None:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, 'densecap-%s-%s.json' % (val_split, opt.id)), 'w') as f:
+            json.dump({'version': 'VERSION 1.0', 'results': predictions,
+                       'external_data': {'used': 'true', 'details': 'Visual Genome for Faster R-CNN pre-training'}}, f)
+        if grounding:
+            with open(os.path.join(out_dir, 'attn-gen-sent-results-%s-%s.json' % (val_split, opt.id)), 'w') as f:
+                json.dump({'results': grd_output, 'eval_mode': 'gen',
+                           'external_data': {'used': True, 'details': 'Object detector pre-trained on Visual Genome on '
+                                                                      'object detection task.'}}, f)
+    return predictions, grd_output

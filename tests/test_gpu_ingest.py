@@ -61,3 +61,51 @@ def test_ingested_batch_decodes_like_the_oracle_batch(tmp_path):
         a = model._sample(*[t[k] for k in order])
         b = model._sample(*[want[k].cuda() for k in order])
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+
+
+def test_eval_split_writes_the_reference_result_files(tmp_path):
+    """driver.eval_split = the inference loop of main.eval (main.py:313-452) over the ingest pipeline: sentences per
+    video in segment order, grounding boxes for words with a detection lemma, the two JSON files."""
+    import json
+    from gvd_amd import driver
+    opt = gvd_amd.opts.default_opt(t_attn_size=12, vocab_size=600)
+    opt.id = 'unit'
+    fr, sr, recs = IO.write_synthetic_dataset(str(tmp_path / 'feats'), opt, seed=4, short_props=False)
+    sd = synth.init_state_dict(opt, seed=2, profile='trained_like')
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    itow = {str(i): 'w%d' % i for i in range(opt.vocab_size)}
+    wtol = {w: w for w in itow.values()}
+    lemma_det = {'w%d' % i: i % 7 + 1 for i in range(1, opt.vocab_size, 3)}
+    itod = {i: 'cls%d' % i for i in range(1, 9)}
+    ing = ingest.InferenceIngest(opt, fr, sr, device=torch.device('cuda', 0), max_batch=4)
+    pred, grd = driver.eval_split(model, ing, recs, 4, itow, opt, wtol=wtol, lemma_det_dict=lemma_det, itod=itod,
+                                  out_dir=str(tmp_path / 'out'))
+    assert sum(len(v) for v in pred.values()) == len(recs)
+    with open(tmp_path / 'out' / 'densecap-validation-unit.json') as f:
+        dc = json.load(f)
+    assert dc['version'] == 'VERSION 1.0' and set(dc['results']) == set(pred)
+    with open(tmp_path / 'out' / 'attn-gen-sent-results-validation-unit.json') as f:
+        ag = json.load(f)
+    assert ag['eval_mode'] == 'gen'
+    # the same sentences as decoding the oracle-assembled batch directly
+    want = IO.assemble_batch(recs[:4], fr, sr, opt)
+    order = ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')
+    with torch.no_grad():
+        seq = model._sample(*[want[k].cuda() for k in order])[0]
+    sents = driver.decode_sequence(itow, seq.cpu())
+    got = []
+    for r in recs[:4]:
+        vid, k = r['seg_id'].split('_segment_')
+        got.append((vid, int(k)))
+    flat = {}
+    for vid, entries in pred.items():
+        for j, e in enumerate(entries):
+            flat[(vid, j)] = e['sentence']
+    assert [flat[g] for g in got] == sents
+    for vid in grd:
+        for seg, d in grd[vid].items():
+            assert len(d['clss']) == len(d['idx_in_sent']) == len(d['bbox_for_all_frames'])
+            for boxes in d['bbox_for_all_frames']:
+                assert len(boxes) == opt.num_sampled_frm and len(boxes[0]) == 4

@@ -156,6 +156,117 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   *reinterpret_cast<f32x4*>(p.part_ctx + ((int64_t)b * p.nctot + cglob) * ATT_H + 4 * tid) = acc;
 }
 
+// Beam-search variant: ONE workgroup serves the G beam rows of a sample (rows b*G .. b*G+G-1 share its features).
+// Every p_feats / feats row of the chunk is loaded once and used for all G queries: G score accumulations per
+// projection row, G context accumulators per feature row, so the HBM stream is the sample's bytes, not G x them
+// ("shared across beams in a batched redesign").  Partials are written per beam row in the layout
+// attn_combine_kernel expects.  grid = (chunks, samples).
+template <int G>
+__global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams p) {
+  __shared__ float s_score[G][MAX_CHUNK];
+  __shared__ float s_m[G];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int smp = blockIdx.y;                    // sample; its beam rows are smp*G + g
+  int c = blockIdx.x;
+  const int sidx = (p.nside > 1 && c >= p.side[0].nchunks) ? 1 : 0;
+  const SideDev& S = p.side[sidx];
+  const int cglob = c;
+  if (sidx) c -= p.side[0].nchunks;
+  const int n0 = c * S.chunk;
+  const int rows = min(S.chunk, S.N - n0);
+
+  const f32x4 w0 = *reinterpret_cast<const f32x4*>(S.w + 4 * lane);
+  const f32x4 w1 = *reinterpret_cast<const f32x4*>(S.w + 256 + 4 * lane);
+  f32x4 q0[G], q1[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float* qb = S.q + (int64_t)(smp * G + g) * S.ldq;
+    q0[g] = *reinterpret_cast<const f32x4*>(qb + 4 * lane);
+    q1[g] = *reinterpret_cast<const f32x4*>(qb + 256 + 4 * lane);
+  }
+  const float ab = *S.alpha_bias;
+  const float* pf = S.p_feats + ((int64_t)smp * S.N + n0) * ATT_A;
+
+  // ---- phase 1: one projection row per wave per pass, G scores from it
+  for (int r = wave; r < rows; r += 4) {
+    const float* p0 = pf + (int64_t)r * ATT_A;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(p0 + 4 * lane);
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane);
+    float sc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a = fmaf(w0[k], tanhf(x0[k] + q0[g][k]), a);
+        a = fmaf(w1[k], tanhf(x1[k] + q1[g][k]), a);
+      }
+      sc[g] = wave_sum(a) + ab;
+    }
+    if (lane < G) {
+      float e = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) if (lane == g) e = sc[g];
+      const int64_t row = (int64_t)smp * G + lane;
+      const bool am = S.att_mask && S.att_mask[row * S.ld_att_mask + n0 + r];
+      if (am) e = GVD_MIN_VALUE;
+      s_score[lane][r] = e;
+      if (S.scores_out) S.scores_out[row * S.ld_scores + n0 + r] = e;
+      if (S.logits_out) {
+        const bool pm = S.pnt_mask && S.pnt_mask[row * S.ld_pnt_mask + n0 + r];
+        S.logits_out[row * S.ld_logits + n0 + r] = pm ? GVD_MIN_VALUE : e;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- chunk-local softmax numerators: wave g handles beam g (G <= 8 -> two passes over the 4 waves)
+  for (int g = wave; g < G; g += 4) {
+    float m = lane < rows ? s_score[g][lane] : -INFINITY;     // rows <= 64
+    m = wave_max(m);
+    const float pr = lane < rows ? expf(s_score[g][lane] - m) : 0.f;
+    if (lane < rows) s_score[g][lane] = pr;
+    const float l = wave_sum(pr);
+    if (lane == 0) {
+      float* ml = p.part_ml + ((int64_t)(smp * G + g) * p.nctot + cglob) * 2;
+      ml[0] = m; ml[1] = l;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: G partial contexts from one pass over the chunk's feature rows; thread owns 4 columns of H = 1024
+  const float* fb = S.feats + ((int64_t)smp * S.N + n0) * ATT_H + 4 * tid;
+  f32x4 acc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int r = 0;
+  for (; r + 4 <= rows; r += 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(fb + (int64_t)(r + u) * ATT_H);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float pw = s_score[g][r + u];
+        acc[g][0] = fmaf(pw, v[u][0], acc[g][0]); acc[g][1] = fmaf(pw, v[u][1], acc[g][1]);
+        acc[g][2] = fmaf(pw, v[u][2], acc[g][2]); acc[g][3] = fmaf(pw, v[u][3], acc[g][3]);
+      }
+  }
+  for (; r < rows; ++r) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(fb + (int64_t)r * ATT_H);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float pw = s_score[g][r];
+      acc[g][0] = fmaf(pw, v[0], acc[g][0]); acc[g][1] = fmaf(pw, v[1], acc[g][1]);
+      acc[g][2] = fmaf(pw, v[2], acc[g][2]); acc[g][3] = fmaf(pw, v[3], acc[g][3]);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+    *reinterpret_cast<f32x4*>(p.part_ctx + ((int64_t)(smp * G + g) * p.nctot + cglob) * ATT_H + 4 * tid) = acc[g];
+}
+
 struct CombParams {
   const float* part_ctx; const float* part_ml;
   int nc[2]; int nside; int nctot;
@@ -299,7 +410,19 @@ extern "C" int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_sid
   p.part_ml = p.part_ctx + (int64_t)B * p.nctot * ATT_H;
   hipStream_t st = gvd_s(stream);
   gvd_prof_begin(prof, st);
-  if (tune_int("GVD_ATTN_NT", 0))
+  // beam search: both attentions share features within groups of G rows -> one workgroup per (chunk, sample)
+  const int G = region->group;
+  const bool grouped = G >= 2 && G <= 5 && B % G == 0 && (!temporal || temporal->group == G) &&
+                       tune_int("GVD_ATTN_GROUPED", 1);
+  if (grouped) {
+    const dim3 grid((unsigned)p.nctot, (unsigned)(B / G));
+    switch (G) {
+      case 2: hipLaunchKernelGGL(attn_partial_group_kernel<2>, grid, dim3(256), 0, st, p); break;
+      case 3: hipLaunchKernelGGL(attn_partial_group_kernel<3>, grid, dim3(256), 0, st, p); break;
+      case 4: hipLaunchKernelGGL(attn_partial_group_kernel<4>, grid, dim3(256), 0, st, p); break;
+      default: hipLaunchKernelGGL(attn_partial_group_kernel<5>, grid, dim3(256), 0, st, p); break;
+    }
+  } else if (tune_int("GVD_ATTN_NT", 0))
     hipLaunchKernelGGL(attn_partial_kernel<true>, dim3((unsigned)p.nctot, (unsigned)B), dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL(attn_partial_kernel<false>, dim3((unsigned)p.nctot, (unsigned)B), dim3(256), 0, st, p);

@@ -181,6 +181,43 @@ def test_masked_lsm_loss():
     assert abs(float(out) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
 
 
+@pytest.mark.parametrize('K,Bs,N,Ft', [(5, 3, 203, 10), (3, 2, 2000, 37), (2, 7, 100, 1), (4, 1, 64, 480)])
+def test_attention_beam_group_kernel_is_bitwise_the_row_kernel(K, Bs, N, Ft):
+    """Beam search: the K beam rows of a sample share its features.  The grouped kernel (one workgroup per chunk and
+    SAMPLE, features read once for K queries) must give bit-for-bit what the per-row kernel gives on the expanded rows."""
+    import os
+    g = _g(K * 100 + N)
+    A, H = 512, 1024
+    feats, p_feats = torch.randn(Bs, N, H, generator=g), torch.randn(Bs, N, A, generator=g)
+    tf, tp = torch.randn(Bs, Ft, H, generator=g), torch.randn(Bs, Ft, A, generator=g)
+    q = torch.randn(Bs * K, 2 * A, generator=g)
+    w2, w1 = torch.randn(1, A, generator=g) * 0.1, torch.randn(1, A, generator=g) * 0.1
+    b2, b1 = torch.randn(1, generator=g), torch.randn(1, generator=g)
+    mask = (torch.rand(Bs * K, N + 1, generator=g) < 0.2).to(torch.uint8)
+    mask[:, 0] = 0
+    outs = {}
+    for mode in ('1', '0'):
+        os.environ['GVD_ATTN_GROUPED'] = mode
+        lo = torch.zeros(Bs * K, N).cuda()
+        region = dict(feats=feats.cuda(), p_feats=p_feats.cuda(), q=q.cuda()[:, A:], w=w2.cuda(), alpha_bias=b2.cuda(),
+                      att_mask=mask.cuda()[:, 1:], pnt_mask=mask.cuda()[:, 1:], logits_out=lo, group=K)
+        temporal = dict(feats=tf.cuda(), p_feats=tp.cuda(), q=q.cuda()[:, :A], w=w1.cuda(), alpha_bias=b1.cuda(), group=K)
+        out, cr, ct = ops.attention_step(region, temporal, want_separate=True)
+        torch.cuda.synchronize()
+        outs[mode] = (out.cpu(), cr.cpu(), ct.cpu(), lo.cpu())
+    os.environ.pop('GVD_ATTN_GROUPED', None)
+    for a, b in zip(outs['1'], outs['0']):
+        assert torch.equal(a, b)
+    # and both equal the row kernel on explicitly expanded features (group = 0)
+    region = dict(feats=feats.repeat_interleave(K, 0).cuda(), p_feats=p_feats.repeat_interleave(K, 0).cuda(),
+                  q=q.cuda()[:, A:], w=w2.cuda(), alpha_bias=b2.cuda(), att_mask=mask.cuda()[:, 1:],
+                  pnt_mask=mask.cuda()[:, 1:])
+    temporal = dict(feats=tf.repeat_interleave(K, 0).cuda(), p_feats=tp.repeat_interleave(K, 0).cuda(), q=q.cuda()[:, :A],
+                    w=w1.cuda(), alpha_bias=b1.cuda())
+    ref = ops.attention_step(region, temporal)
+    np.testing.assert_allclose(outs['1'][0].numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize('barrier', ['counter', 'cg'])
 @pytest.mark.parametrize('B,T', [(3, 10), (2, 480), (40, 37), (70, 12), (257, 5)])
 def test_gru_persistent_kernel(B, T, barrier):

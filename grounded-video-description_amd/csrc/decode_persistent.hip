@@ -650,16 +650,17 @@ bool gvd_pd_eligible(int B, int H, int A, int E, int V, int R, int Ft) {
 }
 
 int gvd_pd_launch(PdParams p, void* workspace, hipStream_t st) {
-  // attention chunking: about 256 / B work items per sample, chunks of at most 64 rows
+  // attention chunking: about 256 / B work items per sample (one per workgroup), the same number of rows per item for
+  // the region and the temporal attention so no workgroup holds the phase up, chunks of at most 64 rows
   const int target = PD_G / p.B;
-  p.nch_t = (p.Ft + PD_MAXCH - 1) / PD_MAXCH;
-  p.chunk_t = (p.Ft + p.nch_t - 1) / p.nch_t;
-  int nr = target - p.nch_t;
-  if (nr < 1) nr = 1;
-  p.chunk_r = (p.R + nr - 1) / nr;
-  if (p.chunk_r > PD_MAXCH) p.chunk_r = PD_MAXCH;
-  if (p.chunk_r < 1) p.chunk_r = 1;
+  int chunk = (p.R + p.Ft + target - 1) / target;
+  if (chunk < 1) chunk = 1;
+  while (chunk < PD_MAXCH && (p.R + chunk - 1) / chunk + (p.Ft + chunk - 1) / chunk > target) ++chunk;
+  if (chunk > PD_MAXCH) chunk = PD_MAXCH;
+  p.chunk_r = chunk < p.R ? chunk : p.R;
+  p.chunk_t = chunk < p.Ft ? chunk : p.Ft;
   p.nch_r = (p.R + p.chunk_r - 1) / p.chunk_r;
+  p.nch_t = (p.Ft + p.chunk_t - 1) / p.chunk_t;
   const int nct = p.nch_r + p.nch_t;
   if (nct > PD_MAXNCT) return GVD_EINVAL;
   pd_carve(&p, workspace, nct);

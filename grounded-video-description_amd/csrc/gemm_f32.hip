@@ -295,7 +295,8 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
   }
   if (a->M <= 32) return launch<32, 128, 1, 4, false>(p, a->batch, st);
   const long big = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
-  if (big >= 256) {
+  static const long big_min = getenv("GVD_GEMM_BIG") ? atol(getenv("GVD_GEMM_BIG")) : 256;   // tuning knob
+  if (big >= big_min) {
     // default: single LDS buffer + register prefetch (36.9 KB -> 3 workgroups/CU): measured 126.6 vs 122.8 TF/s for
     // the double-buffered form on the fc7 shape (tools/gemm_micro.py); GVD_GEMM_VARIANT=0 selects the latter.
     // Tried and rejected: 64-deep K tiles (variant 2: no change, barriers are not the limit) and a 256x128 tile

@@ -218,3 +218,13 @@ def test_pipelined_sampler_equals_serial():
     for a, b, c in zip(serial, piped, piped2):
         for x, y, z in zip(a, b, c):
             assert torch.equal(x, y) and torch.equal(x, z)
+
+
+def test_persistent_kernels_repeatability_stress():
+    """tools/pd_stress.py: back-to-back and two-stream pipelined calls of the persistent decode / GRU kernels reproduce
+    their first result bit for bit and never hit a barrier timeout (18000 calls were run clean when it was written)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'pd_stress.py'), '120'], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and 'STRESS OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -16,45 +16,41 @@ import torch
 
 
 def load_segment(rec, feature_root, seg_feature_root, opt, exclude_bgd_det=False):
-    """dataloader_anet.py:175-212,317-354 for one segment -> dict of per-sample tensors (inference subset)."""
-    seg_id = rec['seg_id']
-    vid_id_ix, seg_id_ix = seg_id.split('_segment_')
-    seg_id_ix = str(int(seg_id_ix))
-    proposals = np.array(rec['proposals'], dtype=np.float64, copy=True)
-    num_proposal = proposals.shape[0]
-    region_feature = np.load(os.path.join(feature_root, seg_id + '.npy'))
-    region_feature = region_feature.reshape(-1, region_feature.shape[2]).copy()
-    assert num_proposal == region_feature.shape[0]
-    pnt_mask = proposals[:, 6] <= opt.prop_thresh                                     # l.194
+    """One segment's inference tensors the way dataloader_anet.py:175-212,317-354 builds them (float64 numpy padding
+    buffers, byte mask, masked rows zeroed after the float32 conversion)."""
+    vid, k = rec['seg_id'].split('_segment_')
+    k = int(k)
+    boxes = np.array(rec['proposals'], dtype=np.float64, copy=True)                    # [n,7]
+    fc6 = np.load(os.path.join(feature_root, rec['seg_id'] + '.npy'))
+    fc6 = fc6.reshape(-1, fc6.shape[2]).copy()
+    n = boxes.shape[0]
+    assert n == fc6.shape[0]                                                           # l.191
+    low = boxes[:, 6] <= opt.prop_thresh                                               # l.194
     if exclude_bgd_det:
-        pnt_mask |= proposals[:, 5] == 0
-    rgb = np.load(os.path.join(seg_feature_root, vid_id_ix[2:] + '_resnet.npy'))       # l.199-201
-    motion = np.load(os.path.join(seg_feature_root, vid_id_ix[2:] + '_bn.npy'))
-    raw = np.concatenate((rgb, motion), axis=1)
+        low |= boxes[:, 5] == 0                                                        # l.195-196
+    frames = np.concatenate((np.load(os.path.join(seg_feature_root, vid[2:] + '_resnet.npy')),
+                             np.load(os.path.join(seg_feature_root, vid[2:] + '_bn.npy'))), axis=1)   # l.199-201
+    F = frames.shape[0]
     t0, t1 = rec['timestamps']
     dur = rec['duration']
-    num_frm = raw.shape[0]
-    sample_idx = np.array([np.round(num_frm * t0 * 1. / dur), np.round(num_frm * t1 * 1. / dur)])   # l.207
-    sample_idx = np.clip(np.round(sample_idx), 0, opt.t_attn_size).astype(int)
-    seg_feature = np.zeros((opt.t_attn_size, raw.shape[1]))
-    seg_feature[:min(opt.t_attn_size, num_frm)] = raw[:opt.t_attn_size]
-    max_proposal = opt.num_sampled_frm * opt.num_prop_per_frm                          # l.45
-    pad_proposals = np.zeros((max_proposal, 7))
-    pad_pnt_mask = np.ones((max_proposal))
-    pad_region_feature = np.zeros((max_proposal, opt.att_feat_size))
-    num_pps = min(proposals.shape[0], max_proposal)
-    pad_proposals[:num_pps] = proposals[:num_pps]
-    pad_pnt_mask[:num_pps] = pnt_mask[:num_pps]
-    pad_region_feature[:num_pps] = region_feature[:num_pps]
-    pad_proposals = torch.from_numpy(pad_proposals).float()
-    pad_pnt_mask = torch.from_numpy(pad_pnt_mask).byte()
-    pad_region_feature = torch.from_numpy(pad_region_feature).float()
-    pad_proposals = pad_proposals.masked_fill(pad_pnt_mask.bool().view(-1, 1), 0.)     # l.343-344
-    pad_region_feature = pad_region_feature.masked_fill(pad_pnt_mask.bool().view(-1, 1), 0.)
-    num = torch.FloatTensor([1, num_pps, 0, int(seg_id_ix), rec['n_seg_in_vid'], t0 * 1. / dur, t1 * 1. / dur])
-    return dict(seg_feature=torch.from_numpy(seg_feature), num=num, proposals=pad_proposals,
-                region_feature=pad_region_feature, sample_idx=torch.from_numpy(sample_idx).long(),
-                pnt_mask=pad_pnt_mask)
+    span = np.array([np.round(F * t0 * 1. / dur), np.round(F * t1 * 1. / dur)])        # l.207 (half-to-even)
+    span = np.clip(np.round(span), 0, opt.t_attn_size).astype(int)                     # l.208
+    Ft = opt.t_attn_size
+    frame_buf = np.zeros((Ft, frames.shape[1]))                                        # l.209-210
+    frame_buf[:min(Ft, F)] = frames[:Ft]
+    R = opt.num_sampled_frm * opt.num_prop_per_frm                                     # max_proposal, l.45
+    keep_n = min(n, R)
+    box_buf, mask_buf, feat_buf = np.zeros((R, 7)), np.ones((R)), np.zeros((R, opt.att_feat_size))   # l.318-322
+    box_buf[:keep_n], mask_buf[:keep_n], feat_buf[:keep_n] = boxes[:keep_n], low[:keep_n], fc6[:keep_n]
+    box_t = torch.from_numpy(box_buf).float()
+    mask_t = torch.from_numpy(mask_buf).byte()
+    feat_t = torch.from_numpy(feat_buf).float()
+    rows = mask_t.bool().view(-1, 1)
+    box_t = box_t.masked_fill(rows, 0.)                                                # l.343
+    feat_t = feat_t.masked_fill(rows, 0.)                                              # l.344
+    num = torch.FloatTensor([1, keep_n, 0, k, rec['n_seg_in_vid'], t0 * 1. / dur, t1 * 1. / dur])   # l.346-348
+    return dict(seg_feature=torch.from_numpy(frame_buf), num=num, proposals=box_t, region_feature=feat_t,
+                sample_idx=torch.from_numpy(span).long(), pnt_mask=mask_t)
 
 
 def assemble_batch(records, feature_root, seg_feature_root, opt, exclude_bgd_det=False):

@@ -48,9 +48,12 @@ struct FwdParams {
 };
 
 // workgroup (chunk c of side s, sample b)
-template <typename T>
-__device__ __forceinline__ T ld_stream(const T* ptr, bool nt) {
-  return nt ? __builtin_nontemporal_load(ptr) : *ptr;
+// streaming load of data that is read exactly once per launch.  (A run-time `nt ? nontemporal : plain` select folds
+// into ONE plain load - the hint is lost - so the choice has to be made at compile time.)
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_stream(const T* ptr) {
+  if constexpr (NT) return __builtin_nontemporal_load(ptr);
+  else return *ptr;
 }
 
 template <bool NT>
@@ -85,10 +88,10 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
     const bool two = (r + 1) < rows;
     const float* p0 = pf + (int64_t)r * ATT_A;
     const float* p1 = two ? p0 + ATT_A : p0;
-    f32x4 x00 = ld_stream(reinterpret_cast<const f32x4*>(p0 + 4 * lane), NT);
-    f32x4 x01 = ld_stream(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane), NT);
-    f32x4 x10 = ld_stream(reinterpret_cast<const f32x4*>(p1 + 4 * lane), NT);
-    f32x4 x11 = ld_stream(reinterpret_cast<const f32x4*>(p1 + 256 + 4 * lane), NT);
+    f32x4 x00 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 4 * lane));
+    f32x4 x01 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane));
+    f32x4 x10 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 4 * lane));
+    f32x4 x11 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 256 + 4 * lane));
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   for (; r + 8 <= rows; r += 8) {
     f32x4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = ld_stream(reinterpret_cast<const f32x4*>(fb + (int64_t)(r + u) * ATT_H), NT);
+    for (int u = 0; u < 8; ++u) v[u] = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)(r + u) * ATT_H));
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float pw = s_score[r + u];
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
     }
   }
   for (; r < rows; ++r) {
-    const f32x4 v = ld_stream(reinterpret_cast<const f32x4*>(fb + (int64_t)r * ATT_H), NT);
+    const f32x4 v = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)r * ATT_H));
     const float pw = s_score[r];
     acc[0] = fmaf(pw, v[0], acc[0]); acc[1] = fmaf(pw, v[1], acc[1]);
     acc[2] = fmaf(pw, v[2], acc[2]); acc[3] = fmaf(pw, v[3], acc[3]);
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
 // projection row, G context accumulators per feature row, so the HBM stream is the sample's bytes, not G x them
 // ("shared across beams in a batched redesign").  Partials are written per beam row in the layout
 // attn_combine_kernel expects.  grid = (chunks, samples).
-template <int G>
+template <int G, bool NT>
 __global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams p) {
   __shared__ float s_score[G][MAX_CHUNK];
   __shared__ float s_m[G];
@@ -190,8 +193,8 @@ __global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams
   // ---- phase 1: one projection row per wave per pass, G scores from it
   for (int r = wave; r < rows; r += 4) {
     const float* p0 = pf + (int64_t)r * ATT_A;
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(p0 + 4 * lane);
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane);
+    const f32x4 x0 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 4 * lane));
+    const f32x4 x1 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane));
     float sc[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams
   for (; r + 4 <= rows; r += 4) {
     f32x4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(fb + (int64_t)(r + u) * ATT_H);
+    for (int u = 0; u < 4; ++u) v[u] = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)(r + u) * ATT_H));
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams
       }
   }
   for (; r < rows; ++r) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(fb + (int64_t)r * ATT_H);
+    const f32x4 v = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)r * ATT_H));
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const float pw = s_score[g][r];
@@ -410,19 +413,31 @@ extern "C" int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_sid
   p.part_ml = p.part_ctx + (int64_t)B * p.nctot * ATT_H;
   hipStream_t st = gvd_s(stream);
   gvd_prof_begin(prof, st);
+  // Streaming hint: when one launch reads more than the 256 MB Infinity Cache can hold, nothing it reads survives to
+  // the next token anyway, and nontemporal loads stream measurably faster (tools/stream_read_micro.hip: 7.1 vs 6.3 TB/s
+  // read-only; this kernel 311 -> 285 us at B = 256).  Smaller launches keep plain loads so the features stay cached
+  // across tokens.  GVD_ATTN_NT=0/1 overrides.
+  const double launch_bytes = (double)B / (region->group > 1 ? region->group : 1) *
+                              ((double)region->N + (temporal ? temporal->N : 0)) * (ATT_A + ATT_H) * 4.0;
+  const int nt_env = tune_int("GVD_ATTN_NT", -1);
+  const bool nt = nt_env >= 0 ? nt_env != 0 : launch_bytes > 192.0 * 1024 * 1024;
   // beam search: both attentions share features within groups of G rows -> one workgroup per (chunk, sample)
   const int G = region->group;
   const bool grouped = G >= 2 && G <= 5 && B % G == 0 && (!temporal || temporal->group == G) &&
                        tune_int("GVD_ATTN_GROUPED", 1);
   if (grouped) {
     const dim3 grid((unsigned)p.nctot, (unsigned)(B / G));
+#define GVD_LAUNCH_GROUP(GG)                                                                                   \
+    if (nt) hipLaunchKernelGGL((attn_partial_group_kernel<GG, true>), grid, dim3(256), 0, st, p);              \
+    else hipLaunchKernelGGL((attn_partial_group_kernel<GG, false>), grid, dim3(256), 0, st, p)
     switch (G) {
-      case 2: hipLaunchKernelGGL(attn_partial_group_kernel<2>, grid, dim3(256), 0, st, p); break;
-      case 3: hipLaunchKernelGGL(attn_partial_group_kernel<3>, grid, dim3(256), 0, st, p); break;
-      case 4: hipLaunchKernelGGL(attn_partial_group_kernel<4>, grid, dim3(256), 0, st, p); break;
-      default: hipLaunchKernelGGL(attn_partial_group_kernel<5>, grid, dim3(256), 0, st, p); break;
+      case 2: GVD_LAUNCH_GROUP(2); break;
+      case 3: GVD_LAUNCH_GROUP(3); break;
+      case 4: GVD_LAUNCH_GROUP(4); break;
+      default: GVD_LAUNCH_GROUP(5); break;
     }
-  } else if (tune_int("GVD_ATTN_NT", 0))
+#undef GVD_LAUNCH_GROUP
+  } else if (nt)
     hipLaunchKernelGGL(attn_partial_kernel<true>, dim3((unsigned)p.nctot, (unsigned)B), dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL(attn_partial_kernel<false>, dim3((unsigned)p.nctot, (unsigned)B), dim3(256), 0, st, p);

@@ -30,9 +30,9 @@ __global__ __launch_bounds__(256) void add_ln_unbiased_kernel(const float* __res
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + 4 * lane);
+    v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + i * 256 + 4 * lane));   // read-once streams
     if (yr) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(yr + i * 256 + 4 * lane);
+      const f32x4 w = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(yr + i * 256 + 4 * lane));
       v[i][0] += w[0]; v[i][1] += w[1]; v[i][2] += w[2]; v[i][3] += w[3];
     }
     s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void region_feature_rows_kernel(const float* _
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      v[i] = *reinterpret_cast<const f32x4*>(gr + i * 256 + 4 * lane);
+      v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gr + i * 256 + 4 * lane));
       s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
     const float mean = wave_sum(s) / RF_G;

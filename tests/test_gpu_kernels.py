@@ -196,8 +196,9 @@ def test_attention_beam_group_kernel_is_bitwise_the_row_kernel(K, Bs, N, Ft):
     mask = (torch.rand(Bs * K, N + 1, generator=g) < 0.2).to(torch.uint8)
     mask[:, 0] = 0
     outs = {}
-    for mode in ('1', '0'):
-        os.environ['GVD_ATTN_GROUPED'] = mode
+    for mode, nt in (('1', '0'), ('0', '0'), ('1n', '1'), ('0n', '1')):       # grouped / per-row x plain / nontemporal loads
+        os.environ['GVD_ATTN_GROUPED'] = mode[0]
+        os.environ['GVD_ATTN_NT'] = nt
         lo = torch.zeros(Bs * K, N).cuda()
         region = dict(feats=feats.cuda(), p_feats=p_feats.cuda(), q=q.cuda()[:, A:], w=w2.cuda(), alpha_bias=b2.cuda(),
                       att_mask=mask.cuda()[:, 1:], pnt_mask=mask.cuda()[:, 1:], logits_out=lo, group=K)
@@ -206,8 +207,10 @@ def test_attention_beam_group_kernel_is_bitwise_the_row_kernel(K, Bs, N, Ft):
         torch.cuda.synchronize()
         outs[mode] = (out.cpu(), cr.cpu(), ct.cpu(), lo.cpu())
     os.environ.pop('GVD_ATTN_GROUPED', None)
-    for a, b in zip(outs['1'], outs['0']):
-        assert torch.equal(a, b)
+    os.environ.pop('GVD_ATTN_NT', None)
+    for other in ('0', '1n', '0n'):
+        for a, b in zip(outs['1'], outs[other]):
+            assert torch.equal(a, b)
     # and both equal the row kernel on explicitly expanded features (group = 0)
     region = dict(feats=feats.repeat_interleave(K, 0).cuda(), p_feats=p_feats.repeat_interleave(K, 0).cuda(),
                   q=q.cuda()[:, A:], w=w2.cuda(), alpha_bias=b2.cuda(), att_mask=mask.cuda()[:, 1:],

@@ -96,11 +96,11 @@ __global__ __launch_bounds__(256) void attn_bwd_step_kernel(const BwdStepParams 
     float da = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const f32x4 f = *reinterpret_cast<const f32x4*>(fb + (int64_t)r * ATT_H + 256 * j + 4 * lane);
+      const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(fb + (int64_t)r * ATT_H + 256 * j + 4 * lane));   // read-once stream
       da += f[0] * dcv[j][0] + f[1] * dcv[j][1] + f[2] * dcv[j][2] + f[3] * dcv[j][3];
     }
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(pf + (int64_t)r * ATT_A + 4 * lane);
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(pf + (int64_t)r * ATT_A + 256 + 4 * lane);
+    const f32x4 x0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pf + (int64_t)r * ATT_A + 4 * lane));
+    const f32x4 x1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pf + (int64_t)r * ATT_A + 256 + 4 * lane));
     da = wave_sum(da);
     const bool a_masked = am && am[r];
     float de = a_masked ? 0.f : al[r] * (da - dot);          // softmax backward; masked_fill blocks the gradient

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void add_ln_unbiased_kernel(const float* __res
     f32x4 r;
 #pragma unroll
     for (int k = 0; k < 4; ++k) r[k] = g[k] * (v[i][k] - mean) * inv + b[k];
-    *reinterpret_cast<f32x4*>(o + i * 256 + 4 * lane) = r;
+    __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(o + i * 256 + 4 * lane));
   }
 }
 

@@ -10,11 +10,21 @@ CASES = {
     'greedy_b4_v5000_ft10_trained': dict(mode='sample', B=4, V=5000, Ft=10, seed=1, profile='trained_like'),
     'greedy_b4_v5000_ft480_trained': dict(mode='sample', B=4, V=5000, Ft=480, seed=2, profile='trained_like'),
     'greedy_b16_v5000_ft10_trained': dict(mode='sample', B=16, V=5000, Ft=10, seed=3, profile='trained_like'),
+    # larger decode batches: every kernel-variant boundary of the HIP path (2-group GRU above 32 rows, wide combine
+    # above 64, nontemporal 50-row attention chunks at the bench batch) against the reference itself
+    'greedy_b32_v5000_ft10_trained': dict(mode='sample', B=32, V=5000, Ft=10, seed=6, profile='trained_like'),
+    # `slice`: the reference is ALSO run on rows [40,44) alone (slice_seq / slice_att_idx), so that batch-shard invariance
+    # is checked against the reference at both batch sizes rather than statistically
+    'greedy_b96_v5000_ft10_trained': dict(mode='sample', B=96, V=5000, Ft=10, seed=7, profile='trained_like',
+                                          slice=(40, 44)),
+    # BASELINE north_star batch (bench.py default workload, same seed as bench.py uses)
+    'greedy_b256_v5000_ft10_trained': dict(mode='sample', B=256, V=5000, Ft=10, seed=0, profile='trained_like'),
     # training / grounding paths
     'mle_b4_v1000_ft10_trained': dict(mode='MLE', B=4, V=1000, Ft=10, seed=1, profile='trained_like'),
     'mle_b4_v1000_ft10_short': dict(mode='MLE', B=4, V=1000, Ft=10, seed=4, profile='default', max_cap_len=11),
     'mle_b8_v5000_ft480_default': dict(mode='MLE', B=8, V=5000, Ft=480, seed=2, profile='default'),
     'grd_b4_v1000_ft10_trained': dict(mode='GRD', B=4, V=1000, Ft=10, seed=1, profile='trained_like'),
+    'mle_b32_v5000_ft10_trained': dict(mode='MLE', B=32, V=5000, Ft=10, seed=8, profile='trained_like'),
     # BASELINE configs[2]: training step batch 64 (losses only)
     'mle_b64_v5000_ft10_trained': dict(mode='MLE', B=64, V=5000, Ft=10, seed=5, profile='trained_like'),
 }
@@ -39,6 +49,12 @@ def build_case(name):
     if train:
         inp = pkg.synth.trim_to_batch(inp)
     return opt, sd, inp
+
+
+def sim_sub(sim):
+    """The slice of sim_mat_static [B,D1,R] a greedy fixture stores: every 97th region column for small batches, one
+    column for large ones (keeps the fixture small)."""
+    return sim[:, :, ::97] if sim.shape[0] <= 16 else sim[:, :, 485:486]
 
 
 def _bits_checksum(t):

@@ -45,10 +45,18 @@ def run_case(name):
                                               {'sample_max': 1, 'beam_size': 1})
         B, L = seq.shape
         idx = att2.view(B, L, opt.num_sampled_frm, opt.num_prop_per_frm).max(dim=-1)[1]
-        out.update(seq=seq.numpy(), seqLogprobs=lps.numpy(), att_idx=idx.numpy().astype(np.int16),
-                   sim_sub=sim[:, :, ::97].contiguous().numpy())
+        out.update(seq=seq.numpy(), seqLogprobs=lps.numpy(), att_idx=idx.numpy().astype(np.int16))
+        out['sim_sub'] = cases.sim_sub(sim).contiguous().numpy()
         if B <= 4:
             out['att2_weights'] = att2.numpy()
+        if 'slice' in spec:
+            a, b = spec['slice']
+            with torch.no_grad():
+                sseq, slps, satt2, _ = ref._sample(*[inp[k][a:b].contiguous() for k in (
+                    'segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')], {'sample_max': 1, 'beam_size': 1})
+            sidx = satt2.view(b - a, L, opt.num_sampled_frm, opt.num_prop_per_frm).max(dim=-1)[1]
+            out.update(slice_seq=sseq.numpy(), slice_att_idx=sidx.numpy().astype(np.int16),
+                       slice_seqLogprobs=slps.numpy())
     elif spec['mode'] == 'MLE':
         if need_grad:
             lm, a2, gl, cl = ref(*args, 'MLE')

@@ -1,8 +1,9 @@
 """Beam-search decode on the HIP path, batched over samples x beams.
 
 Semantics = AttModel._sample_beam + CaptionModel.beam_search (model.py:627-742; CaptionModelBU.py:24-185)
-with the minimal repair documented in SURVEY.md §3.4 / oracle.sample_beam (the reference's own beam path
-raises a TypeError, so parity for this row is UNPINNED; the CPU oracle restatement is the only checker).
+with the minimal repair documented in SURVEY.md §3.4 (the reference's own beam path raises a TypeError as shipped;
+parity is pinned "reference-with-shim": tests/golden/beam*.npz hold the outputs of the reference's own beam_search
+run under a run-time shim that drops the two stray core arguments, oracle/ref_harness.beam_shim).
 Reproduced: candidate order word-rank-major / beam-minor with a stable sort by descending summed log-prob;
 only beam 0 expands at t=0; no UNK suppression; finished beams get sum = -1000 but stay in the pool; the core
 also runs after the last token; att2 holds argmax-over-all-regions indices and a finished beam's att2 is the

@@ -17,9 +17,11 @@ tests/test_oracle_vs_reference.py imports the real model from /root/reference (o
 in the build container and requires identical greedy token ids / attended-region indices and
 matching losses on seeded inputs; oracle/make_golden.py stores those reference outputs under
 tests/golden/ so the pin travels to the GPU box where /root/reference is absent.
-Beam search: the reference's beam path does not run (TypeError at CaptionModelBU.py:179-181,
-SURVEY.md §0.4), so `sample_beam` follows the code with the documented minimal repair and is
-"parity unpinned" by construction (only self-consistency with greedy at beam_size=1 is testable).
+Beam search: the reference's beam path raises as shipped (TypeError at CaptionModelBU.py:179-181,
+SURVEY.md §0.4).  `sample_beam` follows the code with the documented minimal repair and is pinned
+"reference-with-shim": oracle/ref_harness.beam_shim makes the reference's OWN beam_search run (drops the two
+stray core arguments, `.cuda()` -> identity; no reference file edited) and the ids / attended regions must be
+identical (tests/test_oracle_vs_reference.py live; tests/golden/beam*.npz for the GPU box).
 
 Mode: evaluation semantics only (dropout = identity, BatchNorm1d uses running stats), which is the only
 mode in which CPU and GPU runs are comparable (the RNG streams cannot match).  All tensors fp32.
@@ -416,7 +418,8 @@ def sample_beam(W, opt, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, b
     """AttModel._sample_beam + CaptionModel.beam_search (model.py:627-742; CaptionModelBU.py:24-185)
     with the minimal repair of SURVEY.md §3.4: the core is called with its 10 real arguments
     (CaptionModelBU.py:179-181 passes 12 -> TypeError in the reference), no `.cuda()`, and
-    `sim_mat_static` is returned as the 4th value.  PARITY UNPINNED (the reference path cannot run).
+    `sim_mat_static` is returned as the 4th value.  Pinned against the reference's own beam_search run under
+    oracle/ref_harness.beam_shim ("reference-with-shim").
 
     Reproduced quirks: candidates are ordered word-rank-major / beam-minor and stably sorted by
     descending summed log-prob (CaptionModelBU.py:49-61); at t=0 only beam 0 is expanded (48-49);

@@ -9,6 +9,8 @@ What is stored per case (all produced by the reference model, eval mode, CPU fp3
           att2_weights f32[B,L,R] (only B<=4), sim_sub f32[B,D1,11] (every 97th region of sim_mat)
   MLE:    losses f32[4] (lm, att2, ground, cls); for B<=8 also grad_norms (per-parameter L2 norm of the
           gradient of lm + w_att2*att2 + w_grd*ground + w_cls*cls, cases.GRAD_WEIGHTS)
+  beam:   seq i64[B,L], seqLogprobs f32[B,L], att2 i32[B,L] (global argmax-over-R region index per step) from the
+          reference's own beam_search run under ref_harness.beam_shim (the unshimmed reference raises)
   GRD:    cls_pred i64[N,2], att2_ind i16[B,Lc,T], grd_ind i16[B,Lc,T]
 plus weight/input fingerprints (exact integer checksums of the raw bits) so a consumer can prove it regenerated the
 identical weights and inputs from the seeds.
@@ -57,6 +59,9 @@ def run_case(name):
             sidx = satt2.view(b - a, L, opt.num_sampled_frm, opt.num_prop_per_frm).max(dim=-1)[1]
             out.update(slice_seq=sseq.numpy(), slice_att_idx=sidx.numpy().astype(np.int16),
                        slice_seqLogprobs=slps.numpy())
+    elif spec['mode'] == 'beam':
+        seq, lps, att2 = ref_harness.reference_beam_sample(ref, inp, spec['K'])
+        out.update(seq=seq.numpy(), seqLogprobs=lps.numpy(), att2=att2.numpy().astype(np.int32))
     elif spec['mode'] == 'MLE':
         if need_grad:
             lm, a2, gl, cl = ref(*args, 'MLE')

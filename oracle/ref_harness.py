@@ -90,3 +90,37 @@ def build_reference_model(opt, state_dict, need_grad=False):
             if isinstance(m, torch.nn.Dropout):
                 m.inplace = False
     return model
+
+
+@contextlib.contextmanager
+def beam_shim(model):
+    """Run-time repair that lets the reference's OWN `CaptionModel.beam_search` / `_sample_beam`
+    (CaptionModelBU.py:24-185, model.py:627-742) execute on CPU, so that beam parity is pinned on the reference's
+    code instead of on a re-reading of it.  Nothing in /root/reference is edited:
+      * CaptionModelBU.py:179-181 calls `self.core(...)` with 12 positional arguments (a stray all-zero tensor before
+        `beam_sim_mat_static` and a trailing `self`) while TopDownCore.forward takes 10 (AttModel.py:134) -> the
+        instance's `core.forward` is wrapped to drop exactly those two;
+      * `.cuda()` is hard-coded at CaptionModelBU.py:136 and model.py:738-740 -> identity while the shim is active.
+    """
+    core = model.core
+    bound = core.forward
+
+    def forward(*a):
+        if len(a) == 12:
+            a = a[:9] + (a[10],)
+        return bound(*a)
+    core.forward = forward
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        yield model
+    finally:
+        torch.Tensor.cuda = orig_cuda
+        del core.forward
+
+
+def reference_beam_sample(model, inp, beam_size):
+    """The reference's beam `'sample'` under `beam_shim` -> (seq i64[B,L], seqLogprobs f32[B,L], att2 i64[B,L])."""
+    with beam_shim(model), torch.no_grad():
+        return model._sample(inp['segs_feat'], inp['ppls'], inp['num'], inp['ppls_feat'], inp['sample_idx'],
+                             inp['pnt_mask'], {'sample_max': 1, 'beam_size': beam_size})

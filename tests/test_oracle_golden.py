@@ -13,6 +13,7 @@ from oracle import cases, gvd_oracle as O
 SAMPLE = [n for n, s in cases.CASES.items() if s['mode'] == 'sample']
 MLE = [n for n, s in cases.CASES.items() if s['mode'] == 'MLE']
 GRD = [n for n, s in cases.CASES.items() if s['mode'] == 'GRD']
+BEAM = [n for n, s in cases.CASES.items() if s['mode'] == 'beam']
 
 
 def _load(golden_dir, name):
@@ -83,6 +84,20 @@ def test_grd_matches_reference(name, golden_dir):
     assert np.array_equal(gi.numpy(), g['grd_ind'].astype(np.int64))
 
 
+@pytest.mark.parametrize('name', BEAM)
+def test_beam_matches_reference_with_shim(name, golden_dir):
+    """Beam fixtures come from the reference's own beam_search under oracle/ref_harness.beam_shim
+    (oracle/make_golden.py); the oracle restatement reproduces ids and attended regions bit for bit."""
+    g = _load(golden_dir, name)
+    opt, sd, inp = _build(name, g)
+    with torch.no_grad():
+        seq, lps, att2, _ = O.sample_beam(sd, opt, inp['segs_feat'], inp['num'], inp['ppls'], inp['ppls_feat'],
+                                          inp['sample_idx'], inp['pnt_mask'], beam_size=cases.CASES[name]['K'])
+    assert np.array_equal(seq.numpy(), g['seq'])
+    assert np.array_equal(att2.numpy(), g['att2'].astype(np.int64))
+    np.testing.assert_allclose(lps.numpy(), g['seqLogprobs'], rtol=0, atol=1e-5)
+
+
 def test_gru_loop_matches_fused():
     """The readable GRU spec and the fused library GRU the oracle uses for speed agree."""
     opt = gvd_amd.opts.default_opt(vocab_size=50)
@@ -95,7 +110,7 @@ def test_gru_loop_matches_fused():
 
 
 def test_beam1_equals_greedy_without_unk_rule():
-    """Beam search (unpinned: the reference's beam path cannot run) degenerates to greedy at
+    """Beam search degenerates to greedy at
     beam_size=1 when UNK never wins (the beam path has no UNK suppression, CaptionModelBU.py:130)."""
     opt = gvd_amd.opts.default_opt(vocab_size=300, t_attn_size=10)
     sd = gvd_amd.synth.init_state_dict(opt, seed=7, profile='trained_like')

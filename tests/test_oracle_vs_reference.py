@@ -59,6 +59,30 @@ def test_reference_beam_is_broken(setup):
         ref(*gvd_amd.synth.as_args(inp), 'sample', {'sample_max': 1, 'beam_size': 3})
 
 
+@pytest.mark.parametrize('B,K,seed,end', [(2, 3, 5, None), (3, 5, 6, None), (4, 3, 7, (3.0, -1.5)), (3, 5, 8, (3.0, -2.0))])
+def test_beam_reference_with_shim_equals_oracle(B, K, seed, end):
+    """Beam pin ("reference-with-shim"): the reference's OWN CaptionModel.beam_search / _sample_beam
+    (CaptionModelBU.py:24-185, model.py:627-742) run under oracle/ref_harness.beam_shim (drops the two stray core
+    arguments, makes .cuda() a no-op — no reference file edited) gives exactly the ids / attended regions of the
+    oracle's restatement `O.sample_beam`; `end` reshapes the END logit so beams finish at different steps."""
+    opt = gvd_amd.opts.default_opt(vocab_size=600, t_attn_size=12)
+    sd = gvd_amd.synth.init_state_dict(opt, seed=seed, profile='trained_like')
+    if end:
+        sd['logit.weight'][0] *= end[0]
+        sd['logit.bias'][0] += end[1]
+    ref = ref_harness.build_reference_model(opt, sd).eval()
+    inp = gvd_amd.synth.make_inputs(opt, B, seed=seed, train=False)
+    seq, lps, att2 = ref_harness.reference_beam_sample(ref, inp, K)
+    with torch.no_grad():
+        oseq, olps, oatt, _ = O.sample_beam(sd, opt, inp['segs_feat'], inp['num'], inp['ppls'], inp['ppls_feat'],
+                                            inp['sample_idx'], inp['pnt_mask'], beam_size=K)
+    assert torch.equal(seq, oseq) and torch.equal(att2, oatt)
+    assert float((lps - olps).abs().max()) <= 1e-5
+    # the shim is gone afterwards: the unrepaired reference raises again
+    with torch.no_grad(), pytest.raises(Exception):
+        ref(*gvd_amd.synth.as_args(inp), 'sample', {'sample_max': 1, 'beam_size': K})
+
+
 @pytest.mark.parametrize('name', sorted(edge_cases.EDGE_CASES))
 def test_greedy_edge_shapes_bitwise(name):
     """Pins the oracle on the edge shapes of oracle/edge_cases.py (the GPU test then compares HIP vs oracle)."""

@@ -222,6 +222,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
+    model.check_kernel_status()          # outside the timed region: no persistent-kernel barrier timed out
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -161,10 +161,32 @@ class TopDownModel(nn.Module):
                                        frm_mask, sample_idx, pnt_mask, True)
         if opt == 'sample':
             seq, lps, att2, sim = self._sample(segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, eval_opt)
+            self.check_kernel_status()      # fail loudly: a timed-out persistent kernel must not yield captions
             return seq, att2, sim
         raise ValueError(opt)
 
     # ------------------------------------------------------------------ helpers
+    def _flags(self):
+        """Device status words of the persistent cooperative kernels launched since the last check."""
+        if not hasattr(self, '_kernel_flags'):
+            self._kernel_flags = []
+        return self._kernel_flags
+
+    def check_kernel_status(self):
+        """The persistent kernels (greedy decoder B <= 4, bi-GRU) bound their grid-barrier spins and latch a flag
+        instead of hanging the GPU when workgroups are not co-resident; their outputs are then garbage.  One deferred
+        device->host read for all launches since the last call; raises GvdHipError if any flag is set.  Called by
+        `forward(..., 'sample')` and `sample_pipelined`; callers of the private `_sample` (bench, tests) call it
+        themselves after their timed region."""
+        flags, self._kernel_flags = self._flags(), []
+        if not flags:
+            return
+        bad = int(torch.stack([f.reshape(-1).ne(0).sum() for f in flags]).sum())
+        if bad:
+            raise GvdHipError('%d persistent-kernel launch(es) hit a grid-barrier timeout (workgroups not co-resident, '
+                              'e.g. a shared GPU): results are invalid.  Re-run, or set GVD_PERSISTENT=0 / '
+                              'GVD_GRU_BARRIER=cg' % bad)
+
     def _lin(self, x, lin, act=0):
         """nn.Linear (+ReLU) on the fp32 MFMA GEMM."""
         return ops.linear(x, lin.weight, lin.bias, act)
@@ -253,7 +275,7 @@ class TopDownModel(nn.Module):
         c = self.att_embed_aux(c.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
         if not torch.is_grad_enabled():
             # inference: persistent cooperative HIP GRU (one launch per layer instead of ~6 per step/direction)
-            c = ops.gru_bidir_2layer(c, self.context_enc)
+            c = ops.gru_bidir_2layer(c, self.context_enc, flags=self._flags())
         elif not self.training:
             # MIOpen's fused RNN has no backward in eval mode; the native GRU does (parity tests differentiate in eval)
             with torch.backends.cudnn.flags(enabled=False):
@@ -295,7 +317,9 @@ class TopDownModel(nn.Module):
                 seq, lps, att2 = beam.beam_decode(self, pre, P, beam_size)
             else:
                 seq, lps, att2 = ops.greedy_decode(pre, P, pre['pnt_mask'], self.seq_length, self.unk_idx,
-                                                    prof=getattr(self, 'kernel_timer', None))
+                                                    prof=getattr(self, 'kernel_timer', None), flags=self._flags())
+        if len(self._flags()) > 4096:        # a caller that never checks must not grow the list without bound
+            self.check_kernel_status()
         return seq, lps, att2, pre['sim_mat_static']
 
     def sample_pipelined(self, batches, eval_opt={}):
@@ -309,12 +333,14 @@ class TopDownModel(nn.Module):
         if not hasattr(self, '_streams'):
             self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
         s_pre, s_dec = self._streams
-        s_pre.wait_stream(cur)
         s_dec.wait_stream(cur)
         outs, keep = [], []
         P = {k: v.detach() for k, v in self._decode_params().items()}
         with torch.no_grad():
             for b in batches:
+                # `batches` may be a lazy producer (InferenceIngest.batches uploads on the caller's stream while we
+                # iterate): order the preamble stream after everything the caller's stream has enqueued so far
+                s_pre.wait_stream(cur)
                 with torch.cuda.stream(s_pre):
                     pre = self._preamble(b[0], b[2], b[1], b[3], b[4], b[5])
                     ev = torch.cuda.Event()
@@ -322,12 +348,16 @@ class TopDownModel(nn.Module):
                 with torch.cuda.stream(s_dec):
                     s_dec.wait_event(ev)
                     seq, lps, att2 = ops.greedy_decode(pre, P, pre['pnt_mask'], self.seq_length, self.unk_idx,
-                                                       prof=getattr(self, 'kernel_timer', None))
+                                                       prof=getattr(self, 'kernel_timer', None), flags=self._flags())
                 keep.append(pre)                      # features stay alive until the decode stream is joined below
                 outs.append((seq, lps, att2, pre['sim_mat_static']))
         cur.wait_stream(s_pre)
         cur.wait_stream(s_dec)
+        for o in outs:                               # allocated on the side streams, consumed on the caller's
+            for t in o:
+                t.record_stream(cur)
         self._pipeline_keepalive = keep              # released on the next call, after the streams were joined
+        self.check_kernel_status()
         return outs
 
     # ------------------------------------------------------------------ 'MLE' / 'GRD' (model.py:283-489)

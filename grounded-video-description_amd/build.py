@@ -4,6 +4,7 @@ hipcc cross-compiles without a GPU, so this runs in the build container; the res
 git-ignored but travels to the GPU box with the repo snapshot.  Every source is compiled to its own
 object (in parallel, only when it or a header changed), then linked.
 """
+import fcntl
 import hashlib
 import os
 import subprocess
@@ -62,10 +63,24 @@ def is_fresh():
 
 
 def build_library(force=False, verbose=True):
+    """Compile + link in-tree.  Safe under `torch.distributed.run` (every rank may call this at import time): the whole
+    build runs under an exclusive file lock, a rank that waited re-checks freshness instead of rebuilding, and the
+    library / stamp are published with atomic renames so no process can dlopen a half-written file."""
     if not force and is_fresh():
         return LIB
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and is_fresh():         # another process built it while we waited for the lock
+                return LIB
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     hh = _header_hash()
 
     def compile_one(src):
@@ -86,12 +101,17 @@ def build_library(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc] + LDFLAGS + objs + ['-o', LIB]
+    tmp = '%s.tmp.%d' % (LIB, os.getpid())
+    cmd = [hipcc] + LDFLAGS + objs + ['-o', tmp]
     if verbose:
         print('[gvd build]', ' '.join(cmd))
     subprocess.check_call(cmd)
-    with open(STAMP, 'w') as f:
+    if os.path.exists(STAMP):
+        os.unlink(STAMP)                 # never a fresh stamp next to an old library
+    os.replace(tmp, LIB)
+    with open(STAMP + '.tmp', 'w') as f:
         f.write(_source_hash())
+    os.replace(STAMP + '.tmp', STAMP)
     return LIB
 
 

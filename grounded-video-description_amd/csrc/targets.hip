@@ -152,4 +152,4 @@ extern "C" int gvd_masked_lsm_loss(const float* x, int64_t ldx, const float* lab
 }
 
 extern "C" const char* gvd_version(void) { return "gvd_hip 0.1 (gfx950, fp32 MFMA)"; }
-extern "C" int gvd_abi_version(void) { return 1; }
+extern "C" int gvd_abi_version(void) { return GVD_ABI_VERSION; }

@@ -30,3 +30,13 @@ __device__ __forceinline__ Top2 top2_wave(Top2 t) {
   }
   return t;
 }
+
+// Token rule of model.py:590-594 on a merged top-2: the best word unless it is UNK, then the runner-up.  A row of
+// all-NaN logits (diverged weights) leaves the sentinel index 0x7fffffff in place; clamp it to END (0) so the
+// next-token embedding gather can never leave the table.
+__device__ __forceinline__ int top2_token(const Top2& g, int unk, int V, bool* keep_out) {
+  const bool keep = g.i1 != unk;
+  *keep_out = keep;
+  const int it = keep ? g.i1 : g.i2;
+  return (unsigned)it < (unsigned)V ? it : 0;
+}

@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void top2_embed_kernel(const float* __restrict
   se = block_sum(se, s_red);
   if (tid == 0) {
     const float lse = logf(se);
-    const bool keep = g.i1 != unk;
-    const int it = keep ? g.i1 : g.i2;
+    bool keep;
+    const int it = top2_token(g, unk, V, &keep);
     const float lp = keep ? (g.v1 - mx) - lse : (g.v2 - mx) - lse;
     it_out[(int64_t)b * it_stride] = it;
     lp_out[(int64_t)b * lp_stride] = lp;
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(T2W_THREADS) void top2_embed_wide_kernel(const floa
   }
   se = wave_sum(se);
   if ((tid & 63) == 0) s_red[wave] = se;
-  const bool keep = g.i1 != unk;
-  const int it = keep ? g.i1 : g.i2;
+  bool keep;
+  const int it = top2_token(g, unk, V, &keep);
   // the embedding row does not depend on the sum: gather it while the reduction finishes
   if (xt) {
     const float* e = embed + (int64_t)it * E;

@@ -47,19 +47,38 @@ class GradAllReducer:
     """Bucketed, backward-overlapped gradient averaging for a replica.
 
     Parameters are packed into flat buckets in REVERSE registration order (gradients of late layers are
-    produced first).  A post-accumulate-grad hook marks a parameter ready; when a bucket is complete its
-    gradients are copied into the flat buffer and an async all-reduce is issued.  `finish()` waits for all
-    buckets, divides by the world size and scatters the averages back into `.grad`.  Parameters that
-    received no gradient this step (the unused core.i2h_2/h2h_2, AttModel.py:130-131) contribute zeros, so
-    all ranks always issue identical collectives.
+    produced first).  A post-accumulate-grad hook marks a parameter ready; a bucket whose gradients are all
+    there is copied into its flat buffer and all-reduced asynchronously.  Collectives are issued STRICTLY IN
+    BUCKET ORDER (a ready bucket waits for its predecessors), so every rank launches the same sequence
+    whatever the local hook timing.  `finish()` launches what is left, waits, divides by the world size and
+    writes the averages back into `.grad`.
+
+    Parameters that never receive a gradient (the reference's unused core.i2h_2 / core.h2h_2,
+    AttModel.py:130-131) are found in the first step — the union over ranks of "has a gradient", one small
+    all-reduce(MAX) — and are then left out of the buckets: they no longer hold a bucket's pending count
+    above zero (which used to push the bucket with the earliest gradients into `finish()`), and their
+    `.grad` stays None exactly as in a single-process run, so the optimizer treats them the same on 1 and
+    N ranks.  A parameter that has a gradient on some rank but not on this one contributes zeros.
     """
 
     def __init__(self, module, bucket_mb=64, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.bucket_mb = bucket_mb
+        self.all_params = [p for p in module.parameters() if p.requires_grad]
+        self.params = list(self.all_params)
+        self._discovered = False
+        self._hooks = []
+        # GVD_DP_FORCE=1: run the hook/bucket/all-reduce machinery even on a 1-rank group (single-GPU test of the path)
+        self.active = self.world > 1 or (os.environ.get('GVD_DP_FORCE') == '1' and dist.is_initialized())
+        self._build_buckets()
+        if self.active:
+            for p in self.all_params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _build_buckets(self):
         self.buckets = []          # list of dict(params, offsets, numel, flat)
-        cap = int(bucket_mb * 1024 * 1024 / 4)
+        cap = int(self.bucket_mb * 1024 * 1024 / 4)
         cur, cur_n = [], 0
         for p in reversed(self.params):
             if cur and cur_n + p.numel() > cap:
@@ -73,13 +92,6 @@ class GradAllReducer:
         for bi, b in enumerate(self.buckets):
             for p in b['params']:
                 self.where[id(p)] = bi
-        self._handles = []
-        self._hooks = []
-        # GVD_DP_FORCE=1: run the hook/bucket/all-reduce machinery even on a 1-rank group (single-GPU test of the path)
-        self.active = self.world > 1 or (os.environ.get('GVD_DP_FORCE') == '1' and dist.is_initialized())
-        if self.active:
-            for p in self.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.reset()
 
     def _close(self, params):
@@ -93,7 +105,7 @@ class GradAllReducer:
 
     def reset(self):
         self._pending = [len(b['params']) for b in self.buckets]
-        self._launched = [False] * len(self.buckets)
+        self._next = 0             # buckets [0, _next) have been launched
         self._handles = []
 
     def _launch(self, bi):
@@ -105,21 +117,39 @@ class GradAllReducer:
             else:
                 flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
         self._handles.append((bi, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
-        self._launched[bi] = True
+
+    def _launch_ready(self, force=False):
+        while self._next < len(self.buckets) and (force or self._pending[self._next] == 0):
+            self._launch(self._next)
+            self._next += 1
 
     def _on_grad(self, p):
-        bi = self.where[id(p)]
+        bi = self.where.get(id(p))
+        if bi is None:                  # excluded (never-used) parameter suddenly got a gradient: rediscover next step
+            self._discovered = False
+            return
         self._pending[bi] -= 1
-        if self._pending[bi] == 0 and not self._launched[bi]:
-            self._launch(bi)
+        if self._discovered:            # step 0 reduces everything in finish(), after the discovery exchange
+            self._launch_ready()
+
+    def _discover(self):
+        """Union over ranks of the parameters that got a gradient in this (first) step; rebuild the buckets from them."""
+        used = torch.tensor([0 if p.grad is None else 1 for p in self.all_params], dtype=torch.int32,
+                            device=self.all_params[0].device)
+        dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group)
+        used = used.tolist()
+        self.params = [p for p, u in zip(self.all_params, used) if u]
+        self.unused = [p for p, u in zip(self.all_params, used) if not u]
+        self._build_buckets()
+        self._discovered = True
 
     def finish(self):
         """Call after loss.backward(): completes every bucket and writes the averaged gradients back."""
         if not self.active:
             return
-        for bi in range(len(self.buckets)):
-            if not self._launched[bi]:          # buckets holding parameters that got no gradient
-                self._launch(bi)
+        if not self._discovered:
+            self._discover()
+        self._launch_ready(force=True)
         for bi, h in self._handles:
             h.wait()
             b = self.buckets[bi]

@@ -121,6 +121,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
+ABI_VERSION = 2        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 
@@ -130,19 +131,27 @@ def lib():
     if _lib is None:
         path = _build.library_path()
         if not _build.is_fresh():
-            # not built yet (or sources changed): compile the HIP sources in-tree now.  This is still the HIP path —
-            # there is no CPU/eager fallback; without hipcc the call below raises.
+            # not built yet (or sources changed): compile the HIP sources in-tree now (serialised across processes by a
+            # file lock, published atomically).  This is still the HIP path — there is no CPU/eager fallback.  A stale
+            # library is NEVER loaded silently: its struct layouts may no longer match the ctypes mirrors above.
             try:
                 _build.build_library(force=False, verbose=False)
             except Exception as e:
-                if not os.path.exists(path):
-                    raise GvdHipError('libgvd_hip.so not built (%s) and building it failed (%s): run '
-                                      '`python __graft_entry__.py build`; there is no CPU/eager fallback for the '
-                                      'hot path' % (path, e))
+                raise GvdHipError('libgvd_hip.so (%s) is %s and rebuilding it failed (%s): run `python '
+                                  '__graft_entry__.py build`; there is no CPU/eager fallback for the hot path'
+                                  % (path, 'stale (sources changed since it was built)' if os.path.exists(path)
+                                     else 'not built', e))
         try:
             l = C.CDLL(path)
         except OSError as e:   # e.g. libamdhip64 missing
             raise GvdHipError('cannot load %s: %s' % (path, e))
+        try:
+            l.gvd_abi_version.restype = C.c_int
+            got = l.gvd_abi_version()
+        except AttributeError:
+            got = None
+        if got != ABI_VERSION:
+            raise GvdHipError('%s reports ABI %r, the Python binding expects %d (stale build?)' % (path, got, ABI_VERSION))
         for name, (res, args) in _SIG.items():
             try:
                 fn = getattr(l, name)

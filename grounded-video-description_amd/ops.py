@@ -177,9 +177,12 @@ def logsoftmax_rows(logits, target=None, topk=0):
     return lse, picked, tv, ti
 
 
-def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None):
+def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None, flags=None):
     """Whole greedy token loop (AttModel._sample, model.py:580-624) in one C call.
-    pre: dict(fc, conv, p_conv, pool, p_pool) from the preamble; P: dict of parameter tensors."""
+    pre: dict(fc, conv, p_conv, pool, p_pool) from the preamble; P: dict of parameter tensors.
+    `flags`: list that receives the launch's device status word (non-zero after a sync = the persistent kernel's grid
+    barrier timed out and the ids are poisoned); the caller must check it before trusting the result
+    (TopDownModel.check_kernel_status)."""
     fc, conv, p_conv, pool, p_pool = (pre[k].contiguous() for k in ('fc', 'conv', 'p_conv', 'pool', 'p_pool'))
     require_cuda_f32(fc, conv, p_conv, pool, p_pool)
     B, H = fc.shape
@@ -213,6 +216,8 @@ def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None):
     greedy_decode.last_trace = trace
     check(lib().gvd_greedy_decode(C.byref(a), stream_ptr()), 'gvd_greedy_decode')
     greedy_decode.last_status = status      # 1 after a device sync = the persistent decode kernel timed out (ids are -1)
+    if flags is not None:
+        flags.append(status)
     return seq, lps, att2
 
 
@@ -432,7 +437,7 @@ def attn_bwd_pfeats(p_feats, q_all, de_all, w):
 GRU_BARRIER = os.environ.get('GVD_GRU_BARRIER', 'counter')   # 'counter' (hand-rolled) | 'cg' (library grid sync)
 
 
-def gru_bidir_2layer(x, gru, barrier=None):
+def gru_bidir_2layer(x, gru, barrier=None, flags=None):
     """Inference forward of the frame encoder nn.GRU(1024, 512, 2, bidirectional, batch_first) (model.py:399):
     per layer one MFMA GEMM for both directions' input projections + one persistent cooperative kernel for the
     recurrence (gvd_gru_bidir_layer).  x [B,T,1024] -> [B,T,1024]."""
@@ -458,6 +463,8 @@ def gru_bidir_2layer(x, gru, barrier=None):
                                         ptr(sync), stream_ptr()), 'gvd_gru_bidir_layer')
         inp = out
     gru_bidir_2layer.last_sync = syncs     # tests read the timeout flags (sync_timed_out) after a device sync
+    if flags is not None:                  # word 32 of every barrier object latches a spin timeout
+        flags.extend(s.view(-1, lib().gvd_grid_sync_words())[:, 32] for s in syncs)
     return inp
 
 

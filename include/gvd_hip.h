@@ -32,7 +32,10 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 #define GVD_EINVAL (-1)
 #define GVD_MIN_VALUE (-1e8f) /* AttModel.py:31,66; model.py:71 */
 
-/* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded) */
+/* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
+ * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
+ * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
+#define GVD_ABI_VERSION 2
 const char* gvd_version(void);
 int gvd_abi_version(void);
 

@@ -49,13 +49,25 @@ def _worker(rank, world, port, outdir):
     m[2](torch.relu(m[0](x))).pow(2).mean().backward()          # m[3] unused -> no grad
     local = [None if p.grad is None else p.grad.clone() for p in m.parameters()]
     red.finish()
-    avg = [p.grad.clone() for p in m.parameters()]
+    avg = [None if p.grad is None else p.grad.clone() for p in m.parameters()]
     gathered = [None] * world
     dist.all_gather_object(gathered, local)
     ok = True
     for i, a in enumerate(avg):
+        if all(g[i] is None for g in gathered):      # unused on every rank: .grad stays None, as on a single rank
+            ok &= a is None
+            continue
         want = sum((g[i] if g[i] is not None else torch.zeros_like(a)) for g in gathered) / world
         ok &= torch.allclose(a, want, atol=1e-7)
+    # second step: buckets now launch from the hooks, strictly in order; same averages
+    for p in m.parameters():
+        p.grad = None
+    red.reset()
+    m[2](torch.relu(m[0](x))).pow(2).mean().backward()
+    launched_in_backward = red._next
+    red.finish()
+    ok &= launched_in_backward == len(red.buckets)     # every bucket was complete before finish()
+    ok &= all((a is None and p.grad is None) or torch.allclose(a, p.grad, atol=1e-7) for a, p in zip(avg, m.parameters()))
     # (2) the real loss on this rank's shard of a batch (oracle), averaged grads == mean of shard grads
     opt = gvd_amd.opts.default_opt(vocab_size=120, t_attn_size=6)
     sd = synth.init_state_dict(opt, seed=4)
@@ -69,7 +81,7 @@ def _worker(rank, world, port, outdir):
     local_g = {n: (None if p.grad is None else p.grad.clone()) for n, p in zip(bag.names, bag.p)}
     red2.finish()
     out = dict(rank=rank, ok_toy=bool(ok), losses=local_losses,
-               local=local_g, avg={n: p.grad.clone() for n, p in zip(bag.names, bag.p)})
+               local=local_g, avg={n: (None if p.grad is None else p.grad.clone()) for n, p in zip(bag.names, bag.p)})
     torch.save(out, os.path.join(outdir, 'rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -93,6 +105,9 @@ def test_two_rank_gradient_averaging(tmp_path):
     for n in names:
         l0, l1 = res[0]['local'][n], res[1]['local'][n]
         a = res[0]['avg'][n]
+        if l0 is None and l1 is None:
+            assert a is None and res[1]['avg'][n] is None, n          # never-used parameters keep .grad None
+            continue
         want = ((l0 if l0 is not None else torch.zeros_like(a)) + (l1 if l1 is not None else torch.zeros_like(a))) / 2
         assert torch.allclose(a, want, rtol=1e-6, atol=1e-8), n
         assert torch.equal(res[0]['avg'][n], res[1]['avg'][n]), n        # replicas stay in lock-step

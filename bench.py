@@ -1,20 +1,27 @@
 """bench.py — captions/sec of the GVD greedy-decode hot path on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--t-attn Ft] [--vocab V]
+                    [--mode sample|train] [--beam K --frames T]
 
 One "step" = one full `'sample'` call (AttModel._sample: per-segment preamble + 20-token greedy loop)
-over one batch of synthetic segments that is already resident in HBM.  N>1 is launched by
-torch.distributed.run (one process per GPU); the path shards purely over the batch of video segments,
-so every rank decodes its own B segments with no data-path collective (weak scaling) and the only
-communication is the barrier + max-reduction of the elapsed time.
+over one batch of synthetic segments that is already resident in HBM.  With `--gpus N > 1` and no RANK in
+the environment the script re-executes itself under `torch.distributed.run` (one process per GPU, rendezvous on
+127.0.0.1); launched by the driver under torch.distributed.run it reads RANK/LOCAL_RANK/WORLD_SIZE.  The path
+shards purely over the batch of video segments, so every rank decodes its own B segments with no data-path
+collective (weak scaling) and the only communication is the barrier + max-reduction of the elapsed time
+(`--mode train` adds the RCCL gradient all-reduce).
 
-Prints ONE JSON line (rank 0): metric/value (whole-job captions/s), `roofline` of the dominant kernel
-(the attention streaming kernel, timed live with HIP events on its stream over the timed region) and
-`cpu_baseline` (the CPU oracle = port of the reference path, timed on this box's host cores).
+Prints ONE JSON line (rank 0): metric/value (whole-job captions/s), `roofline` of the dominant hand-written
+kernel (the attention streaming kernel, timed live with HIP events on its stream over the timed region),
+`cpu_baseline` (the CPU oracle = port of the reference path, timed on this box's host cores; the timing of the REAL
+reference in the build container is attached from profiles/cpu_reference_timing.json) and — for the default
+workload, whose inputs and weights are exactly the committed reference case `greedy_b256_v5000_ft10_trained` —
+`parity`: the decoded ids / attended regions of the timed run compared with the reference's own output.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -25,6 +32,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured copy
+GOLDEN_B256 = os.path.join(ROOT, 'tests', 'golden', 'greedy_b256_v5000_ft10_trained.npz')
 
 
 def parse():
@@ -51,46 +59,134 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(opt, sd, seconds):
-    """The oracle (CPU port of the reference path) on BASELINE configs[0]: B=4 greedy, same shapes.
-    torch's default of one thread per hardware thread is pathologically slow on many-core hosts for these
-    small ops, so a few thread counts are tried (one call each) and the fastest is used and reported."""
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: become `torch.distributed.run ... bench.py <same args>`."""
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit('bench.py: --gpus %d requested but this node exposes %d GPU(s) (torch.cuda.device_count()); '
+                 'run with --gpus <= %d' % (args.gpus, have, max(have, 1)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def _reference_timing():
+    """Timing of the REAL reference (imported from /root/reference, which does not exist on the GPU box) measured in the
+    build container by tools/time_reference_cpu.py and committed; attached to cpu_baseline for context."""
+    p = os.path.join(ROOT, 'profiles', 'cpu_reference_timing.json')
+    if os.path.exists(p):
+        with open(p) as f:
+            return json.load(f)
+    return None
+
+
+def _best_threads(fn):
+    """torch's default of one thread per hardware thread is pathologically slow on many-core hosts for these small
+    ops: try a few thread counts (one call each) and keep the fastest."""
+    ncpu = os.cpu_count() or 1
+    best = None
+    for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        fn()                                  # warm-up at this thread count
+        t0 = time.time()
+        fn()
+        dt = time.time() - t0
+        if best is None or dt < best[1]:
+            best = (nt, dt)
+        if dt > 20.0:
+            break
+    torch.set_num_threads(best[0])
+    return best[0], ncpu
+
+
+def _timed_loop(fn, seconds, max_n=200):
+    n, t0 = 0, time.time()
+    while True:
+        fn()
+        n += 1
+        if time.time() - t0 >= seconds or n >= max_n:
+            break
+    return n, time.time() - t0
+
+
+def cpu_baseline(opt, sd, seconds, beam=1):
+    """The oracle (CPU port of the reference path) on BASELINE configs[0]: B=4 greedy (or beam), same shapes."""
     from gvd_amd import synth
     from oracle import gvd_oracle as O
     inp = synth.make_inputs(opt, 4, seed=0, train=False)
     a = [inp[k] for k in ('segs_feat', 'num', 'ppls', 'ppls_feat', 'sample_idx', 'pnt_mask')]
-    ncpu = os.cpu_count() or 1
-    best = None
     with torch.no_grad():
-        for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):
-            torch.set_num_threads(nt)
-            O.sample_greedy(sd, opt, *a)      # warm-up at this thread count
-            t0 = time.time()
-            O.sample_greedy(sd, opt, *a)
-            dt = time.time() - t0
-            if best is None or dt < best[1]:
-                best = (nt, dt)
-            if dt > 20.0:
-                break
-        torch.set_num_threads(best[0])
-        n, t0 = 0, time.time()
-        while True:
-            O.sample_greedy(sd, opt, *a)
-            n += 1
-            if time.time() - t0 >= seconds or n >= 200:
-                break
-        dt = time.time() - t0
-    return {'value': round(4 * n / dt, 3), 'unit': 'captions/s', 'cores': best[0], 'kind': 'port',
-            'host_cpus': ncpu,
-            'sample': '%d greedy sample() calls of B=4 (L=20, 10x100 regions, Ft=%d, V=%d) with oracle/gvd_oracle.py '
+        if beam > 1:
+            run = lambda: O.sample_beam(sd, opt, *a, beam_size=beam)
+        else:
+            run = lambda: O.sample_greedy(sd, opt, *a)
+        nt, ncpu = _best_threads(run)
+        n, dt = _timed_loop(run, seconds)
+    return {'value': round(4 * n / dt, 3), 'unit': 'captions/s', 'cores': nt, 'kind': 'port', 'host_cpus': ncpu,
+            'sample': '%d %s sample() calls of B=4 (L=20, %dx100 regions, Ft=%d, V=%d) with oracle/gvd_oracle.py '
                       '(torch-CPU restatement pinned bit-for-bit to the reference), %.1f s, best of 8/16/32/64 threads'
-                      % (n, opt.t_attn_size, opt.vocab_size, dt)}
+                      % (n, 'beam=%d' % beam if beam > 1 else 'greedy', opt.num_sampled_frm, opt.t_attn_size,
+                         opt.vocab_size, dt),
+            'reference_in_build_container': _reference_timing()}
+
+
+def cpu_baseline_train(opt, sd, seconds):
+    """Oracle 'MLE' forward + autograd backward + clip + Adam on B=8 segments (eval-mode arithmetic: dropout is the only
+    difference to a train-mode step and costs nothing on CPU)."""
+    from gvd_amd import synth
+    from oracle import gvd_oracle as O
+    Bc = 8
+    inp = synth.trim_to_batch(synth.make_inputs(opt, Bc, seed=0, train=True))
+    W = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v) for k, v in sd.items()}
+    params = [v for v in W.values() if v.requires_grad]
+    optim = torch.optim.Adam(params, lr=opt.learning_rate)
+
+    def run():
+        optim.zero_grad(set_to_none=True)
+        lm, a2, gl, cl, _ = O.forward_train(W, opt, *[inp[k] for k in synth.FORWARD_ORDER])
+        (lm + opt.w_att2 * a2 + opt.w_grd * gl + opt.w_cls * cl).backward()
+        torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], opt.grad_clip)
+        optim.step()
+    ncpu = os.cpu_count() or 1
+    nt = min(ncpu, 32)
+    torch.set_num_threads(nt)
+    run()
+    n, dt = _timed_loop(run, seconds, max_n=20)
+    return {'value': round(Bc * n / dt, 3), 'unit': 'segments/s', 'cores': nt, 'kind': 'port', 'host_cpus': ncpu,
+            'sample': "%d train steps ('MLE' forward + autograd backward + clip + Adam) of B=%d with oracle/gvd_oracle.py, "
+                      '%.1f s, %d threads' % (n, Bc, dt, nt),
+            'reference_in_build_container': _reference_timing()}
+
+
+def _roofline(attn_ms, attn_n, bytes_per_launch, traffic, kernel):
+    avg_s = (attn_ms / max(attn_n, 1)) * 1e-3
+    achieved = bytes_per_launch / avg_s / 1e9 if attn_n else None
+    return {'bound': 'hbm', 'kernel': kernel,
+            'achieved': None if achieved is None else round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+            'traffic': traffic[0], 'traffic_source': traffic[1], 'bytes_per_launch': bytes_per_launch,
+            'avg_launch_us': round(avg_s * 1e6, 2), 'launches_timed': attn_n}
+
+
+def _static_traffic(B, Ft, R):
+    """PMC HBM bytes per launch are collected in separate rocprofv3 --pmc passes (profiles/), not in this run."""
+    tpath = os.path.join(ROOT, 'profiles', 'attn_traffic.json')
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get('batch') == B and tj.get('t_attn') == Ft and tj.get('regions', 1000) == R:
+            return tj.get('hbm_bytes_per_launch'), 'profiles/attn_traffic.json (static: rocprofv3 --pmc passes of this workload)'
+    return None, None
 
 
 def bench_train(args, opt, sd, model, B, rank, world, dev):
     """BASELINE configs[2]/[3]: one optimisation step = 'MLE' forward (LM + attention + grounding + cls losses),
     hand-scheduled BPTT, RCCL gradient all-reduce (N>1), clip 0.1, Adam.  Train mode (dropout, BN batch stats)."""
-    from gvd_amd import dist as gdist, synth, train
+    from gvd_amd import dist as gdist, hip, ops, synth, train
     model.train()
     gdist.broadcast_parameters(model)
     tr = train.Trainer(model, opt)
@@ -100,8 +196,11 @@ def bench_train(args, opt, sd, model, B, rank, world, dev):
         tr.step(a)
     torch.cuda.synchronize()
     use_dist = dist.is_initialized()
+    timer = hip.KernelTimer(max_pairs=opt.seq_length * max(args.steps, 1))
+    ops.set_kernel_timer(timer)
     if use_dist:
         dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = tr.step(a)
@@ -109,12 +208,16 @@ def bench_train(args, opt, sd, model, B, rank, world, dev):
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    attn_ms, attn_n = timer.read()
     if rank == 0:
-        print(json.dumps({
+        R = opt.num_sampled_frm * opt.num_prop_per_frm
+        A, H, Ft = opt.att_hid_size, opt.rnn_size, args.t_attn
+        out = {
             'metric': "train segments/sec ('MLE' fwd + BPTT + grad all-reduce + clip + Adam)",
             'value': round(world * B * args.steps / elapsed, 2), 'unit': 'segments/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
@@ -122,13 +225,20 @@ def bench_train(args, opt, sd, model, B, rank, world, dev):
             'config': {'workload': 'train step, %d segments/GPU, L=20, 10x100 regions, Ft=%d, V=%d, w_att2=%.2f '
                                    'w_grd=%.2f w_cls=%.2f' % (B, args.t_attn, args.vocab, opt.w_att2, opt.w_grd, opt.w_cls),
                        'batch_per_gpu': B, 'parallelism': 'dp%d (RCCL bucketed grad all-reduce)' % world},
-            'losses_last': [round(float(x), 5) for x in losses], 'roofline': None, 'cpu_baseline': None}))
+            'losses_last': [round(float(x), 5) for x in losses],
+            # the forward attention streaming kernel of the teacher-forced loop (same kernel, same bytes as in decode)
+            'roofline': _roofline(attn_ms, attn_n, B * (R + Ft) * (A + H) * 4, (None, None),
+                                  'attn_partial_kernel (forward region+temporal attention of the teacher-forced loop)'),
+            'cpu_baseline': None if (world != 1 or args.no_cpu_baseline) else cpu_baseline_train(opt, sd, args.cpu_seconds)}
+        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        self_launch(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -138,11 +248,12 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
-    assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     dev = torch.device('cuda', local)
 
     import gvd_amd  # noqa: F401
-    from gvd_amd import att_model, hip, opts, synth
+    from gvd_amd import att_model, hip, ops, opts, synth
     opt = opts.default_opt(vocab_size=args.vocab, t_attn_size=args.t_attn, num_sampled_frm=args.frames)
     sd = synth.init_state_dict(opt, seed=0, profile='trained_like')
     model = att_model.TopDownModel(opt)
@@ -151,21 +262,16 @@ def main():
     B = args.batch or ((256 if args.beam == 1 else 64) if args.mode == 'sample' else 64)
     if args.mode == 'train':
         return bench_train(args, opt, sd, model, B, rank, world, dev)
-    # each rank: its own shard of segments.  The CPU generator is slow for 2 GB of features, so a 32-segment base
-    # batch is generated from the seed and tiled (with a per-copy perturbation of the float features) up to B
-    base_n = min(B, 32)
-    inp = synth.make_inputs(opt, base_n, seed=100 + rank, train=False)
+    # each rank: its own shard of seeded segments (rank r uses seed r).  Rank 0 of the default workload therefore holds
+    # exactly the inputs + weights of the committed reference case greedy_b256_v5000_ft10_trained (oracle/cases.py).
     keys = ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')
-    reps = (B + base_n - 1) // base_n
-    dinp = []
-    for k in keys:
-        t = inp[k].to(dev)
-        if reps > 1:
-            t = t.repeat(reps, *([1] * (t.dim() - 1)))[:B].contiguous()
-            if k in ('segs_feat', 'ppls_feat'):
-                scale = 1.0 + 0.01 * torch.arange(B, device=dev, dtype=torch.float32).div(base_n, rounding_mode='floor')
-                t = t * scale.view(B, *([1] * (t.dim() - 1)))
-        dinp.append(t)
+    inp = synth.make_inputs(opt, B, seed=rank, train=False)
+    dinp = [inp[k].to(dev) for k in keys]
+    golden = None
+    if (rank == 0 and B == 256 and args.beam == 1 and args.vocab == 5000 and args.t_attn == 10 and args.frames == 10
+            and os.path.exists(GOLDEN_B256)):
+        import numpy as np
+        golden = np.load(GOLDEN_B256)
     timer = hip.KernelTimer(max_pairs=opt.seq_length * max(args.steps, 1))
     model.kernel_timer = None
 
@@ -179,6 +285,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         model.kernel_timer = timer
+        ops.set_kernel_timer(timer if args.beam > 1 else None)     # beam: the grouped attention launches of beam.py
         timer.reset()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -222,6 +329,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
     model.check_kernel_status()          # outside the timed region: no persistent-kernel barrier timed out
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -232,16 +340,9 @@ def main():
     if rank == 0:
         R = opt.num_sampled_frm * opt.num_prop_per_frm
         A, H, Ft = opt.att_hid_size, opt.rnn_size, args.t_attn
-        bytes_per_launch = B * (R + Ft) * (A + H) * 4          # algorithmic bytes
-        avg_s = (attn_ms / max(attn_n, 1)) * 1e-3
-        achieved = bytes_per_launch / avg_s / 1e9 if attn_n else None   # (beam mode does not attach the event timer)
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'attn_traffic.json')
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get('batch') == B and tj.get('t_attn') == Ft:
-                traffic = tj.get('hbm_bytes_per_launch')
+        # algorithmic bytes.  Beam: the grouped kernel streams a SAMPLE's features once for
+        # its K beams, so the algorithmic bytes per launch are per sample, not per beam row.
+        bytes_per_launch = B * (R + Ft) * (A + H) * 4
         out = {
             'metric': 'captions/sec (seq_len=20, %dx100 regions), %s' % (args.frames, 'greedy decode' if args.beam == 1
                                                                          else 'beam-search decode (beam=%d)' % args.beam),
@@ -258,12 +359,21 @@ def main():
                        'batch_per_gpu': B, 'parallelism': 'batch-sharded replicas x%d (no data-path collective)' % world,
                        'overlap': 'preamble(i+1) || token-loop(i) on 2 HIP streams' if args.overlap else 'off (steps run serially)',
                        'inputs': 'copied from pinned host memory every step (PCIe-inclusive)' if args.h2d else 'resident in HBM'},
-            'roofline': {'bound': 'hbm', 'kernel': 'attn_partial_kernel (region+temporal additive attention)',
-                         'achieved': None if achieved is None else round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': traffic, 'bytes_per_launch': bytes_per_launch,
-                         'avg_launch_us': round(avg_s * 1e6, 2), 'launches_timed': attn_n},
+            'roofline': _roofline(attn_ms, attn_n, bytes_per_launch, _static_traffic(B, Ft, R),
+                                  'attn_partial_kernel (region+temporal additive attention)' if args.beam == 1 else
+                                  'attn_partial_group_kernel<%d> (one feature stream per sample for its %d beams)'
+                                  % (args.beam, args.beam)),
         }
+        if golden is not None:
+            # the timed run decoded the committed reference case: compare with the reference's own output
+            from gvd_amd.att_model import attended_region_indices
+            ids_ok = bool((seq.cpu().numpy() == golden['seq']).all())
+            idx = attended_region_indices(att2, opt.num_sampled_frm, opt.num_prop_per_frm).cpu().numpy()
+            idx_ok = bool((idx == golden['att_idx'].astype(idx.dtype)).all())
+            out['parity'] = {'golden': 'tests/golden/greedy_b256_v5000_ft10_trained.npz (reference CPU output, '
+                                       'oracle/make_golden.py)', 'token_ids_equal': ids_ok,
+                             'attended_region_indices_equal': idx_ok,
+                             'max_abs_logprob_diff': float(abs(lps.cpu().numpy() - golden['seqLogprobs']).max())}
         if world == 1 and args.beam == 1 and B != 4 and not args.h2d:
             # BASELINE configs[1] shape (batch_size=4 eval) next to the headline batch: the latency-bound case
             model.kernel_timer = None
@@ -277,10 +387,11 @@ def main():
                     model._sample(*small)
                 torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / 20
+            model.check_kernel_status()
             out['config']['configs1_b4'] = {'batch': 4, 'ms_per_call': round(1e3 * dt, 3),
                                             'captions_per_s': round(4 / dt, 1), 'calls_timed': 20}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(opt, sd, args.cpu_seconds)
+            out['cpu_baseline'] = cpu_baseline(opt, sd, args.cpu_seconds, beam=args.beam)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))

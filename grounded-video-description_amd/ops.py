@@ -132,6 +132,17 @@ def _workspace(nbytes, device):
     return t
 
 
+_kernel_timer = None
+
+
+def set_kernel_timer(timer):
+    """Bracket every `attention_step` launch with the HIP event pairs of `timer` (hip.KernelTimer) — bench.py's live
+    roofline measurement for the paths that call the attention kernel from Python (training forward, beam search).
+    None switches it off."""
+    global _kernel_timer
+    _kernel_timer = timer
+
+
 def attention_step(region, temporal, want_separate=False):
     """Both additive attentions of one decoder step (AttModel.py:33-53,71-108) in one streaming pass.
 
@@ -150,8 +161,9 @@ def attention_step(region, temporal, want_separate=False):
     out = torch.empty(B, H, device=f.device, dtype=torch.float32)
     cr = torch.empty(B, H, device=f.device, dtype=torch.float32) if want_separate else None
     ct = torch.empty(B, H, device=f.device, dtype=torch.float32) if (want_separate and st is not None) else None
-    check(lib().gvd_attn_fwd(C.byref(sr), C.byref(st) if st is not None else None, B, A, H, ptr(out), H,
-                             ptr(cr), ptr(ct), ptr(ws), stream_ptr()), 'gvd_attn_fwd')
+    prof = _kernel_timer.h if _kernel_timer is not None else None
+    check(lib().gvd_attn_fwd_prof(C.byref(sr), C.byref(st) if st is not None else None, B, A, H, ptr(out), H,
+                                  ptr(cr), ptr(ct), ptr(ws), prof, stream_ptr()), 'gvd_attn_fwd')
     return (out, cr, ct) if want_separate else out
 
 

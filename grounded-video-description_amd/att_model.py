@@ -194,12 +194,66 @@ class TopDownModel(nn.Module):
     def _drop(self, x, p=None):
         return F.dropout(x, self.drop_prob_lm if p is None else p, self.training)
 
+    def _packed(self, key, params, build):
+        """Derived (re-laid-out) copies of parameters for the fused inference kernels, rebuilt whenever a source
+        parameter changed (in-place update, load_state_dict, .to(device))."""
+        cache = self.__dict__.setdefault('_pack_cache', {})
+        sig = tuple((t.data_ptr(), t._version, t.device) for t in params)
+        hit = cache.get(key)
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                hit = (sig, build())
+            cache[key] = hit
+        return hit[1]
+
+    def _obj_interact_fused(self, x):
+        """Inference path of the encoder on the HIP kernels only (transformer.py:107-190): per layer ONE projection GEMM
+        for q|k|v against row-permuted weights that drop every head into its own zero-padded 176-column slot (16-byte
+        aligned heads), the padded-head flash attention kernel, the output projection over the padded layout (zero
+        weight columns on the pads), residual + LayerNorm row kernel, and the feed-forward pair on the MFMA GEMM with
+        bias/ReLU fused."""
+        d = x.shape[-1]
+        HP, nh = ops.HEAD_PAD, 6
+        sizes = [t.shape[-1] for t in x[:1, :1].chunk(nh, -1)]
+        starts = [sum(sizes[:i]) for i in range(nh)]
+        for lay in self.obj_interact.encoder.layers:
+            sa = lay.selfattn.layer
+
+            def build_qkv(sa=sa):
+                w = torch.zeros(3 * nh * HP, d, device=x.device, dtype=torch.float32)
+                for j, lin in enumerate((sa.wq, sa.wk, sa.wv)):
+                    for h in range(nh):
+                        w[(j * nh + h) * HP:(j * nh + h) * HP + sizes[h]] = lin.weight[starts[h]:starts[h] + sizes[h]]
+                return w
+
+            def build_wo(sa=sa):
+                w = torch.zeros(d, nh * HP, device=x.device, dtype=torch.float32)
+                for h in range(nh):
+                    w[:, h * HP:h * HP + sizes[h]] = sa.wo.weight[:, starts[h]:starts[h] + sizes[h]]
+                return w
+            w_qkv = self._packed(('qkv', id(sa)), (sa.wq.weight, sa.wk.weight, sa.wv.weight), build_qkv)
+            w_o = self._packed(('wo', id(sa)), (sa.wo.weight,), build_wo)
+            qkv = ops.gemm_nt(x, w_qkv)                                        # [B,R,3*6*176]
+            o = ops.flash_attn_padded(qkv, nh, 1.0 / math.sqrt(d))              # [B,R,6*176]
+            att = ops.gemm_nt(o, w_o)
+            ln = lay.selfattn.layernorm
+            x = ops.add_layernorm_unbiased(x.contiguous(), att, ln.gamma.detach(), ln.beta.detach(), ln.eps)
+            ff = lay.feedforward.layer
+            y = ops.gemm_nt(ops.gemm_nt(x, ff.linear1.weight.detach(), ff.linear1.bias.detach(), 1),
+                            ff.linear2.weight.detach(), ff.linear2.bias.detach())
+            ln = lay.feedforward.layernorm
+            x = ops.add_layernorm_unbiased(x, y, ln.gamma.detach(), ln.beta.detach(), ln.eps)
+        return x
+
     def _obj_interact(self, x):
         """transformer.py:135-190,244-254 as built at model.py:126-135 (6 uneven heads, scale sqrt(d_model),
-        no padding mask, custom LayerNorm).  Library GEMMs for now."""
+        no padding mask, custom LayerNorm)."""
         d = x.shape[-1]
         scale = math.sqrt(d)
         fused = not torch.is_grad_enabled()
+        if (fused and not self.training and self.flash_obj_interact and os.environ.get('GVD_ENC_FUSED', '1') == '1'
+                and scale == 2.0 ** round(math.log2(scale)) and d % 32 == 0 and -(-d // 6) <= ops.HEAD_PAD):
+            return self._obj_interact_fused(x)
         for lay in self.obj_interact.encoder.layers:
             sa = lay.selfattn.layer
             q, k, v = sa.wq(x), sa.wk(x), sa.wv(x)
@@ -248,13 +302,27 @@ class TopDownModel(nn.Module):
         vis_word = self._drop(F.relu(self.vis_embed[0].weight))
         loc_in = torch.cat([ppls[:, :, :4] / 720., (ppls[:, :, 4] * 1. / self.num_sampled_frm).unsqueeze(-1)], dim=2)
         loc = F.dropout(F.relu(self.loc_fc[0](loc_in)), 0.5, self.training)
+        pool_done = False
         if not torch.is_grad_enabled():
             # inference: class-last similarity logits from ONE plain MFMA GEMM (the visual words are shared by the
             # batch), then mask + class softmax + the three layer norms + concat as one HIP row kernel
             # (model.py:321-340,357-364)
             logits_t = ops.gemm_nt(g_pool, vis_word.detach(), self.vis_classifiers_bias.detach())     # [B,R,D1]
-            pool, sim_t = ops.region_feature_rows(g_pool, loc.contiguous(), logits_t, pm)
+            own = os.environ.get('GVD_POOL_EMBED_OWN', '1') == '1'
+            pool, sim_t = ops.region_feature_rows(g_pool, loc.contiguous(), logits_t, pm, pad_to=32 if own else 1)
             sim_mat = sim_t.transpose(1, 2)          # [B,D1,R] view (the reference returns this layout)
+            if own:
+                # pool_embed (model.py:384, K = 2781) on the MFMA GEMM: the row kernel wrote the concat zero-padded to
+                # K = 2816 (16-byte aligned rows, 32-multiple K); the weight gets matching zero columns once
+                pw = self.pool_embed[0].weight
+
+                def build_pool(pw=pw, K=pool.shape[-1]):
+                    w = torch.zeros(pw.shape[0], K, device=pw.device, dtype=torch.float32)
+                    w[:, :pw.shape[1]] = pw
+                    return w
+                w_pool = self._packed('pool_embed', (pw,), build_pool)
+                pool = self._drop(ops.gemm_nt(pool, w_pool, self.pool_embed[0].bias.detach(), 1))
+                pool_done = True
         else:
             # region-class similarity: batched grounder GEMM with fused bias + proposal mask (model.py:321-340)
             sim_logits = ops.grounder(vis_word, g_pool, pm[:, 1:], mbias=self.vis_classifiers_bias, xt_shared=True)
@@ -264,14 +332,16 @@ class TopDownModel(nn.Module):
             pool = torch.cat([F.layer_norm(g_pool, [g_pool.shape[-1]]), F.layer_norm(loc, [300]),
                               F.layer_norm(label, [D1])], dim=2)
         fc = self._drop(F.relu(self.fc_embed[0](fc)))
-        pool = self._drop(F.relu(self.pool_embed[0](pool)))
+        if not pool_done:
+            pool = self._drop(F.relu(self.pool_embed[0](pool)))
         if self.has_obj_interact:
             pool = self._obj_interact(pool)
         pool = pool.contiguous()
         p_pool = self._lin(pool, self.ctx2pool)                           # MFMA GEMM (model.py:391)
         # frame-wise context (model.py:393-405)
-        c = torch.cat([self._drop(F.relu(self.att_embed[0][0](segs_feat[:, :, :2048]))),
-                       self._drop(F.relu(self.att_embed[1][0](segs_feat[:, :, 2048:])))], dim=2)
+        # frame embeddings (model.py:393-395) on the MFMA GEMM, straight from the two column blocks of segs_feat
+        c = torch.cat([self._drop(self._lin(segs_feat[:, :, :2048], self.att_embed[0][0], act=1)),
+                       self._drop(self._lin(segs_feat[:, :, 2048:], self.att_embed[1][0], act=1))], dim=2)
         c = self.att_embed_aux(c.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
         if not torch.is_grad_enabled():
             # inference: persistent cooperative HIP GRU (one launch per layer instead of ~6 per step/direction)

@@ -15,9 +15,9 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libgvd_hip.so')
 STAMP = LIB + '.srchash'
-SOURCES = ['gemm_f32.hip', 'gemv_f32.hip', 'attention.hip', 'vocab.hip', 'decode.hip', 'decode_persistent.hip',
-           'targets.hip', 'prof.hip', 'backward.hip', 'gru.hip', 'rowwise.hip', 'flash_attn.hip', 'ingest.hip']
-HEADERS = ['gvd_common.h', 'gemv_f32.h', 'top2.h', 'decode_persistent.h']
+SOURCES = ['gemm_f32.hip', 'gemm_pipe.hip', 'gemv_f32.hip', 'attention.hip', 'vocab.hip', 'decode.hip', 'decode_persistent.hip',
+           'targets.hip', 'prof.hip', 'backward.hip', 'gru.hip', 'rowwise.hip', 'flash_attn.hip', 'flash_attn_pad.hip', 'ingest.hip']
+HEADERS = ['gvd_common.h', 'gemm_common.h', 'gemv_f32.h', 'top2.h', 'decode_persistent.h']
 CFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
 # decode_persistent.hip keeps ~150 weight registers per lane for the whole launch; the SLP vectorizer would pair its
 # accumulators into v_pk_fma_f32 and splat every resident weight into a register PAIR (2x the footprint -> spills)

@@ -1,0 +1,234 @@
+// Fused multi-head self-attention of the `obj_interact` encoder (transformer.py:90-123 as configured at
+// model.py:126-135) over PADDED heads: the fused QKV projection (one GEMM against the row-permuted weights
+// [wq | wk | wv], att_model.py) writes every head of q, k and v into its own 176-column slot (171 / 169 real columns,
+// the rest exactly zero because the matching weight rows are zero), so every head starts on a 16-byte boundary.
+// That removes what held the first flash kernels (flash_attn.hip) at 62 % MFMA-busy:
+//   * K/V tiles are fetched with 16-byte buffer loads and staged with ds_write_b128 - 6 loads + 6 LDS writes per lane
+//     and key tile instead of 48 + 48 dword accesses with per-element column predicates (pads need no masking:
+//     they are zeros in memory; rows past R read as zero through the buffer bound and are masked to -inf);
+//   * eight waves (128 queries) share one K/V tile: half the staging work and half the K/V L2 traffic per query;
+//   * LDS holds THREE tile buffers with ONE barrier per key tile, placed before the second half of the PV product, so
+//     the barrier wait and the next tile's write pass sit under 44 MFMAs (three buffers because that second half still
+//     reads the current tile after the barrier: the buffer overwritten in iteration j held tile j-2, whose last reads
+//     every wave finished before it arrived at barrier j-1); two waves per SIMD cover the softmax VALU work.
+// Arithmetic is the 16x16x4 fp32-MFMA scheme of flash_attn16_kernel (swapped products S^T = K Q^T, O^T = V^T P^T,
+// lane-local online softmax in the log2 domain, exact skip of the identity rescale): same values.
+#include "gvd_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int DP = 176;             // padded head width: 11 MFMA k-blocks / output row tiles of 16
+constexpr int LD = 180;             // LDS row stride (floats): 16-byte multiple, conflict-free fragment reads
+constexpr int TK = 32;              // keys per tile
+constexpr int NW = 8;               // waves per workgroup (16 queries each)
+constexpr int NT = NW * 64;
+constexpr int NSB = DP / 16;        // 11
+constexpr int F4_PER_TILE = TK * DP / 4;              // 1408 16-byte pieces per operand tile
+constexpr int NLD = (F4_PER_TILE + NT - 1) / NT;      // 3 loads per thread per operand (the last round is partial)
+
+struct PParams {
+  const float* q; const float* k; const float* v; float* o;
+  int64_t ld, ldo;       // row strides (floats) of q/k/v and of o
+  int B, R, n_heads;
+  float qscale;          // 1/sqrt(d_model) (a power of two in the reference configuration) times log2(e)
+};
+
+__global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[3 * 2 * TK * LD];       // [buf][K|V][32][180] = 138,240 B
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c16 = lane & 15, g = lane >> 4;
+  // linear workgroup id, XCD-aware: the query tiles of one (sample, head) run on ONE XCD so its K/V slices are fetched
+  // into that L2 once
+  const unsigned nqt = (unsigned)((p.R + 16 * NW - 1) / (16 * NW));
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = lid % nqt;
+  const int h = (lid / nqt) % p.n_heads;
+  const int b = lid / (nqt * p.n_heads);
+  const int R = p.R;
+  const int64_t ld = p.ld;
+  const unsigned span = (unsigned)((int64_t)R * ld * 4);                     // bytes of one sample's rows: loads past
+  __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(            // row R-1 return zeros
+      const_cast<float*>(p.q + (int64_t)b * R * ld + h * DP), 0, span - 4u * h * DP, 0x00020000);
+  __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.k + (int64_t)b * R * ld + h * DP), 0, span - 4u * h * DP, 0x00020000);
+  __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.v + (int64_t)b * R * ld + h * DP), 0, span - 4u * h * DP, 0x00020000);
+  const int qrow = qt * (16 * NW) + wave * 16 + c16;
+  const unsigned ld4 = (unsigned)ld * 4u;
+
+  // Q as the MFMA B operand: qreg[sb][t] = Q[qrow][16 sb + 4 g + t], pre-multiplied into the log2 domain
+  f32x4 qreg[NSB];
+#pragma unroll
+  for (int sb = 0; sb < NSB; ++sb) {
+    f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * ld4 + 64u * sb + 16u * g, 0, 0));
+    qreg[sb] = v * p.qscale;
+  }
+
+  // staging role: piece idx = tid + NT i of a 32 x 176 tile -> (row, 16-byte column chunk)
+  unsigned voff[NLD], loff[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = tid + NT * i;
+    const int row = idx / (DP / 4), c4 = idx % (DP / 4);
+    voff[i] = (unsigned)row * ld4 + 16u * c4;
+    loff[i] = (unsigned)(row * LD + 4 * c4);
+  }
+  const bool last_ok = tid + NT * (NLD - 1) < F4_PER_TILE;                   // the third round covers 384 threads
+  f32x4 gk[NLD], gv[NLD];
+  auto fetch = [&](int key0) {
+    const unsigned so = (unsigned)key0 * ld4;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      if (i + 1 < NLD || last_ok) {
+        gk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, voff[i], so, 0));
+        gv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, voff[i], so, 0));
+      }
+    }
+  };
+  auto stage = [&](int buf) {
+    float* kd = smem + buf * (2 * TK * LD);
+    float* vd = kd + TK * LD;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      if (i + 1 < NLD || last_ok) {
+        *reinterpret_cast<f32x4*>(kd + loff[i]) = gk[i];
+        *reinterpret_cast<f32x4*>(vd + loff[i]) = gv[i];
+      }
+    }
+  };
+
+  f32x4 oacc[NSB];
+#pragma unroll
+  for (int dt = 0; dt < NSB; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (R + TK - 1) / TK;
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  int buf = 0;
+  // first K fragments of the next tile, read right after the barrier that publishes it (under the last 44 MFMAs)
+  f32x4 kpre[2];
+  kpre[0] = *reinterpret_cast<const f32x4*>(smem + c16 * LD + 4 * g);
+  kpre[1] = *reinterpret_cast<const f32x4*>(smem + (c16 + 16) * LD + 4 * g);
+#pragma unroll 1
+  for (int jt = 0; jt < ntiles; ++jt) {
+    const int key0 = jt * TK;
+    const bool more = jt + 1 < ntiles;                                     // wave-uniform
+    if (more) fetch(key0 + TK);                                            // flies under this tile's MFMAs
+    const float* sk = smem + buf * (2 * TK * LD);
+    const float* sv = sk + TK * LD;
+
+    // ---- S^T for the two 16-key sub-tiles.  The two accumulator chains alternate (16x16x4: 40-cycle dependent latency
+    // against a 32-cycle issue interval); the K fragments of k-block sb+1 are read while block sb multiplies (the
+    // compiler on its own reads each fragment right before its use and stalls on it: that, not the softmax, is what
+    // held the first kernels at 62 % matrix-pipe utilisation).
+    f32x4 sacc[2];
+    sacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    sacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* kp0 = sk + c16 * LD + 4 * g;
+    const float* kp1 = kp0 + 16 * LD;
+    f32x4 ka[2][2];
+    ka[0][0] = kpre[0];
+    ka[0][1] = kpre[1];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) {
+      if (sb + 1 < NSB) {
+        ka[(sb + 1) & 1][0] = *reinterpret_cast<const f32x4*>(kp0 + 16 * (sb + 1));
+        ka[(sb + 1) & 1][1] = *reinterpret_cast<const f32x4*>(kp1 + 16 * (sb + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[sb & 1][0][t], qreg[sb][t], sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[sb & 1][1][t], qreg[sb][t], sacc[1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // V fragments of PV step 0 (key 4 g of sub-tile 0) do not depend on the softmax: fetch them under it
+    float vf[2][NSB];
+    auto vload = [&](float (&dst)[NSB], int step) {          // step = 4 u + s4 -> key 16 u + 4 g + s4
+      const float* vp = sv + (16 * (step >> 2) + 4 * g + (step & 3)) * LD + c16;
+#pragma unroll
+      for (int dt = 0; dt < NSB; ++dt) dst[dt] = vp[16 * dt];
+    };
+    vload(vf[0], 0);
+    // ---- online softmax: this lane holds keys 16 u + 4 g + reg of its query
+    float mt = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (key0 + 16 * u + 4 * g + r >= R) sacc[u][r] = -INFINITY;
+        mt = fmaxf(mt, sacc[u][r]);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, GVD_WAVE));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, GVD_WAVE));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sacc[u][r] = __builtin_amdgcn_exp2f(sacc[u][r] - m_new);
+        psum += sacc[u][r];
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int dt = 0; dt < NSB; ++dt) oacc[dt] *= alpha;
+    }
+    // ---- O^T += V^T P^T: step = 4 u + s4 contracts key 16 u + 4 g + s4 = score register s4 of sub-tile u; the V
+    // fragments of step+1 are read while step multiplies.  Between steps 3 and 4: LDS write pass of the next tile +
+    // the tile's only barrier (the reads of step 4 are already in flight; steps 4..7 still read `buf`).
+    const int nxt = buf == 2 ? 0 : buf + 1;
+#pragma unroll
+    for (int step = 0; step < 8; ++step) {
+      if (step + 1 < 8) vload(vf[(step + 1) & 1], step + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < NSB; ++dt)
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[step & 1][dt], sacc[step >> 2][step & 3], oacc[dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (step == 3) {
+        if (more) stage(nxt);              // held tile jt-2: every wave finished it before arriving at the last barrier
+        __syncthreads();
+        const float* nk = smem + nxt * (2 * TK * LD) + c16 * LD + 4 * g;     // (stale but harmless after the last tile)
+        kpre[0] = *reinterpret_cast<const f32x4*>(nk);
+        kpre[1] = *reinterpret_cast<const f32x4*>(nk + 16 * LD);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    buf = nxt;
+  }
+
+  float l_tot = l_run + __shfl_xor(l_run, 16, GVD_WAVE);
+  l_tot += __shfl_xor(l_tot, 32, GVD_WAVE);
+  const float inv = 1.0f / l_tot;
+  if (qrow < R) {
+    float* orow = p.o + ((int64_t)b * R + qrow) * p.ldo + h * DP + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < NSB; ++dt) *reinterpret_cast<f32x4*>(orow + 16 * dt) = oacc[dt] * inv;
+  }
+}
+
+}  // namespace
+
+extern "C" int gvd_flash_attn_padded_f32(const float* q, const float* k, const float* v, int64_t ld, float* o, int64_t ldo,
+                                         int B, int R, int n_heads, int head_pad, float scale, gvd_stream_t stream) {
+  if (!q || !k || !v || !o || B <= 0 || R <= 0 || n_heads <= 0 || head_pad != DP || (ld % 4) != 0 || (ldo % 4) != 0 ||
+      !gvd_aligned16(q) || !gvd_aligned16(k) || !gvd_aligned16(v) || !gvd_aligned16(o) || ld < (int64_t)n_heads * DP ||
+      ldo < (int64_t)n_heads * DP || (int64_t)R * ld * 4 >= (int64_t)1 << 31)
+    return GVD_EINVAL;
+  PParams p = {};
+  p.q = q; p.k = k; p.v = v; p.o = o; p.ld = ld; p.ldo = ldo; p.B = B; p.R = R; p.n_heads = n_heads;
+  p.qscale = 1.4426950408889634f * scale;
+  const unsigned nwg = (unsigned)((R + 16 * NW - 1) / (16 * NW)) * n_heads * B;
+  hipLaunchKernelGGL(flash_attn_pad_kernel, dim3(nwg), dim3(NT), 0, gvd_s(stream), p);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}

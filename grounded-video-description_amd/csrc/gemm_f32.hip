@@ -15,35 +15,13 @@
 // permutation of the summation order only.  The f32 MFMA issues every 64 cycles per SIMD, so LDS and
 // global traffic hide completely behind the matrix pipe.  Workgroup ids are remapped XCD-aware so the
 // tiles that share an A panel land on one XCD's L2.
-#include "gvd_common.h"
+#include "gemm_common.h"
 #include "gemv_f32.h"
 #include <stdlib.h>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 namespace {
 
-constexpr int BK_MIN = 32;   // K granularity every segment must be a multiple of
-
-struct KParams {
-  const float* A[3]; int64_t lda[3]; int64_t abs_[3];
-  const float* W[3]; int64_t ldw[3]; int64_t wbs[3];
-  int K[3]; int nseg;
-  const float* nbias; const float* nbias2;
-  const float* mbias; int64_t mbias_bs;
-  const float* rowbias; int64_t rowbias_ld; int64_t rowbias_bs;
-  const uint8_t* mask; int64_t mask_ldm; int64_t mask_bs;
-  float* C; int64_t ldc; int64_t cbs;
-  int M, N, act;
-  // LSTM epilogue
-  const float* c_prev; int64_t ldcp;
-  float* h_out; int64_t ldh;
-  float* c_out; int64_t ldco;
-  float* gates_out; int64_t ldg;
-  int H;
-  int ntn, ntm;
-};
+constexpr int BK_MIN = GVD_GEMM_BK_MIN;
 
 template <int BM, int BN, int WGM, int WGN, bool LSTM, int NBUF = 2, int BK = 32>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
@@ -177,33 +155,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
   }
 
   if (!LSTM) {
-    float* Cb = p.C + (int64_t)bz * p.cbs;
-    const float* rb = p.rowbias ? p.rowbias + (int64_t)bz * p.rowbias_bs : nullptr;
-    const float* mb = p.mbias ? p.mbias + (int64_t)bz * p.mbias_bs : nullptr;
-    const uint8_t* mk = p.mask ? p.mask + (int64_t)bz * p.mask_bs : nullptr;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int gn = n0 + wn * WTN + j * 32 + r;
-        if (gn >= p.N) continue;
-        float nb = 0.f;
-        if (p.nbias) nb += p.nbias[gn];
-        if (p.nbias2) nb += p.nbias2[gn];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-          const int gm = m0 + wm * WTM + i * 32 + row;
-          if (gm < p.M) {
-            float v = acc[i][j][e] + nb;
-            if (mb) v += mb[gm];
-            if (rb) v += rb[(int64_t)gm * p.rowbias_ld + gn];
-            if (p.act == 1) v = fmaxf(v, 0.f);
-            if (mk && mk[(int64_t)gm * p.mask_ldm + gn]) v = GVD_MIN_VALUE;
-            Cb[(int64_t)gm * p.ldc + gn] = v;
-          }
-        }
-      }
+    gemm_epilogue_plain<TM, TN>(p, acc, bz, m0 + wm * WTM, n0 + wn * WTN, r, half);
   } else {
     // gates -> LDS tile G[BM][BN+1] (columns grouped i|f|g|o, HU units each), then the pointwise cell.
     constexpr int LDG = BN + 1;
@@ -301,7 +253,8 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
     // the double-buffered form on the fc7 shape (tools/gemm_micro.py); GVD_GEMM_VARIANT=0 selects the latter.
     // Tried and rejected: 64-deep K tiles (variant 2: no change, barriers are not the limit) and a 256x128 tile
     // (272 registers -> 1 wave/SIMD: 116 TF/s).  PMC: 81 % MFMA-busy vs rocBLAS 95 % with one pipelined wave/SIMD.
-    static const int variant = getenv("GVD_GEMM_VARIANT") ? atoi(getenv("GVD_GEMM_VARIANT")) : 1;
+    static const int variant = getenv("GVD_GEMM_VARIANT") ? atoi(getenv("GVD_GEMM_VARIANT")) : 3;
+    if (variant == 3) return gvd_gemm_pipe_launch(p, a->batch, st);      // software-pipelined kernel (gemm_pipe.hip)
     if (variant == 0) return launch<128, 128, 2, 2, false, 2>(p, a->batch, st);
     if (variant == 2) {      // 64-deep K tiles (half the barriers per flop); needs every segment K % 64 == 0
       bool ok64 = true;

@@ -1,0 +1,218 @@
+// Software-pipelined fp32-MFMA "NT" GEMM for the large per-segment projections of the hot path (fc7, class logits,
+// pool_embed, the obj_interact projections / feed-forward, ctx2pool: M = B*R rows, hundreds of tiles per CU).
+//
+//   C[b][M,N] = epi( sum_s A_s[b][M,K_s] * W_s[b][N,K_s]^T ),  128 x 128 output tile per workgroup, 32-deep k tiles
+//
+// Why a second kernel (gemm_f32.hip keeps the small/odd shapes and the LSTM epilogue): PMC on the general kernel showed
+// 81 % MFMA-busy against 95 % for the library kernel on the same shape.  Its k-loop spends the gap between two k tiles
+// in scalar segment look-ups, 64-bit address arithmetic, eight exec-masked loads, a register->LDS pass and two
+// barriers, all with the matrix pipe of that wave idle.  Here the loop carries nothing but loads, LDS traffic and MFMAs:
+//   * operands come through buffer loads: one SGPR descriptor per operand and segment, one precomputed 32-bit offset
+//     per (thread, row) and the k position as the scalar offset - no per-tile address VALU, no branches.  Rows past
+//     M / N are CLAMPED to the last valid row instead of zero-filled: their accumulators are never stored;
+//   * one barrier per k tile, placed BEFORE the tile's last quarter: order per tile is
+//         global loads (tile t+1) | MFMA q0 | MFMA q1 | MFMA q2 + LDS writes (tile t+1) | barrier |
+//         fragment reads (tile t+1, q0) | MFMA q3
+//     so the barrier wait, the LDS write pass and the first fragment reads of the next tile all sit under 16 MFMAs
+//     (1024 cycles) of the current one; fragment registers are double-buffered (q+1 is read while q multiplies);
+//   * epilogue through LDS: the wave's 64 x 64 block is transposed in its own LDS slice and leaves as 16-byte stores
+//     (4 rows x 256 B per instruction instead of 2 rows x 128 B of dword stores) when the output allows it.
+// Numerics are identical to gemm_f32.hip: the same v_mfma_f32_32x32x2_f32 chain in the same k order per output.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 4;
+constexpr int NLD = 4;                 // 16-byte loads per thread per operand per k tile (128 rows x 8 / 256)
+constexpr int EPI_LD = 68;             // padded row of the epilogue transpose slice (floats)
+
+struct Seg {
+  __amdgpu_buffer_rsrc_t ra, rw;
+  unsigned voa[NLD], vow[NLD];
+};
+
+template <bool EPI_LDS>
+__global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];     // 73,728 B -> two workgroups per CU
+  float* As = smem;
+  float* Ws = smem + 2 * BM * LDK;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn_ = lid % p.ntn, tm_ = lid / p.ntn;
+  const int bz = blockIdx.y;
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
+
+  // staging role: thread covers rows srow + 32 i (i < 4), 16-byte chunk kq of the 128-byte k slice of a row
+  const int srow = tid >> 3, kq = tid & 7;
+  int arow[NLD], wrow[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    arow[i] = min(m0 + srow + 32 * i, p.M - 1) - m0;       // clamp: rows past the edge re-read the last valid row
+    wrow[i] = min(n0 + srow + 32 * i, p.N - 1) - n0;
+  }
+
+  Seg sg;
+  int seg = 0, kpos = 0;                                    // position of the NEXT tile to fetch
+  const int kseg1 = p.K[1], kseg2 = p.K[2], nseg = p.nseg;  // (kept in SGPRs: no kernarg reload inside the k loop)
+  int kend = p.K[0];
+  auto seg_setup = [&](int s) {
+    sg.ra = gvd_rsrc(p.A[s] + (int64_t)bz * p.abs_[s] + (int64_t)m0 * p.lda[s]);
+    sg.rw = gvd_rsrc(p.W[s] + (int64_t)bz * p.wbs[s] + (int64_t)n0 * p.ldw[s]);
+    const unsigned lda4 = (unsigned)p.lda[s] * 4u, ldw4 = (unsigned)p.ldw[s] * 4u;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      sg.voa[i] = (unsigned)arow[i] * lda4 + 16u * kq;
+      sg.vow[i] = (unsigned)wrow[i] * ldw4 + 16u * kq;
+    }
+  };
+  seg_setup(0);
+
+  int nkt = 0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+    if (s < p.nseg) nkt += p.K[s] / BK;
+
+  f32x4 ga[NLD], gw[NLD];
+  auto fetch = [&]() {
+    const unsigned so = 4u * (unsigned)kpos;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      ga[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sg.ra, sg.voa[i], so, 0));
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      gw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sg.rw, sg.vow[i], so, 0));
+    kpos += BK;
+    if (kpos == kend && seg + 1 < nseg) {                  // wave-uniform, taken nseg-1 times per workgroup
+      ++seg;
+      kpos = 0;
+      kend = seg == 1 ? kseg1 : kseg2;
+      seg_setup(seg);
+    }
+  };
+  float* Ast = &As[srow * LDK + 4 * kq];
+  float* Wst = &Ws[srow * LDK + 4 * kq];
+  auto stage_part = [&](int buf, int i) {      // one A row and one W row of this thread's share of the tile
+    *reinterpret_cast<f32x4*>(Ast + (buf * BM + 32 * i) * LDK) = ga[i];
+    *reinterpret_cast<f32x4*>(Wst + (buf * BN + 32 * i) * LDK) = gw[i];
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) stage_part(buf, i);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment q (8 k values) of the tile in `buf`: lane (r, half) takes k = 8q + 4 half + t for MFMA step t
+  const float* Afr = &As[(wm * 64 + r) * LDK + half * 4];
+  const float* Wfr = &Ws[(wn * 64 + r) * LDK + half * 4];
+  auto frags = [&](f32x4 (&a)[2], f32x4 (&b)[2], int buf, int q) {
+    a[0] = *reinterpret_cast<const f32x4*>(Afr + buf * BM * LDK + q * 8);
+    a[1] = *reinterpret_cast<const f32x4*>(Afr + buf * BM * LDK + 32 * LDK + q * 8);
+    b[0] = *reinterpret_cast<const f32x4*>(Wfr + buf * BN * LDK + q * 8);
+    b[1] = *reinterpret_cast<const f32x4*>(Wfr + buf * BN * LDK + 32 * LDK + q * 8);
+    __builtin_amdgcn_sched_barrier(0);     // keep the reads AHEAD of the MFMAs that follow in program order
+  };
+  auto mfma4 = [&](const f32x4 (&a)[2], const f32x4 (&b)[2], int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+  };
+  auto mfma16 = [&](const f32x4 (&a)[2], const f32x4 (&b)[2]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) mfma4(a, b, t);
+  };
+
+  f32x4 a0[2], b0[2], a1[2], b1[2];
+  fetch();
+  stage(0);
+  __syncthreads();
+  frags(a0, b0, 0, 0);
+  int buf = 0;
+#pragma unroll 1
+  for (int kt = 0; kt + 1 < nkt; ++kt) {
+    fetch();                                   // tile kt+1: in flight under the first three quarters
+    frags(a1, b1, buf, 1);
+    mfma16(a0, b0);
+    frags(a0, b0, buf, 2);
+    mfma16(a1, b1);
+    frags(a1, b1, buf, 3);
+    // third quarter, with the LDS write pass of tile kt+1 spread between its MFMAs (nobody reads buf^1: its last reads
+    // preceded the previous barrier; the global loads were issued three quarters = ~3000 cycles ago)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      mfma4(a0, b0, t);
+      stage_part(buf ^ 1, t);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    frags(a0, b0, buf ^ 1, 0);
+    mfma16(a1, b1);
+    buf ^= 1;
+  }
+  frags(a1, b1, buf, 1);
+  mfma16(a0, b0);
+  frags(a0, b0, buf, 2);
+  mfma16(a1, b1);
+  frags(a1, b1, buf, 3);
+  mfma16(a0, b0);
+  mfma16(a1, b1);
+
+  if (!EPI_LDS) {
+    gemm_epilogue_plain<2, 2>(p, acc, bz, m0 + wm * 64, n0 + wn * 64, r, half);
+    return;
+  }
+  // ---- epilogue through LDS (bias / bias2 / ReLU only; N % 4 == 0, ldc % 4 == 0, C 16-byte aligned)
+  __syncthreads();                                             // every wave finished reading the operand tiles
+  float* T = smem + wave * 64 * EPI_LD;                        // this wave's private 64 x 64 slice
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        T[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * EPI_LD + j * 32 + r] = acc[i][j][e];
+  const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+  const int gn = n0 + wn * 64 + c4;
+  f32x4 nb = {0.f, 0.f, 0.f, 0.f};
+  if (gn < p.N) {
+    if (p.nbias) nb = *reinterpret_cast<const f32x4*>(p.nbias + gn);
+    if (p.nbias2) nb += *reinterpret_cast<const f32x4*>(p.nbias2 + gn);
+  }
+  float* Cb = p.C + (int64_t)bz * p.cbs;
+  const bool relu = p.act == 1;
+  // (DS operations of one wave execute in order: its reads below see its own writes above)
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 4 + rsub;
+    const int gm = m0 + wm * 64 + row;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&T[row * EPI_LD + c4]) + nb;
+    if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    if (gm < p.M && gn < p.N) *reinterpret_cast<f32x4*>(Cb + (int64_t)gm * p.ldc + gn) = v;
+  }
+}
+
+}  // namespace
+
+int gvd_gemm_pipe_launch(KParams& p, int batch, hipStream_t st) {
+  p.ntm = (p.M + BM - 1) / BM;
+  p.ntn = (p.N + BN - 1) / BN;
+  dim3 grid((unsigned)(p.ntm * p.ntn), (unsigned)batch);
+  const bool lds_epi = !p.mbias && !p.rowbias && !p.mask && (p.N % 4) == 0 && (p.ldc % 4) == 0 && (p.cbs % 4) == 0 &&
+                       gvd_aligned16(p.C) && (!p.nbias || gvd_aligned16(p.nbias)) && (!p.nbias2 || gvd_aligned16(p.nbias2));
+  if (lds_epi) hipLaunchKernelGGL(gemm_pipe_kernel<true>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(gemm_pipe_kernel<false>, grid, dim3(256), 0, st, p);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}

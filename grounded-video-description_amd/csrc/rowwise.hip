@@ -65,13 +65,15 @@ __global__ __launch_bounds__(256) void region_feature_rows_kernel(const float* _
                                                                   const float* __restrict__ logits, int n_cls,
                                                                   const uint8_t* __restrict__ row_mask,
                                                                   int64_t mask_row_div, int64_t mask_ld,
-                                                                  float* __restrict__ out, float* __restrict__ sim_out,
-                                                                  int64_t rows, float ln_eps) {
+                                                                  float* __restrict__ out, int64_t out_ld,
+                                                                  float* __restrict__ sim_out, int64_t rows,
+                                                                  float ln_eps) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const int out_ld = RF_G + n_loc + n_cls;
   float* o = out + row * out_ld;
+  // pad columns (out_ld > 2048 + n_loc + n_cls: the K-padded operand of the pool_embed GEMM) are zero
+  for (int c = RF_G + n_loc + n_cls + lane; c < out_ld; c += 64) o[c] = 0.f;
 
   // ---- segment 1: F.layer_norm over the 2048 fc7 features (biased variance, eps inside the sqrt, no affine)
   {
@@ -90,11 +92,21 @@ __global__ __launch_bounds__(256) void region_feature_rows_kernel(const float* _
 #pragma unroll
       for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q = fmaf(d, d, q); }
     const float rstd = rsqrtf(wave_sum(q) / RF_G + ln_eps);
-    // output rows are 2781 floats: not 16-byte aligned -> scalar stores, lane-contiguous (coalesced)
+    if ((out_ld & 3) == 0) {               // padded rows are 16-byte aligned: vector stores
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i) {
+        f32x4 r;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) o[i * 256 + 4 * lane + k] = (v[i][k] - mean) * rstd;
+        for (int k = 0; k < 4; ++k) r[k] = (v[i][k] - mean) * rstd;
+        *reinterpret_cast<f32x4*>(o + i * 256 + 4 * lane) = r;
+      }
+    } else {
+      // rows of 2781 floats are not 16-byte aligned -> scalar stores, lane-contiguous (coalesced)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[i * 256 + 4 * lane + k] = (v[i][k] - mean) * rstd;
+    }
   }
   // ---- segment 2: layer_norm over the location embedding (n_loc = 300)
   {
@@ -183,15 +195,16 @@ extern "C" int gvd_add_layernorm_unbiased(const float* x, const float* y, const 
 
 extern "C" int gvd_region_feature_rows(const float* g_pool, const float* loc, int n_loc, const float* sim_logits,
                                        int n_cls, const uint8_t* row_mask, int64_t mask_rows_per_batch,
-                                       int64_t mask_ld, float* out, float* sim_out, int64_t rows, int G, float ln_eps,
-                                       gvd_stream_t stream) {
+                                       int64_t mask_ld, float* out, int64_t out_ld, float* sim_out, int64_t rows, int G,
+                                       float ln_eps, gvd_stream_t stream) {
   if (!g_pool || !loc || !sim_logits || !out || rows <= 0 || G != RF_G || n_loc <= 0 || n_loc > 64 * RF_MAXC ||
-      n_cls <= 0 || n_cls > 64 * RF_MAXC || !gvd_aligned16(g_pool))
+      n_cls <= 0 || n_cls > 64 * RF_MAXC || !gvd_aligned16(g_pool) || out_ld < G + n_loc + n_cls ||
+      ((out_ld & 3) == 0 && !gvd_aligned16(out)))
     return GVD_EINVAL;
   if (row_mask && mask_rows_per_batch <= 0) return GVD_EINVAL;
   hipLaunchKernelGGL(region_feature_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, gvd_s(stream), g_pool,
-                     loc, n_loc, sim_logits, n_cls, row_mask, row_mask ? mask_rows_per_batch : 1, mask_ld, out, sim_out,
-                     rows, ln_eps);
+                     loc, n_loc, sim_logits, n_cls, row_mask, row_mask ? mask_rows_per_batch : 1, mask_ld, out, out_ld,
+                     sim_out, rows, ln_eps);
   GVD_CHECK_LAUNCH();
   return 0;
 }

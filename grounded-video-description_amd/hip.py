@@ -89,9 +89,11 @@ _SIG = {
     'gvd_add_layernorm_unbiased': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_float,
                                              C.c_void_p]),
     'gvd_region_feature_rows': (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_u8p, C.c_int64, C.c_int64,
-                                          c_f32p, c_f32p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+                                          c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     'gvd_flash_attn_f32': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int64, C.c_int,
                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
+    'gvd_flash_attn_padded_f32': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_float, C.c_void_p]),
     'gvd_grid_sync_words': (C.c_int, []),
     'gvd_gru_bidir_layer': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p]),

@@ -509,20 +509,22 @@ def add_layernorm_unbiased(x, y, gamma, beta, eps=1e-6):
     return out.view_as(x)
 
 
-def region_feature_rows(g_pool, loc, sim_logits_t, pnt_mask, ln_eps=1e-5):
+def region_feature_rows(g_pool, loc, sim_logits_t, pnt_mask, ln_eps=1e-5, pad_to=1):
     """[LN(g_pool) | LN(loc) | LN(softmax_classes(masked sim logits))] per proposal (model.py:336-364) in one pass.
     g_pool [B,R,2048], loc [B,R,n_loc], sim_logits_t [B,R,D1] (class-last), pnt_mask u8 [B,R+1].
-    Returns pool_in [B,R,2048+n_loc+D1] and the class distribution sim_t [B,R,D1]."""
+    Returns pool_in [B,R,K] (K = 2048+n_loc+D1 rounded up to a multiple of `pad_to`, pad columns zero) and the class
+    distribution sim_t [B,R,D1]."""
     require_cuda_f32(g_pool, loc, sim_logits_t)
     B, R, G = g_pool.shape
     n_loc, n_cls = loc.shape[-1], sim_logits_t.shape[-1]
     assert g_pool.is_contiguous() and loc.is_contiguous() and sim_logits_t.is_contiguous()
     assert pnt_mask.dtype == torch.uint8 and pnt_mask.is_contiguous() and pnt_mask.shape == (B, R + 1)
-    out = torch.empty(B, R, G + n_loc + n_cls, device=g_pool.device, dtype=torch.float32)
+    K = (G + n_loc + n_cls + pad_to - 1) // pad_to * pad_to
+    out = torch.empty(B, R, K, device=g_pool.device, dtype=torch.float32)
     sim = torch.empty(B, R, n_cls, device=g_pool.device, dtype=torch.float32)
     mask_ptr = C.c_void_p(pnt_mask.data_ptr() + 1)              # skip the legacy pad column (main.py:227)
     check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(sim_logits_t), n_cls, mask_ptr, R, R + 1,
-                                        ptr(out), ptr(sim), B * R, G, ln_eps, stream_ptr()), 'gvd_region_feature_rows')
+                                        ptr(out), K, ptr(sim), B * R, G, ln_eps, stream_ptr()), 'gvd_region_feature_rows')
     return out, sim
 
 
@@ -537,4 +539,23 @@ def flash_attn_heads(q, k, v, head_sizes):
     w = (C.c_int * n)(*head_sizes)
     check(lib().gvd_flash_attn_f32(ptr(q), ptr(k), ptr(v), ptr(o), B, R, D, n, c0, w, stream_ptr()),
           'gvd_flash_attn_f32')
+    return o
+
+
+HEAD_PAD = 176      # padded head width of the fused obj_interact attention (11 MFMA k-blocks of 16)
+
+
+def flash_attn_padded(qkv, n_heads, scale):
+    """softmax(scale * q_h k_h^T) v_h for the heads of a fused, head-padded projection: qkv [B,R,3*n_heads*176] holds
+    [q | k | v], head h of each in columns [176 h, 176 h + width) with zero pads (att_model packs the weights that way).
+    Returns o [B,R,n_heads*176] in the same padded layout."""
+    require_cuda_f32(qkv)
+    B, R, W3 = qkv.shape
+    W = n_heads * HEAD_PAD
+    assert W3 == 3 * W and qkv.is_contiguous()
+    o = torch.empty(B, R, W, device=qkv.device, dtype=torch.float32)
+    base = qkv.data_ptr()
+    check(lib().gvd_flash_attn_padded_f32(C.c_void_p(base), C.c_void_p(base + 4 * W), C.c_void_p(base + 8 * W), W3,
+                                          ptr(o), W, B, R, n_heads, HEAD_PAD, scale, stream_ptr()),
+          'gvd_flash_attn_padded_f32')
     return o

@@ -156,11 +156,12 @@ int gvd_add_layernorm_unbiased(const float* x, const float* y, const float* gamm
 /* Per proposal row (model.py:336-364): p = softmax over the n_cls similarity logits (all -1e8 when the row is
  * masked: row_mask[(row / mask_rows_per_batch) * mask_ld + row % mask_rows_per_batch] != 0), written to sim_out
  * [rows,n_cls] (optional); out[row] = [layer_norm(g_pool row, G=2048) | layer_norm(loc row, n_loc) |
- * layer_norm(p, n_cls)] with out leading dimension G + n_loc + n_cls.  F.layer_norm semantics (biased variance,
- * eps inside the sqrt, no affine). */
+ * layer_norm(p, n_cls) | zeros] with out leading dimension out_ld >= G + n_loc + n_cls (the zero pad makes the row a
+ * 16-byte-aligned, 32-multiple K operand for the pool_embed GEMM, model.py:384).  F.layer_norm semantics (biased
+ * variance, eps inside the sqrt, no affine). */
 int gvd_region_feature_rows(const float* g_pool, const float* loc, int n_loc, const float* sim_logits, int n_cls,
                             const uint8_t* row_mask, int64_t mask_rows_per_batch, int64_t mask_ld, float* out,
-                            float* sim_out, int64_t rows, int G, float ln_eps, gvd_stream_t stream);
+                            int64_t out_ld, float* sim_out, int64_t rows, int G, float ln_eps, gvd_stream_t stream);
 
 /* Fused multi-head self-attention of the obj_interact encoder (transformer.py:90-123; heads = Tensor.chunk of the
  * model width): o[b,:,c0_h:c0_h+w_h] = softmax(q_h k_h^T) v_h for every head h, flash-style in fp32 on the matrix
@@ -168,6 +169,14 @@ int gvd_region_feature_rows(const float* g_pool, const float* loc, int n_loc, co
  * (o may not alias them); head_col0/head_width: host arrays of n_heads (<= 8) entries, width <= 176. */
 int gvd_flash_attn_f32(const float* q, const float* k, const float* v, float* o, int B, int R, int64_t ld,
                        int n_heads, const int* head_col0, const int* head_width, gvd_stream_t stream);
+
+/* The same attention over PADDED heads (the inference path of the obj_interact encoder): head h of q, k, v occupies
+ * columns [h*head_pad, (h+1)*head_pad) of rows with stride ld, real columns first, pad columns exactly zero (the fused
+ * QKV projection against row-permuted, zero-padded weights writes them that way), so every head is 16-byte aligned.
+ * o: [B,R,ldo] in the same padded layout (pad columns come out zero).  scores = scale * q.k (scale = 1/sqrt(d_model),
+ * transformer.py:92,104).  head_pad must be 176; ld, ldo multiples of 4; all pointers 16-byte aligned. */
+int gvd_flash_attn_padded_f32(const float* q, const float* k, const float* v, int64_t ld, float* o, int64_t ldo, int B,
+                              int R, int n_heads, int head_pad, float scale, gvd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Frame-wise context encoder: one bidirectional GRU layer as a persistent cooperative kernel

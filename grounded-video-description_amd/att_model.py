@@ -313,7 +313,7 @@ class TopDownModel(nn.Module):
             sim_mat = sim_t.transpose(1, 2)          # [B,D1,R] view (the reference returns this layout)
             if own:
                 # pool_embed (model.py:384, K = 2781) on the MFMA GEMM: the row kernel wrote the concat zero-padded to
-                # K = 2816 (16-byte aligned rows, 32-multiple K); the weight gets matching zero columns once
+                # K = 2784 (16-byte aligned rows, 32-multiple K); the weight gets matching zero columns once
                 pw = self.pool_embed[0].weight
 
                 def build_pool(pw=pw, K=pool.shape[-1]):

@@ -293,7 +293,7 @@ def test_flash_attention_heads(B, R):
 
 
 @pytest.mark.parametrize('M,N,K,act', [(33000, 1024, 1024, 0), (32771, 2048, 2048, 1), (40001, 433, 2048, 0),
-                                       (36000, 3168, 1024, 0), (33000, 1024, 1056, 0), (33000, 1024, 2816, 1),
+                                       (36000, 3168, 1024, 0), (33000, 1024, 1056, 0), (33000, 1024, 2784, 1),
                                        (70000, 512, 1024, 0)])
 def test_gemm_pipe_kernel(M, N, K, act):
     """Large projections (>= 256 tiles of 128 x 128) run the software-pipelined kernel (gemm_pipe.hip): ragged M / N edges
@@ -381,7 +381,7 @@ def test_region_feature_rows_padded():
     pm = (torch.rand(B, R + 1, generator=g) < 0.3).to(torch.uint8).cuda()
     a, sa = ops.region_feature_rows(g_pool, loc, logits, pm)
     b, sb = ops.region_feature_rows(g_pool, loc, logits, pm, pad_to=32)
-    assert b.shape[-1] == 2816 and torch.equal(a, b[:, :, :2781]) and torch.equal(sa, sb)
+    assert b.shape[-1] == 2784 and torch.equal(a, b[:, :, :2781]) and torch.equal(sa, sb)
     assert float(b[:, :, 2781:].abs().max()) == 0.0
 
 

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 SHAPES = (  # M, N, K, act : B=256 per-segment projections
     (256000, 2048, 2048, 1),     # fc7
     (256000, 433, 2048, 0),      # class logits
-    (256000, 1024, 2816, 1),     # pool_embed (K padded 2781 -> 2816)
+    (256000, 1024, 2784, 1),     # pool_embed (K padded 2781 -> 2784)
     (256000, 3168, 1024, 0),     # fused q|k|v, heads padded to 176
     (256000, 1024, 1056, 0),     # wo over padded heads
     (256000, 512, 1024, 1),      # feed-forward 1 / ctx2pool

@@ -19,6 +19,7 @@ region_attn_mode='mix', transfer_mode='cls', t_attn_mode='bigru', seq_per_img=1,
 """
 import math
 import os
+import pickle
 
 import torch
 import torch.nn as nn
@@ -145,8 +146,64 @@ class TopDownModel(nn.Module):
         self.context_enc = nn.GRU(H, H // 2, 2, dropout=0.2, bidirectional=True, batch_first=True)
         self.ctx2pool_grd = nn.Sequential(nn.Linear(self.att_feat_size, self.vis_encoding_size), nn.ReLU(),
                                           nn.Dropout(p))
+        self._knowledge_transfer(opt)
         self.core = _Core(opt)
         self.flash_obj_interact = os.environ.get('GVD_FLASH', '1') == '1'   # inference: fused attention kernel
+        self._validate_dims(opt)
+
+    def _validate_dims(self, opt):
+        """The HIP kernels are specialised at compile time for the reference configuration (attention.hip: A = 512,
+        H = 1024; decode_persistent.hip: E = 512; flash kernels: 6 heads of <= 176 columns).  Fail at construction, not
+        with GVD_EINVAL in the middle of a forward."""
+        want = dict(rnn_size=1024, att_hid_size=512, input_encoding_size=512, att_feat_size=2048, fc_feat_size=3072)
+        bad = ['%s=%r (built for %r)' % (k, getattr(opt, k), v) for k, v in want.items() if getattr(opt, k) != v]
+        if opt.seq_length > 64 or opt.seq_length < 1:
+            bad.append('seq_length=%r (1..64)' % opt.seq_length)
+        if opt.num_prop_per_frm * opt.num_sampled_frm < 1:
+            bad.append('num_sampled_frm x num_prop_per_frm must be positive')
+        if not 0 <= self.unk_idx < self.vocab_size:
+            bad.append("wtoi['UNK']=%r outside the vocabulary" % self.unk_idx)
+        if bad:
+            raise NotImplementedError('TopDownModel: the MI355X kernels of libgvd_hip.so are built for the reference '
+                                      'dimensions (opts.py defaults); unsupported: ' + '; '.join(bad))
+
+    def _knowledge_transfer(self, opt):
+        """model.py:173-216 (`transfer_mode='cls'`): the Detectron fc7 layer initialises `ctx2pool_grd`, and every
+        object class takes the Detectron `cls_score` row / bias of its nearest Visual-Genome class (cosine similarity
+        of GloVe vectors) as its visual word `vis_embed` / `vis_classifiers_bias`.  Like the reference the pickles
+        are read relative to the CWD (`data/detectron_weights/{fc7_w,fc7_b,cls_score_w,cls_score_b}.pkl`); unlike the
+        reference (which raises FileNotFoundError) a missing directory leaves the default initialisation in place —
+        checkpoints overwrite these tensors anyway — and says so once."""
+        d = os.path.join('data', 'detectron_weights')
+        names = ('fc7_w', 'fc7_b', 'cls_score_w', 'cls_score_b')
+        if not all(os.path.exists(os.path.join(d, n + '.pkl')) for n in names):
+            if not getattr(TopDownModel, '_warned_no_transfer', False):
+                print('TopDownModel: %s/*.pkl not found - no Detectron knowledge transfer (model.py:173-216); '
+                      'load a checkpoint or provide the pickles' % d)
+                TopDownModel._warned_no_transfer = True
+            self.matched_cls = self.max_sim = None
+            return
+        load = {}
+        for n in names:
+            with open(os.path.join(d, n + '.pkl'), 'rb') as f:
+                load[n] = torch.from_numpy(pickle.load(f))
+        with torch.no_grad():
+            self.ctx2pool_grd[0].weight[:self.att_feat_size].copy_(load['fc7_w'])
+            self.ctx2pool_grd[0].bias[:self.att_feat_size].copy_(load['fc7_b'])
+            assert len(opt.itod) + 1 == opt.glove_clss.size(0)        # index 0 is background (model.py:189)
+            assert len(opt.vg_cls) == opt.glove_vg_cls.size(0)
+            vg = opt.glove_vg_cls / torch.norm(opt.glove_vg_cls, dim=1).unsqueeze(1)
+            cl = opt.glove_clss / torch.norm(opt.glove_clss, dim=1).unsqueeze(1)
+            max_sim, matched = torch.max(torch.matmul(vg, cl.transpose(1, 0)), dim=0)
+            self.max_sim, self.matched_cls = max_sim, matched
+            w, b = load['cls_score_w'], load['cls_score_b']
+            vis = opt.glove_clss.new_zeros(self.detect_size + 1, w.size(1))
+            bias = opt.glove_clss.new_zeros(self.detect_size + 1)
+            vis[0], bias[0] = w[0], b[0]                                  # background
+            vis[1:] = w[matched[1:]]
+            bias[1:] = b[matched[1:]]
+            self.vis_embed[0].weight.copy_(vis)
+            self.vis_classifiers_bias.copy_(bias)
 
     # ------------------------------------------------------------------ API (model.py:227-234)
     def forward(self, segs_feat, seq, gt_seq, num, ppls, gt_boxes, mask_boxes, ppls_feat, frm_mask,
@@ -377,12 +434,13 @@ class TopDownModel(nn.Module):
     def _sample(self, segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, opt={}):
         sample_max = opt.get('sample_max', 1)
         beam_size = opt.get('beam_size', 1)
-        if not sample_max:
-            raise NotImplementedError('multinomial sampling is outside the hot-path scope (greedy/beam only)')
         with torch.no_grad():
             pre = self._preamble(segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask)
             P = {k: v.detach() for k, v in self._decode_params().items()}
-            if beam_size > 1:
+            if not sample_max:
+                from . import sampling
+                seq, lps, att2 = sampling.multinomial_decode(self, pre, P, opt.get('temperature', 1.0))
+            elif beam_size > 1:
                 from . import beam
                 seq, lps, att2 = beam.beam_decode(self, pre, P, beam_size)
             else:

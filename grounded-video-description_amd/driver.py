@@ -8,6 +8,10 @@ model's inputs and outputs, without the dataset / metric submodules that are out
                          histories_<id>.pkl, interchangeable with the reference (same state_dict keys and shapes)
   train_epoch            main.py:197-311   loss bookkeeping around Trainer.step
   eval_split             main.py:313-452   inference loop over the feature-ingest pipeline + the two result JSON files
+  collect_gt_grounding / eval_grounding   main.py:87-194   'GRD' on the ground-truth sentences -> attn-gt-sent-results-*.json,
+                         grd-gt-sent-results-*.json and the per-class classification accuracy
+  run_epochs             main.py:678-743   epoch loop: LR decay schedule, train, validate every k epochs, model.pth /
+                         model-best.pth + infos/histories on improving validation score
 """
 import os
 import pickle
@@ -164,3 +168,135 @@ def eval_split(model, ingest_pipeline, records, batch_size, itow, opt, eval_opt=
                            'external_data': {'used': True, 'details': 'Object detector pre-trained on Visual Genome on '
                                                                       'object detection task.'}}, f)
     return predictions, grd_output
+
+
+def collect_gt_grounding(att2_ind, grd_ind, input_seqs, ppls, seg_ids, opt, itod, att2_output=None, grd_output=None,
+                         vocab_in_split=None):
+    """main.py:128-153 for one 'GRD' batch: the boxes of the attended (att2_ind) and grounded (grd_ind) proposals of every
+    grounded GT word (`input_seqs[:,0,1:,0] > vocab_size`), per frame, keyed like the reference's result files.
+    att2_ind / grd_ind: i64 [B,Lc,T] (model 'GRD' outputs); input_seqs [B,1,L+1,4]; ppls [B,R,7]."""
+    att2_output = defaultdict(dict) if att2_output is None else att2_output
+    grd_output = defaultdict(dict) if grd_output is None else grd_output
+    vocab_in_split = set() if vocab_in_split is None else vocab_in_split
+    T, P = opt.num_sampled_frm, opt.num_prop_per_frm
+    obj_mask = (input_seqs[:, 0, 1:, 0] > opt.vocab_size).cpu()                     # main.py:129
+    by_frame = ppls.view(-1, T, P, ppls.shape[-1]).permute(0, 2, 1, 3).contiguous()  # [B,P,T,7]
+
+    def boxes(ind):
+        B, Lc = ind.shape[0], ind.shape[1]
+        return torch.gather(by_frame, 1, ind.unsqueeze(-1).expand(B, Lc, T, ppls.shape[-1])).cpu()
+    b_att2, b_grd = boxes(att2_ind), boxes(grd_ind)
+    seq_cpu = input_seqs.cpu()
+    for i in range(obj_mask.shape[0]):
+        vid_id, seg_idx = seg_ids[i].split('_segment_')
+        seg_idx = str(int(seg_idx))
+        r_att2 = {'clss': [], 'idx_in_sent': [], 'bbox_for_all_frames': []}
+        r_grd = {'clss': [], 'idx_in_sent': [], 'bbox_for_all_frames': []}
+        for j in range(min(obj_mask.shape[1], b_att2.shape[1])):
+            if obj_mask[i, j]:
+                cls_name = itod[int(seq_cpu[i, 0, j + 1, 0]) - opt.vocab_size]
+                vocab_in_split.add(cls_name)
+                for r, bx in ((r_att2, b_att2), (r_grd, b_grd)):
+                    r['clss'].append(cls_name)
+                    r['idx_in_sent'].append(j)
+                    r['bbox_for_all_frames'].append(bx[i, j, :, :4].tolist())
+        att2_output[vid_id][seg_idx] = r_att2
+        grd_output[vid_id][seg_idx] = r_grd
+    return att2_output, grd_output, vocab_in_split
+
+
+def class_accuracy(cls_pred, vocab_in_split):
+    """main.py:166-171: mean over the classes of the split of the per-class hit rate of the region classifier.
+    cls_pred: i64 [N,2] rows (GT class, predicted class) concatenated over the split ('GRD' first output)."""
+    score = defaultdict(list)
+    hit = (cls_pred[:, 0] == cls_pred[:, 1]).long()
+    for c, h in zip(cls_pred[:, 0].tolist(), hit.tolist()):
+        score[c].append(h)
+    return sum(sum(h) * 1.0 / len(h) for h in score.values()) * 1.0 / max(len(vocab_in_split), 1), len(score)
+
+
+def eval_grounding(model, batches, opt, itod, out_dir=None, val_split='validation', evaluator=None):
+    """main.eval_grounding (main.py:87-194): 'GRD' over the ground-truth sentences of a split.  `batches` yields
+    (seg_ids, the 11 positional model inputs); mask_boxes may be the reference's dummy (main.py:122).  Writes
+    attn-gt-sent-results-<split>-<id>.json and grd-gt-sent-results-<split>-<id>.json (main.py:157-163) and returns
+    (attn_accu, grd_accu, cls_accu); the box-accuracy numbers come from `evaluator(attn_file, grd_file)` — the
+    reference's ANetGrdEval submodule is outside this repository — and are 0 without one / in test mode."""
+    import json
+    att2_output, grd_output, vocab = defaultdict(dict), defaultdict(dict), set()
+    cls_pred = []
+    model.eval()
+    with torch.no_grad():
+        for seg_ids, args in batches:
+            cp, att2_ind, grd_ind = model(*args, 'GRD')
+            collect_gt_grounding(att2_ind, grd_ind, args[1], args[4], seg_ids, opt, itod, att2_output, grd_output, vocab)
+            cls_pred.append(cp.cpu())
+    attn_file = grd_file = None
+    if out_dir is not None:
+        os.makedirs(out_dir, exist_ok=True)
+        ext = {'used': True, 'details': 'Object detector pre-trained on Visual Genome on object detection task.'}
+        attn_file = os.path.join(out_dir, 'attn-gt-sent-results-%s-%s.json' % (val_split, opt.id))
+        with open(attn_file, 'w') as f:
+            json.dump({'results': att2_output, 'eval_mode': 'GT', 'external_data': ext}, f)
+        grd_file = os.path.join(out_dir, 'grd-gt-sent-results-%s-%s.json' % (val_split, opt.id))
+        with open(grd_file, 'w') as f:
+            json.dump({'results': grd_output, 'eval_mode': 'GT', 'external_data': ext}, f)
+    if getattr(opt, 'test_mode', False):
+        return 0, 0, 0                                                  # main.py:187-194
+    cls_accu, _ = class_accuracy(torch.cat(cls_pred, 0), vocab) if cls_pred else (0.0, 0)
+    attn_accu = grd_accu = 0.0
+    if evaluator is not None and attn_file is not None:
+        attn_accu, grd_accu = evaluator(attn_file, grd_file)
+    return attn_accu, grd_accu, cls_accu
+
+
+def set_lr(optimizer, decay_factor):
+    """utils.set_lr (utils.py:155-157)."""
+    for group in optimizer.param_groups:
+        group['lr'] = group['lr'] * decay_factor
+
+
+def run_epochs(trainer, opt, train_batches, validate, checkpoint_path=None, infos=None, histories=None, itow=None,
+               log=print):
+    """The epoch loop of main.py:678-743 around `Trainer` (the reference's `train()` / `eval()` become the callables):
+      * learning-rate decay: for epoch > learning_rate_decay_start >= 0, every learning_rate_decay_every epochs every
+        group's lr and opt.learning_rate are multiplied by learning_rate_decay_rate (main.py:679-683);
+      * `train_batches(epoch)` yields the 11-tuples of one epoch (skipped under opt.inference_only);
+      * every val_every_epoch epochs `validate(epoch)` returns the language stats dict; its 'CIDEr' is the model
+        selection score: model.pth + infos/histories are written every validation, model-best.pth when it improves
+        (main.py:700-743).
+    Returns (infos, histories) exactly as they are pickled."""
+    infos = dict(infos or {})
+    histories = dict(histories or {})
+    best = infos.get('best_val_score', None)
+    start_epoch = infos.get('epoch', 0)
+    val_hist = histories.setdefault('val_result_history', {})
+    histories.setdefault('loss_history', {})
+    lr_hist = histories.setdefault('lr_history', {})
+    histories.setdefault('ss_prob_history', {})
+    for epoch in range(start_epoch, opt.max_epochs):
+        if epoch > opt.learning_rate_decay_start and opt.learning_rate_decay_start >= 0:
+            if (epoch - opt.learning_rate_decay_start) % opt.learning_rate_decay_every == 0:
+                set_lr(trainer.optimizer, opt.learning_rate_decay_rate)
+                opt.learning_rate = opt.learning_rate * opt.learning_rate_decay_rate
+        lr_hist[epoch] = opt.learning_rate
+        if not getattr(opt, 'inference_only', False):
+            means = train_epoch(trainer, train_batches(epoch), opt, log=log)
+            histories['loss_history'][epoch] = means[0]
+        if epoch % opt.val_every_epoch == 0:
+            with torch.no_grad():
+                lang_stats = validate(epoch)
+            if getattr(opt, 'inference_only', False):
+                break
+            score = lang_stats['CIDEr']
+            val_hist[epoch] = lang_stats
+            best_flag = best is None or score > best
+            if best_flag:
+                best = score
+            infos.update(iter=infos.get('iter', 0), epoch=epoch, best_val_score=best)
+            if checkpoint_path is not None:
+                save_checkpoint(trainer.model, opt, checkpoint_path, infos=infos, histories=histories, best=best_flag,
+                                itow=itow)
+                if log:
+                    log('model saved to %s%s' % (os.path.join(checkpoint_path, 'model.pth'),
+                                                  ' (best CIDEr %.3f)' % best if best_flag else ''))
+    return infos, histories

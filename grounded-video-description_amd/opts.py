@@ -19,7 +19,8 @@ _DEFAULTS = dict(
     obj_interact=True, w_att2=0.05, w_grd=0.0, w_cls=0.1, drop_prob_lm=0.5, seq_per_img=1,
     seq_length=20, beam_size=1, test_mode=False, enable_visdom=False, visdom_server='', id='',
     grad_clip=0.1, learning_rate=5e-4, optim='adam', optim_alpha=0.9, optim_beta=0.999,
-    weight_decay=0.0,
+    weight_decay=0.0, max_epochs=40, learning_rate_decay_start=1, learning_rate_decay_every=3,
+    learning_rate_decay_rate=0.8, val_every_epoch=2, inference_only=False, disp_interval=100,
     # data-derived in the reference (dataloader_anet.py:58,126); synthetic here
     vocab_size=5000, detect_size=432,
 )

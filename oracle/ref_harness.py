@@ -124,3 +124,23 @@ def reference_beam_sample(model, inp, beam_size):
     with beam_shim(model), torch.no_grad():
         return model._sample(inp['segs_feat'], inp['ppls'], inp['num'], inp['ppls_feat'], inp['sample_idx'],
                              inp['pnt_mask'], {'sample_max': 1, 'beam_size': beam_size})
+
+
+def construct_reference_fresh(opt, seed):
+    """`torch.manual_seed(seed); misc.AttModel.TopDownModel(opt)` in the harness work directory (synthetic Detectron
+    pickles) WITHOUT loading a state_dict: the reference's own initialisation incl. its knowledge transfer
+    (model.py:173-216).  Returns (model, workdir) so the caller can construct its own model in the same CWD."""
+    assert reference_available()
+    _install_uint8_mask_shim()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    cwd = os.getcwd()
+    _enter_workdir()
+    try:
+        from misc import AttModel  # noqa
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = AttModel.TopDownModel(opt)
+    finally:
+        os.chdir(cwd)
+    return model, _workdir

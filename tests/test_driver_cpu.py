@@ -81,3 +81,96 @@ def test_checkpoint_interchange_with_reference(tmp_path):
     assert infos['iter'] == 7 and infos['epoch'] == 2 and infos['vocab'] == {'1': 'a'}
     for k, v in again.state_dict().items():
         assert torch.equal(v, sd[k]), k
+
+
+@pytest.mark.skipif(not ref_harness.reference_available(), reason='no /root/reference here')
+def test_constructor_equals_reference_constructor_under_the_same_seed():
+    """Boundary: `TopDownModel(opt)` draws its parameters in the reference's order and performs the
+    Detectron / GloVe knowledge transfer (model.py:173-216) -> a freshly constructed model has the reference's
+    state_dict bit for bit under the same torch seed and the same data/detectron_weights pickles."""
+    import copy
+    opt = gvd_amd.opts.default_opt(vocab_size=97, t_attn_size=6)
+    ref, workdir = ref_harness.construct_reference_fresh(copy.deepcopy(opt), seed=5)
+    cwd = os.getcwd()
+    os.chdir(workdir)
+    try:
+        torch.manual_seed(5)
+        ours = att_model.TopDownModel(copy.deepcopy(opt))
+    finally:
+        os.chdir(cwd)
+    rsd, osd = ref.state_dict(), ours.state_dict()
+    assert list(rsd.keys()) == list(osd.keys())
+    for k in rsd:
+        assert torch.equal(rsd[k], osd[k]), k
+    assert torch.equal(ours.matched_cls, ref.matched_cls) and torch.equal(ours.max_sim, ref.max_sim)
+    # the transferred tensors really come from the pickles, not from the default init
+    assert float(osd['ctx2pool_grd.0.weight'].abs().max()) < 0.1 and float(osd['vis_embed.0.weight'].abs().max()) < 0.1
+
+
+def test_constructor_rejects_dimensions_the_kernels_are_not_built_for():
+    for kw in (dict(rnn_size=512), dict(att_hid_size=256), dict(input_encoding_size=300), dict(seq_length=100)):
+        with pytest.raises(NotImplementedError):
+            att_model.TopDownModel(gvd_amd.opts.default_opt(vocab_size=50, **kw))
+    with pytest.raises(NotImplementedError):
+        att_model.TopDownModel(gvd_amd.opts.default_opt(vocab_size=50, att_input_mode='region'))
+
+
+def test_gt_grounding_results_and_class_accuracy():
+    """collect_gt_grounding / class_accuracy vs the literal expressions of main.py:128-153,166-171."""
+    g = torch.Generator().manual_seed(3)
+    B, L, T, P, V = 3, 6, 2, 5, 40
+    opt = argparse.Namespace(num_sampled_frm=T, num_prop_per_frm=P, vocab_size=V, id='t')
+    itod = {i: 'cls%d' % i for i in range(1, 10)}
+    ppls = torch.rand(B, T * P, 7, generator=g)
+    iseq = torch.randint(1, V, (B, 1, L + 1, 4), generator=g)
+    iseq[0, 0, 2, 0] = V + 3
+    iseq[0, 0, 5, 0] = V + 1
+    iseq[2, 0, 1, 0] = V + 7
+    att2_ind = torch.randint(0, P, (B, L, T), generator=g)
+    grd_ind = torch.randint(0, P, (B, L, T), generator=g)
+    a, gr, vocab = driver.collect_gt_grounding(att2_ind, grd_ind, iseq, ppls, ['v1_segment_00', 'v1_segment_01', 'v2_segment_5'],
+                                               opt, itod)
+    ref_att2 = torch.gather(ppls.view(-1, T, P, 7).permute(0, 2, 1, 3).contiguous(), 1,
+                            att2_ind.unsqueeze(-1).expand((B, L, T, 7)))
+    assert vocab == {'cls3', 'cls1', 'cls7'}
+    assert a['v1']['0']['clss'] == ['cls3', 'cls1'] and a['v1']['0']['idx_in_sent'] == [1, 4]
+    assert a['v1']['0']['bbox_for_all_frames'][1] == ref_att2[0, 4, :, :4].tolist()
+    assert a['v1']['1'] == {'clss': [], 'idx_in_sent': [], 'bbox_for_all_frames': []}
+    assert gr['v2']['5']['clss'] == ['cls7'] and len(gr['v2']['5']['bbox_for_all_frames'][0]) == T
+    cls_pred = torch.tensor([[3, 3], [3, 2], [1, 1], [7, 0]])
+    acc, n = driver.class_accuracy(cls_pred, vocab)
+    assert n == 3 and abs(acc - (0.5 + 1.0 + 0.0) / 3) < 1e-12
+
+
+def test_run_epochs_schedule_and_checkpoints(tmp_path):
+    """Epoch loop of main.py:678-743: LR decay epochs, validation cadence, best-score checkpointing."""
+    opt = gvd_amd.opts.default_opt(vocab_size=30, id='ep', max_epochs=9, learning_rate_decay_start=1,
+                                   learning_rate_decay_every=3, learning_rate_decay_rate=0.5, val_every_epoch=2,
+                                   learning_rate=1.0)
+    lin = torch.nn.Linear(2, 2)
+
+    class FakeTrainer:
+        model = lin
+        optimizer = torch.optim.SGD([{'params': [lin.weight], 'lr': 1.0}, {'params': [lin.bias], 'lr': 0.1}])
+
+        def step(self, args):
+            return torch.tensor([1.0, 2.0, 3.0, 4.0])
+    scores = {0: 0.3, 2: 0.5, 4: 0.4, 6: 0.6, 8: 0.6}
+    seen = []
+
+    def validate(epoch):
+        seen.append((epoch, FakeTrainer.optimizer.param_groups[0]['lr'], FakeTrainer.optimizer.param_groups[1]['lr']))
+        return {'CIDEr': scores[epoch]}
+    infos, hist = driver.run_epochs(FakeTrainer(), opt, lambda e: [None, None], validate, checkpoint_path=str(tmp_path),
+                                    log=None)
+    # decay at epochs 4 and 7 ((epoch - 1) % 3 == 0 and epoch > 1), both groups scaled
+    assert [e for e, _, _ in seen] == [0, 2, 4, 6, 8]
+    assert [lr for _, lr, _ in seen] == [1.0, 1.0, 0.5, 0.5, 0.25]
+    assert abs(seen[-1][2] - 0.025) < 1e-12 and abs(opt.learning_rate - 0.25) < 1e-12
+    assert infos['best_val_score'] == 0.6 and infos['epoch'] == 8
+    assert sorted(hist['val_result_history']) == [0, 2, 4, 6, 8]
+    for f in ('model.pth', 'model-best.pth', 'infos_ep.pkl', 'infos_ep-best.pkl', 'histories_ep.pkl'):
+        assert os.path.isfile(os.path.join(str(tmp_path), f))
+    import pickle
+    with open(os.path.join(str(tmp_path), 'infos_ep-best.pkl'), 'rb') as f:
+        assert pickle.load(f)['epoch'] == 6                    # the tie at epoch 8 does not replace the best (strict >)

@@ -1,5 +1,7 @@
-"""Feature ingest for inference: from the reference's on-disk feature layout to the six
-tensors `model(..., 'sample')` receives, as a per-rank pinned-memory H2D pipeline.
+"""Feature ingest: from the reference's on-disk feature layout to the tensors the model
+receives — the six of `model(..., 'sample')` (InferenceIngest) and the eleven of `model(..., 'MLE')` (TrainIngest:
+captions -> input_seq / gt_seq, GT boxes, box and frame masks; dataloader_anet.py:212-334) — as a per-rank
+pinned-memory H2D pipeline.
 
 Contract reproduced (dataloader_anet.py:175-212,317-354 + default collate + main.py:339-347):
   <feature_root>/<seg_id>.npy            f32 [T, P, 2048]   fc6 region features  -> ppls_feat [B, Rb, 2048]
@@ -178,13 +180,19 @@ class InferenceIngest:
                     ppls[b, :n].copy_(slot.ppls[b, :n], non_blocking=True)
                 if f:
                     segs[b, :f].copy_(slot.segs[b, :f], non_blocking=True)
+            extra = self._device_extras(slot, ppls, Rb, dev)      # needs the proposals BEFORE masked rows are zeroed
             ops.zero_masked_rows(feat, mask, mask_off=1)
             ops.zero_masked_rows(ppls, mask, mask_off=1)
             ops.zero_masked_rows(segs, fmask)
             slot.free = torch.cuda.Event()
             slot.free.record(cs)
         cur.wait_stream(cs)
-        return dict(segs_feat=segs, num=num, ppls=ppls, ppls_feat=feat, sample_idx=sidx, pnt_mask=mask)
+        out = dict(segs_feat=segs, num=num, ppls=ppls, ppls_feat=feat, sample_idx=sidx, pnt_mask=mask)
+        out.update(extra)
+        return out
+
+    def _device_extras(self, slot, ppls, Rb, dev):
+        return {}
 
     def batches(self, records, batch_size):
         """Yield (records_of_batch, tensors) with the files of batch i+1 being read while batch i is consumed."""
@@ -204,3 +212,88 @@ class InferenceIngest:
         if not hasattr(self, '_outer'):
             self._outer = ThreadPoolExecutor(max_workers=1)
         return self._outer.submit(self.stage, records)
+
+
+class TrainIngest(InferenceIngest):
+    """The training half of the loader contract (dataloader_anet.py:212-334 + main.py:213-232) on top of the feature
+    pipeline: records additionally carry `caption` = the reference's caption-file entry {'caption': [words], 'clss':
+    [[class names] per box], 'idx': [[word positions] per box], 'bbox': [[x1,y1,x2,y2]], 'frm_idx': [frame per box]};
+    `vocab` = dict(wtoi: word -> index (str or int), wtod: class name -> 1-based detection index).
+    Emits, besides the six inference tensors: seq i64 [B,1,L+1,4] (col 0 = word id, or vocab_size + class for grounded
+    words; col 1 = 1/2 whether the class name is the word; col 2 = class; col 3 = word id of grounded words),
+    gt_seq i64 [B,10,L], gt_boxes f32 [B,NB,6], mask_boxes u8 [B,1,NB,L+1] (0 at a box's word position),
+    frm_mask u8 [B,Rb,NB] (1 = proposal and box on different frames) and num[:,2] = number of boxes; NB = batch
+    maximum (main.py:216-218).  The caption/box tensors are tiny and are built on the host; the [Rb,NB] frame mask is
+    formed on the GPU from the uploaded proposal frames — before the masked proposal rows are zeroed, as in the
+    reference (l.333 precedes l.343)."""
+
+    MAX_GT_BOX = 100                                                   # dataloader_anet.py:44
+
+    def __init__(self, opt, feature_root, seg_feature_root, vocab, **kw):
+        super().__init__(opt, feature_root, seg_feature_root, **kw)
+        self.wtoi = {w: int(i) for w, i in vocab['wtoi'].items()}
+        self.wtod = dict(vocab['wtod'])
+
+    def _caption_arrays(self, rec):
+        L, V = self.opt.seq_length, self.opt.vocab_size
+        cap = rec['caption']
+        words = cap['caption']
+        # one annotation per (box, label) whose word position is inside the caption window, numbered in file order
+        ann = [(pos, serial, b, name) for serial, (b, name, pos) in enumerate(
+            (b, name, cap['idx'][b][j]) for b, names in enumerate(cap['clss']) for j, name in enumerate(names)
+            if cap['idx'][b][j] < L)]
+        ann.sort(key=lambda a: a[0])                                   # by word position, stable
+        keep = []
+        for pos, serial, b, name in ann:
+            x1, y1, x2, y2 = cap['bbox'][b]
+            if not self.opt.test_mode and not ((x2 - x1 + 1) != 1 and (y2 - y1 + 1) != 1):
+                continue                                               # zero-area boxes are dropped (l.244-248)
+            keep.append((pos, serial, b, name))
+        seq = np.zeros((1, L + 1, 4), dtype=np.int64)
+        gts = np.zeros((10, L), dtype=np.int64)
+        n_w = min(len(words), L)
+        ids = np.array([self.wtoi[w] for w in words[:n_w]], dtype=np.int64)
+        seq[0, 1:1 + n_w, 0] = ids
+        gts[0, :n_w] = ids
+        for pos, serial, b, name in keep:                              # later annotations of a position overwrite earlier ones
+            d = self.wtod[name]
+            seq[0, pos + 1] = (V + d, (name != words[pos]) + 1, d, ids[pos])
+        n_box = min(len(keep), self.MAX_GT_BOX)
+        boxes = np.zeros((n_box, 6), dtype=np.float32)
+        bmask = np.ones((1, n_box, L + 1), dtype=np.uint8)
+        for i, (pos, serial, b, name) in enumerate(keep[:n_box]):
+            if self.opt.test_mode:
+                boxes[i] = (0, 0, 0, 0, -1, self.wtod[name])
+            else:
+                boxes[i] = tuple(cap['bbox'][b]) + (cap['frm_idx'][b], self.wtod[name])
+            bmask[0, i, pos + 1] = 0
+        return seq, gts, boxes, bmask
+
+    def stage(self, records):
+        slot = super().stage(records)
+        slot.train = [self._caption_arrays(r) for r in records]
+        for b, t in enumerate(slot.train):
+            slot.num[b, 2] = t[2].shape[0]
+        return slot
+
+    def _device_extras(self, slot, ppls, Rb, dev):
+        B, L = slot.B, self.opt.seq_length
+        NB = max(max(t[2].shape[0] for t in slot.train), 1)            # main.py:216-218
+        seq = torch.from_numpy(np.stack([t[0] for t in slot.train]))
+        gts = torch.from_numpy(np.stack([t[1] for t in slot.train]))
+        boxes = torch.zeros(B, NB, 6)
+        bmask = torch.ones(B, 1, NB, L + 1, dtype=torch.uint8)
+        nb = torch.zeros(B, dtype=torch.int64)
+        for b, t in enumerate(slot.train):
+            k = t[2].shape[0]
+            boxes[b, :k] = torch.from_numpy(t[2])
+            bmask[b, :, :k] = torch.from_numpy(t[3])
+            nb[b] = k
+        d = lambda x: x.to(dev, non_blocking=True)
+        seq, gts, boxes, bmask, nb = d(seq), d(gts), d(boxes), d(bmask), d(nb)
+        npps = d(torch.tensor(slot.n_pps[:B], dtype=torch.int64))
+        r_ok = torch.arange(Rb, device=dev).view(1, Rb, 1) < npps.view(B, 1, 1)
+        k_ok = torch.arange(NB, device=dev).view(1, 1, NB) < nb.view(B, 1, 1)
+        differ = ppls[:, :, 4].unsqueeze(2) != boxes[:, :, 4].unsqueeze(1)
+        frm = torch.where(r_ok & k_ok, differ, torch.ones_like(differ)).to(torch.uint8)
+        return dict(seq=seq, gt_seq=gts, gt_boxes=boxes, mask_boxes=bmask, frm_mask=frm)

@@ -54,6 +54,6 @@ class Trainer:
         loss = combine_losses(losses, self.opt)
         loss.backward()
         self.reducer.finish()
-        nn.utils.clip_grad_norm_(self.model.parameters(), self.opt.grad_clip)
+        self.last_grad_norm = float(nn.utils.clip_grad_norm_(self.model.parameters(), self.opt.grad_clip))
         self.optimizer.step()
         return torch.cat([l.detach() for l in losses])

@@ -33,6 +33,13 @@ CASES = {
                                          end_gain=3.0, end_bias=-1.5),
     'beam3_b4_v1000_ft480_t10_end': dict(mode='beam', B=4, V=1000, Ft=480, T=10, K=3, seed=11, profile='trained_like',
                                          end_gain=3.0, end_bias=-1.5),
+    # one optimisation step of main.train (main.py:234-266 + the optimizer of 660-677): loss assembly, clip 0.1, Adam
+    # with the two learning-rate groups -> per-parameter first moments and update norms
+    'step_b4_v1000_ft10_trained': dict(mode='step', B=4, V=1000, Ft=10, seed=12, profile='trained_like'),
+    # the loader contract (dataloader_anet.py:175-354 + main.py:213-232): outputs of the reference's REAL __getitem__ on
+    # the synthetic dataset of oracle/ingest_oracle.write_synthetic_dataset(seed) (oracle/ref_dataloader_harness.py)
+    'ingest_train_ft480_seed3': dict(mode='ingest', Ft=480, seed=3, V=61),
+    'ingest_train_ft10_seed5': dict(mode='ingest', Ft=10, seed=5, V=61),
     # BASELINE configs[2]: training step batch 64 (losses only)
     'mle_b64_v5000_ft10_trained': dict(mode='MLE', B=64, V=5000, Ft=10, seed=5, profile='trained_like'),
 }
@@ -40,6 +47,22 @@ CASES = {
 # loss weights used for the gradient fixtures (README.md:74-89 recipe + a non-zero w_grd so the
 # grounding branch contributes gradient)
 GRAD_WEIGHTS = dict(w_att2=0.05, w_grd=0.3, w_cls=0.1)
+
+
+INGEST_KEYS = ('segs_feat', 'num', 'ppls', 'ppls_feat', 'sample_idx', 'pnt_mask', 'seq', 'gt_seq', 'gt_boxes',
+               'mask_boxes', 'frm_mask')
+INGEST_SMALL = ('num', 'sample_idx', 'seq', 'gt_seq', 'gt_boxes', 'mask_boxes')     # stored whole; the rest as checksums
+
+
+def build_ingest_case(name, root):
+    """-> (opt, vocab, feature_root, seg_feature_root, records) of an 'ingest' case, files written under `root`."""
+    import importlib
+    pkg = importlib.import_module('grounded-video-description_amd')
+    from . import ingest_oracle
+    spec = CASES[name]
+    opt = pkg.opts.default_opt(t_attn_size=spec['Ft'], vocab_size=spec['V'])
+    fr, sr, recs = ingest_oracle.write_synthetic_dataset(root, opt, seed=spec['seed'])
+    return opt, ingest_oracle.synthetic_vocab(opt), fr, sr, recs
 
 
 def build_case(name):

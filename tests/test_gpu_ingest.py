@@ -1,11 +1,13 @@
 """-m gpu: the whole ingest pipeline (pinned staging -> async H2D of the valid rows -> gvd_zero_masked_rows) delivers
 byte-for-byte the tensors the restated reference dataloader + main.py hand to the model, and the model decodes them."""
+import os
+
 import pytest
 import torch
 
 import gvd_amd
 from gvd_amd import att_model, ingest, ops, synth
-from oracle import ingest_oracle as IO
+from oracle import cases, ingest_oracle as IO
 
 pytestmark = pytest.mark.gpu
 KEYS = ('segs_feat', 'num', 'ppls', 'ppls_feat', 'sample_idx', 'pnt_mask')
@@ -109,3 +111,35 @@ def test_eval_split_writes_the_reference_result_files(tmp_path):
             assert len(d['clss']) == len(d['idx_in_sent']) == len(d['bbox_for_all_frames'])
             for boxes in d['bbox_for_all_frames']:
                 assert len(boxes) == opt.num_sampled_frm and len(boxes[0]) == 4
+
+
+@pytest.mark.parametrize('name', [n for n, s in cases.CASES.items() if s['mode'] == 'ingest'])
+def test_train_pipeline_equals_reference_dataloader(name, golden_dir, tmp_path):
+    """TrainIngest (pinned staging, async H2D, padding / masking and the frame mask on the GPU) delivers bit for bit the
+    eleven tensors the reference's REAL dataloader + main.py produce (tests/golden/ingest_*.npz), and they train."""
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    opt, vocab, fr, sr, recs = cases.build_ingest_case(name, str(tmp_path))
+    ing = ingest.TrainIngest(opt, fr, sr, vocab, device=torch.device('cuda', 0), max_batch=len(recs), workers=4)
+    (chunk, t), = list(ing.batches(recs, len(recs)))
+    torch.cuda.synchronize()
+    for k in cases.INGEST_KEYS:
+        assert tuple(t[k].shape) == tuple(g['shape_' + k]), k
+        assert cases._bits_checksum(t[k].cpu()) == int(g['fp_' + k]), k
+        if k in cases.INGEST_SMALL:
+            assert np.array_equal(t[k].cpu().numpy(), g[k]), k
+    # and against the oracle on a sub-batch (different trimming: NB / Rb are batch maxima)
+    sub = [recs[2], recs[0]]
+    want = IO.assemble_train_batch(sub, vocab, fr, sr, opt)
+    got = ing.upload(ing.stage(sub))
+    for k in cases.INGEST_KEYS:
+        assert torch.equal(got[k].cpu(), want[k]), k
+    # the batch drives a training-mode forward (classes of the synthetic captions index the detection vocabulary)
+    opt.detect_size = 432
+    sd = synth.init_state_dict(opt, seed=2)
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    with torch.no_grad():
+        losses = model(*[t[k] for k in synth.FORWARD_ORDER], 'MLE')
+    assert all(torch.isfinite(l).all() for l in losses[:2])

@@ -129,6 +129,42 @@ def test_mle_edge_shapes_match_oracle(name):
         assert abs(got - want) / max(want, 1e-3) < 2e-3, '%s: |grad| %.6g vs oracle %.6g' % (n, got, want)
 
 
+STEP_CASES = [n for n, s in cases.CASES.items() if s['mode'] == 'step']
+
+
+@pytest.mark.parametrize('name', STEP_CASES)
+def test_one_optimisation_step_matches_reference(name, golden_dir):
+    """main.train's step (main.py:234-266 with the optimizer of 660-677) through train.Trainer on the HIP path vs the
+    reference's own step (tests/golden/step_*.npz, eval-mode arithmetic): loss assembly, clip_grad_norm_(0.1) (the
+    pre-clip total norm), Adam with lr x0.1 for the fc7 / vis_embed groups -> every parameter's first-moment norm
+    (linear in the clipped gradient) and update norm."""
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    opt, sd, inp = cases.build_case(name)
+    for k, v in cases.GRAD_WEIGHTS.items():
+        setattr(opt, k, v)
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    tr = train.Trainer(model, opt)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    losses = tr.step(synth.as_args(inp, 'cuda')).cpu().numpy()
+    np.testing.assert_allclose(losses, g['losses'], atol=1e-4)
+    assert abs(tr.last_grad_norm - float(g['total_grad_norm'])) / float(g['total_grad_norm']) < 2e-3
+    lrs = {id(gr['params'][0]): gr['lr'] for gr in tr.optimizer.param_groups}
+    params = dict(model.named_parameters())
+    assert abs(lrs[id(params['ctx2pool_grd.0.weight'])] - 5e-5) < 1e-12 and abs(lrs[id(params['logit.weight'])] - 5e-4) < 1e-12
+    for n, dn, mn in zip([str(x) for x in g['step_names']], g['delta_norms'], g['exp_avg_norms']):
+        p = params[n]
+        got_m = float(tr.optimizer.state[p]['exp_avg'].double().norm())
+        got_d = float((p.detach() - before[n]).double().norm())
+        assert abs(got_m - mn) / max(mn, 1e-7) < 3e-3, '%s: |exp_avg| %.6g vs reference %.6g' % (n, got_m, mn)
+        # the first Adam update is lr * g / (|g| + eps): elements whose gradient is rounding noise (~1e-8, e.g. the bias
+        # of a softmax-attention alpha_net) can take either sign, so the update norm gets a looser, lr-scaled bound
+        assert abs(got_d - dn) <= 0.02 * dn + 1e-9, '%s: |delta| %.6g vs reference %.6g' % (n, got_d, dn)
+    for n in ('core.i2h_2.weight', 'core.h2h_2.weight'):
+        assert torch.equal(params[n].detach(), before[n])
+
+
 def test_train_steps_reduce_loss():
     """Three optimisation steps (train mode: dropout + BN batch stats; Adam, clip 0.1) on one fixed batch."""
     opt = gvd_amd.opts.default_opt(vocab_size=1000, t_attn_size=10)

@@ -160,7 +160,8 @@ def test_one_optimisation_step_matches_reference(name, golden_dir):
         assert abs(got_m - mn) / max(mn, 1e-7) < 3e-3, '%s: |exp_avg| %.6g vs reference %.6g' % (n, got_m, mn)
         # the first Adam update is lr * g / (|g| + eps): elements whose gradient is rounding noise (~1e-8, e.g. the bias
         # of a softmax-attention alpha_net) can take either sign, so the update norm gets a looser, lr-scaled bound
-        assert abs(got_d - dn) <= 0.02 * dn + 1e-9, '%s: |delta| %.6g vs reference %.6g' % (n, got_d, dn)
+        if mn > 1e-6:      # (the softmax-shift-invariant alpha_net biases have an exactly-zero true gradient)
+            assert abs(got_d - dn) <= 0.02 * dn + 1e-9, '%s: |delta| %.6g vs reference %.6g' % (n, got_d, dn)
     for n in ('core.i2h_2.weight', 'core.h2h_2.weight'):
         assert torch.equal(params[n].detach(), before[n])
 

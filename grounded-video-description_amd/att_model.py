@@ -236,9 +236,17 @@ class TopDownModel(nn.Module):
         `forward(..., 'sample')` and `sample_pipelined`; callers of the private `_sample` (bench, tests) call it
         themselves after their timed region."""
         flags, self._kernel_flags = self._flags(), []
-        if not flags:
+        contract, self._contract_flags = self.__dict__.get('_contract_flags', []), []
+        if not flags and not contract:
             return
-        bad = int(torch.stack([f.reshape(-1).ne(0).sum() for f in flags]).sum())
+        counts = torch.stack([torch.stack([f.reshape(-1).ne(0).sum() for f in fl]).sum() if fl else
+                              torch.zeros((), dtype=torch.int64, device=(flags + contract)[0].device)
+                              for fl in (flags, contract)]).tolist()      # one device->host read
+        bad = counts[0]
+        if counts[1]:
+            raise GvdHipError('%d batch(es) had masked proposals (pnt_mask = 1) whose fc6 features / boxes are not zero. The '
+                              'compacted preamble relies on the loader contract (dataloader_anet.py:343-344 zeroes them); '
+                              'zero them or set GVD_COMPACT=0' % counts[1])
         if bad:
             raise GvdHipError('%d persistent-kernel launch(es) hit a grid-barrier timeout (workgroups not co-resident, '
                               'e.g. a shared GPU): results are invalid.  Re-run, or set GVD_PERSISTENT=0 / '
@@ -263,15 +271,18 @@ class TopDownModel(nn.Module):
             cache[key] = hit
         return hit[1]
 
-    def _obj_interact_fused(self, x):
+    def _obj_interact_fused(self, x, ci=None):
         """Inference path of the encoder on the HIP kernels only (transformer.py:107-190): per layer ONE projection GEMM
         for q|k|v against row-permuted weights that drop every head into its own zero-padded 176-column slot (16-byte
         aligned heads), the padded-head flash attention kernel, the output projection over the padded layout (zero
         weight columns on the pads), residual + LayerNorm row kernel, and the feed-forward pair on the MFMA GEMM with
-        bias/ReLU fused."""
+        bias/ReLU fused.  With `ci` (ops.CompactIndex) x is the compacted row set [cap, d]: every GEMM / row kernel works
+        on the live rows only and the attention runs ragged with the weighted representative key (csrc/compact.hip)."""
         d = x.shape[-1]
         HP, nh = ops.HEAD_PAD, 6
-        sizes = [t.shape[-1] for t in x[:1, :1].chunk(nh, -1)]
+        m = ci.m_dev if ci is not None else None
+        ragged = (ci.B, ci.R + 1, ci.off, ci.rep_w) if ci is not None else None
+        sizes = [t.shape[-1] for t in x.reshape(-1, d)[:1].chunk(nh, -1)]
         starts = [sum(sizes[:i]) for i in range(nh)]
         for lay in self.obj_interact.encoder.layers:
             sa = lay.selfattn.layer
@@ -290,17 +301,56 @@ class TopDownModel(nn.Module):
                 return w
             w_qkv = self._packed(('qkv', id(sa)), (sa.wq.weight, sa.wk.weight, sa.wv.weight), build_qkv)
             w_o = self._packed(('wo', id(sa)), (sa.wo.weight,), build_wo)
-            qkv = ops.gemm_nt(x, w_qkv)                                        # [B,R,3*6*176]
-            o = ops.flash_attn_padded(qkv, nh, 1.0 / math.sqrt(d))              # [B,R,6*176]
-            att = ops.gemm_nt(o, w_o)
+            qkv = ops.gemm_nt(x, w_qkv, m_dev=m)                               # [B,R,3*6*176]
+            o = ops.flash_attn_padded(qkv, nh, 1.0 / math.sqrt(d), ragged=ragged)   # [B,R,6*176]
+            att = ops.gemm_nt(o, w_o, m_dev=m)
             ln = lay.selfattn.layernorm
-            x = ops.add_layernorm_unbiased(x.contiguous(), att, ln.gamma.detach(), ln.beta.detach(), ln.eps)
+            x = ops.add_layernorm_unbiased(x.contiguous(), att, ln.gamma.detach(), ln.beta.detach(), ln.eps, rows_dev=m)
             ff = lay.feedforward.layer
-            y = ops.gemm_nt(ops.gemm_nt(x, ff.linear1.weight.detach(), ff.linear1.bias.detach(), 1),
-                            ff.linear2.weight.detach(), ff.linear2.bias.detach())
+            y = ops.gemm_nt(ops.gemm_nt(x, ff.linear1.weight.detach(), ff.linear1.bias.detach(), 1, m_dev=m),
+                            ff.linear2.weight.detach(), ff.linear2.bias.detach(), m_dev=m)
             ln = lay.feedforward.layernorm
-            x = ops.add_layernorm_unbiased(x, y, ln.gamma.detach(), ln.beta.detach(), ln.eps)
+            x = ops.add_layernorm_unbiased(x, y, ln.gamma.detach(), ln.beta.detach(), ln.eps, rows_dev=m)
         return x
+
+    def _fused_encoder_ok(self, d):
+        scale = math.sqrt(d)
+        return (self.has_obj_interact and self.flash_obj_interact and os.environ.get('GVD_ENC_FUSED', '1') == '1'
+                and scale == 2.0 ** round(math.log2(scale)) and d % 32 == 0 and -(-d // 6) <= ops.HEAD_PAD)
+
+    def _pool_weight_padded(self, K):
+        pw = self.pool_embed[0].weight
+
+        def build_pool(pw=pw, K=K):
+            w = torch.zeros(pw.shape[0], K, device=pw.device, dtype=torch.float32)
+            w[:, :pw.shape[1]] = pw
+            return w
+        return self._packed(('pool_embed', K), (pw,), build_pool)
+
+    def _regions_compact(self, ppls, ppls_feat, pm):
+        """The region half of the inference preamble (model.py:311-391) on the COMPACTED row set: masked proposals are
+        zero rows by the loader contract (dataloader_anet.py:343-344), so per segment only its valid rows plus ONE
+        representative masked row are computed (csrc/compact.hip); the dense [B,R,.] tensors the token loop streams
+        are restored by a row gather at the end.  -> pool [B,R,H], p_pool [B,R,A], sim_mat [B,D1,R]."""
+        ci = ops.CompactIndex(pm)
+        flag = torch.zeros(1, dtype=torch.int32, device=pm.device)
+        ops.check_masked_rows_zero(ppls_feat.contiguous(), pm, flag)
+        ops.check_masked_rows_zero(ppls.contiguous(), pm, flag)
+        self.__dict__.setdefault('_contract_flags', []).append(flag)
+        m = ci.m_dev
+        fc7 = self.ctx2pool_grd[0]
+        g_pool = ops.gemm_nt(ci.gather(ppls_feat), fc7.weight.detach(), fc7.bias.detach(), 1, m_dev=m)   # [cap,2048]
+        pc = ci.gather(ppls)
+        loc_in = torch.cat([pc[:, :4] / 720., (pc[:, 4] * 1. / self.num_sampled_frm).unsqueeze(-1)], dim=1)
+        loc = F.relu(self.loc_fc[0](loc_in)).contiguous()
+        vis_word = F.relu(self.vis_embed[0].weight).detach()
+        logits = ops.gemm_nt(g_pool, vis_word, self.vis_classifiers_bias.detach(), m_dev=m)              # [cap,D1]
+        pool_in, sim_c = ops.region_feature_rows_compact(g_pool, loc, logits, ci.cmask, m, pad_to=32)
+        pool = ops.gemm_nt(pool_in, self._pool_weight_padded(pool_in.shape[-1]), self.pool_embed[0].bias.detach(), 1,
+                           m_dev=m)
+        pool = self._obj_interact_fused(pool, ci=ci)
+        p_pool = ops.gemm_nt(pool, self.ctx2pool.weight.detach(), self.ctx2pool.bias.detach(), m_dev=m)
+        return ci.expand(pool), ci.expand(p_pool), ci.expand(sim_c).transpose(1, 2)
 
     def _obj_interact(self, x):
         """transformer.py:135-190,244-254 as built at model.py:126-135 (6 uneven heads, scale sqrt(d_model),
@@ -343,7 +393,7 @@ class TopDownModel(nn.Module):
                 x = lay.feedforward.layernorm(x + F.dropout(y, 0.2, self.training))
         return x
 
-    def _preamble(self, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask):
+    def _preamble(self, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, allow_compact=False):
         """Per-segment work shared by the three drivers (model.py:302-409 / 504-568 / 634-698)."""
         B, Ft = segs_feat.shape[0], segs_feat.shape[1]
         R = ppls.shape[1]
@@ -354,6 +404,12 @@ class TopDownModel(nn.Module):
         fc = segs_feat.mean(dim=1)
         seg_info = self._drop(F.relu(self.seg_info_embed[0](num[:, 3:7].float())))
         fc = torch.cat([F.layer_norm(fc, [fc.shape[-1]]), F.layer_norm(seg_info, [self.seg_info_size])], dim=-1)
+        compact = (allow_compact and not torch.is_grad_enabled() and not self.training
+                   and os.environ.get('GVD_COMPACT', '1') == '1'
+                   and self._fused_encoder_ok(self.rnn_size) and B * (R + 1) < (1 << 24)
+                   and os.environ.get('GVD_POOL_EMBED_OWN', '1') == '1')
+        if compact:
+            return self._preamble_finish(segs_feat, sample_idx, fc, pm, *self._regions_compact(ppls, ppls_feat, pm), None)
         # fc7 over the raw fc6 region features: MFMA GEMM + fused bias/ReLU (model.py:311-313)
         g_pool = self._drop(self._lin(ppls_feat, self.ctx2pool_grd[0], act=1))
         vis_word = self._drop(F.relu(self.vis_embed[0].weight))
@@ -371,14 +427,8 @@ class TopDownModel(nn.Module):
             if own:
                 # pool_embed (model.py:384, K = 2781) on the MFMA GEMM: the row kernel wrote the concat zero-padded to
                 # K = 2784 (16-byte aligned rows, 32-multiple K); the weight gets matching zero columns once
-                pw = self.pool_embed[0].weight
-
-                def build_pool(pw=pw, K=pool.shape[-1]):
-                    w = torch.zeros(pw.shape[0], K, device=pw.device, dtype=torch.float32)
-                    w[:, :pw.shape[1]] = pw
-                    return w
-                w_pool = self._packed('pool_embed', (pw,), build_pool)
-                pool = self._drop(ops.gemm_nt(pool, w_pool, self.pool_embed[0].bias.detach(), 1))
+                pool = self._drop(ops.gemm_nt(pool, self._pool_weight_padded(pool.shape[-1]),
+                                              self.pool_embed[0].bias.detach(), 1))
                 pool_done = True
         else:
             # region-class similarity: batched grounder GEMM with fused bias + proposal mask (model.py:321-340)
@@ -388,13 +438,18 @@ class TopDownModel(nn.Module):
             label = sim_mat.permute(0, 2, 1)
             pool = torch.cat([F.layer_norm(g_pool, [g_pool.shape[-1]]), F.layer_norm(loc, [300]),
                               F.layer_norm(label, [D1])], dim=2)
-        fc = self._drop(F.relu(self.fc_embed[0](fc)))
         if not pool_done:
             pool = self._drop(F.relu(self.pool_embed[0](pool)))
         if self.has_obj_interact:
             pool = self._obj_interact(pool)
         pool = pool.contiguous()
         p_pool = self._lin(pool, self.ctx2pool)                           # MFMA GEMM (model.py:391)
+        return self._preamble_finish(segs_feat, sample_idx, fc, pm, pool, p_pool, sim_mat, g_pool)
+
+    def _preamble_finish(self, segs_feat, sample_idx, fc, pm, pool, p_pool, sim_mat, g_pool):
+        """fc embedding + the frame half of the preamble (model.py:393-405)."""
+        Ft = segs_feat.shape[1]
+        fc = self._drop(F.relu(self.fc_embed[0](fc)))
         # frame-wise context (model.py:393-405)
         # frame embeddings (model.py:393-395) on the MFMA GEMM, straight from the two column blocks of segs_feat
         c = torch.cat([self._drop(self._lin(segs_feat[:, :, :2048], self.att_embed[0][0], act=1)),
@@ -435,7 +490,7 @@ class TopDownModel(nn.Module):
         sample_max = opt.get('sample_max', 1)
         beam_size = opt.get('beam_size', 1)
         with torch.no_grad():
-            pre = self._preamble(segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask)
+            pre = self._preamble(segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, allow_compact=True)
             P = {k: v.detach() for k, v in self._decode_params().items()}
             if not sample_max:
                 from . import sampling
@@ -470,7 +525,7 @@ class TopDownModel(nn.Module):
                 # iterate): order the preamble stream after everything the caller's stream has enqueued so far
                 s_pre.wait_stream(cur)
                 with torch.cuda.stream(s_pre):
-                    pre = self._preamble(b[0], b[2], b[1], b[3], b[4], b[5])
+                    pre = self._preamble(b[0], b[2], b[1], b[3], b[4], b[5], allow_compact=True)
                     ev = torch.cuda.Event()
                     ev.record(s_pre)
                 with torch.cuda.stream(s_dec):

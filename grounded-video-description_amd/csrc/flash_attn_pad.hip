@@ -33,6 +33,9 @@ struct PParams {
   int64_t ld, ldo;       // row strides (floats) of q/k/v and of o
   int B, R, n_heads;
   float qscale;          // 1/sqrt(d_model) (a power of two in the reference configuration) times log2(e)
+  // ragged (compacted) batches: sample b owns rows off[b] .. off[b+1]-1 of q/k/v/o (at most R of them); its LAST row
+  // stands for n identical rows: as a key its score gets + key_w[b] = log2(n) (-inf: no such rows, key ignored)
+  const int* off; const float* key_w;
 };
 
 __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) {
@@ -46,15 +49,19 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
   const int qt = lid % nqt;
   const int h = (lid / nqt) % p.n_heads;
   const int b = lid / (nqt * p.n_heads);
-  const int R = p.R;
   const int64_t ld = p.ld;
+  const int64_t row0 = p.off ? (int64_t)p.off[b] : (int64_t)b * p.R;        // first row of this sample
+  const int R = p.off ? p.off[b + 1] - p.off[b] : p.R;                       // its row count
+  if (qt * (16 * NW) >= R) return;                                           // (ragged: grid sized for the longest sample)
+  const int wkey = p.off ? R - 1 : -1;                                       // the weighted key, if any
+  const float wval = p.off ? p.key_w[b] : 0.f;
   const unsigned span = (unsigned)((int64_t)R * ld * 4);                     // bytes of one sample's rows: loads past
   __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(            // row R-1 return zeros
-      const_cast<float*>(p.q + (int64_t)b * R * ld + h * DP), 0, span - 4u * h * DP, 0x00020000);
+      const_cast<float*>(p.q + row0 * ld + h * DP), 0, span - 4u * h * DP, 0x00020000);
   __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.k + (int64_t)b * R * ld + h * DP), 0, span - 4u * h * DP, 0x00020000);
+      const_cast<float*>(p.k + row0 * ld + h * DP), 0, span - 4u * h * DP, 0x00020000);
   __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.v + (int64_t)b * R * ld + h * DP), 0, span - 4u * h * DP, 0x00020000);
+      const_cast<float*>(p.v + row0 * ld + h * DP), 0, span - 4u * h * DP, 0x00020000);
   const int qrow = qt * (16 * NW) + wave * 16 + c16;
   const unsigned ld4 = (unsigned)ld * 4u;
 
@@ -161,7 +168,9 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (key0 + 16 * u + 4 * g + r >= R) sacc[u][r] = -INFINITY;
+        const int key = key0 + 16 * u + 4 * g + r;
+        if (key >= R) sacc[u][r] = -INFINITY;
+        else if (key == wkey) sacc[u][r] += wval;        // n identical keys = one key with n times the weight
         mt = fmaxf(mt, sacc[u][r]);
       }
     mt = fmaxf(mt, __shfl_xor(mt, 16, GVD_WAVE));
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
   l_tot += __shfl_xor(l_tot, 32, GVD_WAVE);
   const float inv = 1.0f / l_tot;
   if (qrow < R) {
-    float* orow = p.o + ((int64_t)b * R + qrow) * p.ldo + h * DP + 4 * g;
+    float* orow = p.o + (row0 + qrow) * p.ldo + h * DP + 4 * g;
 #pragma unroll
     for (int dt = 0; dt < NSB; ++dt) *reinterpret_cast<f32x4*>(orow + 16 * dt) = oacc[dt] * inv;
   }
@@ -219,14 +228,16 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
 }  // namespace
 
 extern "C" int gvd_flash_attn_padded_f32(const float* q, const float* k, const float* v, int64_t ld, float* o, int64_t ldo,
-                                         int B, int R, int n_heads, int head_pad, float scale, gvd_stream_t stream) {
+                                         int B, int R, int n_heads, int head_pad, float scale, const int* row_off,
+                                         const float* last_key_log2_weight, gvd_stream_t stream) {
   if (!q || !k || !v || !o || B <= 0 || R <= 0 || n_heads <= 0 || head_pad != DP || (ld % 4) != 0 || (ldo % 4) != 0 ||
       !gvd_aligned16(q) || !gvd_aligned16(k) || !gvd_aligned16(v) || !gvd_aligned16(o) || ld < (int64_t)n_heads * DP ||
-      ldo < (int64_t)n_heads * DP || (int64_t)R * ld * 4 >= (int64_t)1 << 31)
+      ldo < (int64_t)n_heads * DP || (int64_t)R * ld * 4 >= (int64_t)1 << 31 || (row_off && !last_key_log2_weight))
     return GVD_EINVAL;
   PParams p = {};
   p.q = q; p.k = k; p.v = v; p.o = o; p.ld = ld; p.ldo = ldo; p.B = B; p.R = R; p.n_heads = n_heads;
   p.qscale = 1.4426950408889634f * scale;
+  p.off = row_off; p.key_w = last_key_log2_weight;
   const unsigned nwg = (unsigned)((R + 16 * NW - 1) / (16 * NW)) * n_heads * B;
   hipLaunchKernelGGL(flash_attn_pad_kernel, dim3(nwg), dim3(NT), 0, gvd_s(stream), p);
   GVD_CHECK_LAUNCH();

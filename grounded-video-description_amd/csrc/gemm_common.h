@@ -18,6 +18,7 @@ struct KParams {
   const uint8_t* mask; int64_t mask_ldm; int64_t mask_bs;
   float* C; int64_t ldc; int64_t cbs;
   int M, N, act;
+  const int* m_dev;      // when set: the row count is read on the device (<= M; tiles past it exit)
   // LSTM epilogue
   const float* c_prev; int64_t ldcp;
   float* h_out; int64_t ldh;
@@ -31,8 +32,8 @@ struct KParams {
 // Plain epilogue of a wave's TM x TN grid of 32x32 accumulator tiles (bias / per-row bias / 2-D bias / ReLU / masked
 // fill), straight from the MFMA layout: lane (r = l&31, half = l>>5) holds column r, rows (e&3) + 8(e>>2) + 4 half.
 template <int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue_plain(const KParams& p, const f32x16 (&acc)[TM][TN], int bz, int mw0, int nw0,
-                                                    int r, int half) {
+__device__ __forceinline__ void gemm_epilogue_plain(const KParams& p, int M, const f32x16 (&acc)[TM][TN], int bz, int mw0,
+                                                    int nw0, int r, int half) {
   float* Cb = p.C + (int64_t)bz * p.cbs;
   const float* rb = p.rowbias ? p.rowbias + (int64_t)bz * p.rowbias_bs : nullptr;
   const float* mb = p.mbias ? p.mbias + (int64_t)bz * p.mbias_bs : nullptr;
@@ -50,7 +51,7 @@ __device__ __forceinline__ void gemm_epilogue_plain(const KParams& p, const f32x
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
         const int gm = mw0 + i * 32 + row;
-        if (gm < p.M) {
+        if (gm < M) {
           float v = acc[i][j][e] + nb;
           if (mb) v += mb[gm];
           if (rb) v += rb[(int64_t)gm * p.rowbias_ld + gn];

@@ -49,6 +49,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
   const int bz = blockIdx.y;
   const int m0 = tm_ * BM;
   const int n0 = LSTM ? 0 : tn_ * BN;
+  const int M = p.m_dev ? min(*p.m_dev, p.M) : p.M;          // device-side row count (compacted preamble)
+  if (m0 >= M) return;
 
   // per-thread global row pointers are recomputed per segment; row validity is segment independent
   int a_row[NA], w_row[NW];
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
   for (int i = 0; i < NA; ++i) {
     int row = (tid + i * 256) / F4R;
     int gm = m0 + row;
-    a_ok[i] = gm < p.M;
+    a_ok[i] = gm < M;
     a_row[i] = a_ok[i] ? gm : 0;
   }
 #pragma unroll
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
   }
 
   if (!LSTM) {
-    gemm_epilogue_plain<TM, TN>(p, acc, bz, m0 + wm * WTM, n0 + wn * WTN, r, half);
+    gemm_epilogue_plain<TM, TN>(p, M, acc, bz, m0 + wm * WTM, n0 + wn * WTN, r, half);
   } else {
     // gates -> LDS tile G[BM][BN+1] (columns grouped i|f|g|o, HU units each), then the pointwise cell.
     constexpr int LDG = BN + 1;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
           const int ml = wm * WTM + i * 32 + row;
           const int gm = m0 + ml;
           float v = acc[i][j][e] + nb;
-          if (p.rowbias && gm < p.M) v += p.rowbias[(int64_t)gm * p.rowbias_ld + wrow];
+          if (p.rowbias && gm < M) v += p.rowbias[(int64_t)gm * p.rowbias_ld + wrow];
           G[ml * LDG + nl] = v;
         }
       }
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
     for (int idx = tid; idx < BM * HU; idx += 256) {
       const int ml = idx / HU, jl = idx % HU;
       const int gm = m0 + ml;
-      if (gm >= p.M) continue;
+      if (gm >= M) continue;
       const int j = tn_ * HU + jl;
       const float gi = sigmoid_f(G[ml * LDG + jl]);
       const float gf = sigmoid_f(G[ml * LDG + HU + jl]);
@@ -233,9 +235,9 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
   p.rowbias = a->rowbias; p.rowbias_ld = a->rowbias_ld; p.rowbias_bs = a->rowbias_batch_stride;
   p.mask = a->mask; p.mask_ldm = a->mask_ldm; p.mask_bs = a->mask_batch_stride;
   p.C = a->C; p.ldc = a->ldc; p.cbs = a->c_batch_stride;
-  p.M = a->M; p.N = a->N; p.act = a->act;
+  p.M = a->M; p.N = a->N; p.act = a->act; p.m_dev = a->m_dev;
   hipStream_t st = gvd_s(stream);
-  if (a->M <= 16 && a->batch == 1 && !a->mbias && !a->mask) {   // decode batch: weight-streaming skinny kernel
+  if (a->M <= 16 && a->batch == 1 && !a->mbias && !a->mask && !a->m_dev) {   // decode batch: weight-streaming skinny kernel
     GemvParams v = {};
     v.nseg = a->nseg;
     for (int s = 0; s < a->nseg; ++s) {

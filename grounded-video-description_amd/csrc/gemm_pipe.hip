@@ -41,7 +41,12 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   const int wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, half = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  // device-side row count (compacted preamble): only the first ceil(M/128) * ntn workgroups work, and THEY are remapped
+  // XCD-aware among themselves (hardware deals consecutive ids round-robin to the XCDs, so the live ones stay balanced)
+  const int M = p.m_dev ? min(*p.m_dev, p.M) : p.M;
+  const unsigned nlive = p.m_dev ? (unsigned)((M + BM - 1) / BM) * p.ntn : gridDim.x;
+  if (blockIdx.x >= nlive) return;
+  const unsigned lid = xcd_remap(blockIdx.x, nlive);
   const int tn_ = lid % p.ntn, tm_ = lid / p.ntn;
   const int bz = blockIdx.y;
   const int m0 = tm_ * BM, n0 = tn_ * BN;
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   int arow[NLD], wrow[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    arow[i] = min(m0 + srow + 32 * i, p.M - 1) - m0;       // clamp: rows past the edge re-read the last valid row
+    arow[i] = min(m0 + srow + 32 * i, M - 1) - m0;       // clamp: rows past the edge re-read the last valid row
     wrow[i] = min(n0 + srow + 32 * i, p.N - 1) - n0;
   }
 
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   mfma16(a1, b1);
 
   if (!EPI_LDS) {
-    gemm_epilogue_plain<2, 2>(p, acc, bz, m0 + wm * 64, n0 + wn * 64, r, half);
+    gemm_epilogue_plain<2, 2>(p, M, acc, bz, m0 + wm * 64, n0 + wn * 64, r, half);
     return;
   }
   // ---- epilogue through LDS (bias / bias2 / ReLU only; N % 4 == 0, ldc % 4 == 0, C 16-byte aligned)
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
     const int gm = m0 + wm * 64 + row;
     f32x4 v = *reinterpret_cast<const f32x4*>(&T[row * EPI_LD + c4]) + nb;
     if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-    if (gm < p.M && gn < p.N) *reinterpret_cast<f32x4*>(Cb + (int64_t)gm * p.ldc + gn) = v;
+    if (gm < M && gn < p.N) *reinterpret_cast<f32x4*>(Cb + (int64_t)gm * p.ldc + gn) = v;
   }
 }
 

@@ -19,11 +19,11 @@ template <int D>   // D = 64 * 4 * NV
 __global__ __launch_bounds__(256) void add_ln_unbiased_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ out,
-                                                              int64_t rows, float eps) {
+                                                              int64_t rows, const int* __restrict__ rows_dev, float eps) {
   constexpr int NV = D / 256;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  if (row >= (rows_dev ? (int64_t)*rows_dev : rows)) return;
   const float* xr = x + row * D;
   const float* yr = y ? y + row * D : nullptr;
   f32x4 v[NV];
@@ -67,10 +67,10 @@ __global__ __launch_bounds__(256) void region_feature_rows_kernel(const float* _
                                                                   int64_t mask_row_div, int64_t mask_ld,
                                                                   float* __restrict__ out, int64_t out_ld,
                                                                   float* __restrict__ sim_out, int64_t rows,
-                                                                  float ln_eps) {
+                                                                  const int* __restrict__ rows_dev, float ln_eps) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  if (row >= (rows_dev ? (int64_t)*rows_dev : rows)) return;
   float* o = out + row * out_ld;
   // pad columns (out_ld > 2048 + n_loc + n_cls: the K-padded operand of the pool_embed GEMM) are zero
   for (int c = RF_G + n_loc + n_cls + lane; c < out_ld; c += 64) o[c] = 0.f;
@@ -183,20 +183,21 @@ __global__ __launch_bounds__(256) void region_feature_rows_kernel(const float* _
 }  // namespace
 
 extern "C" int gvd_add_layernorm_unbiased(const float* x, const float* y, const float* gamma, const float* beta,
-                                          float* out, int64_t rows, int D, float eps, gvd_stream_t stream) {
+                                          float* out, int64_t rows, const int* rows_dev, int D, float eps,
+                                          gvd_stream_t stream) {
   if (!x || !gamma || !beta || !out || rows <= 0 || D != 1024) return GVD_EINVAL;
   if (!gvd_aligned16(x) || (y && !gvd_aligned16(y)) || !gvd_aligned16(out) || !gvd_aligned16(gamma) || !gvd_aligned16(beta))
     return GVD_EINVAL;
   hipLaunchKernelGGL(add_ln_unbiased_kernel<1024>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, gvd_s(stream), x, y,
-                     gamma, beta, out, rows, eps);
+                     gamma, beta, out, rows, rows_dev, eps);
   GVD_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int gvd_region_feature_rows(const float* g_pool, const float* loc, int n_loc, const float* sim_logits,
                                        int n_cls, const uint8_t* row_mask, int64_t mask_rows_per_batch,
-                                       int64_t mask_ld, float* out, int64_t out_ld, float* sim_out, int64_t rows, int G,
-                                       float ln_eps, gvd_stream_t stream) {
+                                       int64_t mask_ld, float* out, int64_t out_ld, float* sim_out, int64_t rows,
+                                       const int* rows_dev, int G, float ln_eps, gvd_stream_t stream) {
   if (!g_pool || !loc || !sim_logits || !out || rows <= 0 || G != RF_G || n_loc <= 0 || n_loc > 64 * RF_MAXC ||
       n_cls <= 0 || n_cls > 64 * RF_MAXC || !gvd_aligned16(g_pool) || out_ld < G + n_loc + n_cls ||
       ((out_ld & 3) == 0 && !gvd_aligned16(out)))
@@ -204,7 +205,7 @@ extern "C" int gvd_region_feature_rows(const float* g_pool, const float* loc, in
   if (row_mask && mask_rows_per_batch <= 0) return GVD_EINVAL;
   hipLaunchKernelGGL(region_feature_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, gvd_s(stream), g_pool,
                      loc, n_loc, sim_logits, n_cls, row_mask, row_mask ? mask_rows_per_batch : 1, mask_ld, out, out_ld,
-                     sim_out, rows, ln_eps);
+                     sim_out, rows, rows_dev, ln_eps);
   GVD_CHECK_LAUNCH();
   return 0;
 }

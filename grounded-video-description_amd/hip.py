@@ -33,7 +33,7 @@ class GemmArgs(C.Structure):
                 ('rowbias', c_f32p), ('rowbias_ld', C.c_int64), ('rowbias_batch_stride', C.c_int64),
                 ('mask', c_u8p), ('mask_ldm', C.c_int64), ('mask_batch_stride', C.c_int64),
                 ('C', c_f32p), ('ldc', C.c_int64), ('c_batch_stride', C.c_int64),
-                ('M', C.c_int), ('N', C.c_int), ('batch', C.c_int), ('act', C.c_int)]
+                ('M', C.c_int), ('N', C.c_int), ('batch', C.c_int), ('act', C.c_int), ('m_dev', C.c_void_p)]
 
 
 class LstmArgs(C.Structure):
@@ -86,14 +86,21 @@ _SIG = {
     'gvd_attn_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'gvd_attn_fwd': (C.c_int, [C.POINTER(AttnSide), C.POINTER(AttnSide), C.c_int, C.c_int, C.c_int,
                                c_f32p, C.c_int64, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
-    'gvd_add_layernorm_unbiased': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_float,
-                                             C.c_void_p]),
+    'gvd_add_layernorm_unbiased': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int,
+                                             C.c_float, C.c_void_p]),
     'gvd_region_feature_rows': (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_u8p, C.c_int64, C.c_int64,
-                                          c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+                                          c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_void_p, C.c_int, C.c_float,
+                                          C.c_void_p]),
     'gvd_flash_attn_f32': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int64, C.c_int,
                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
     'gvd_flash_attn_padded_f32': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int,
-                                            C.c_int, C.c_int, C.c_float, C.c_void_p]),
+                                            C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'gvd_compact_index': (C.c_int, [c_u8p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    c_f32p, c_u8p, C.c_void_p]),
+    'gvd_gather_rows_f32': (C.c_int, [c_f32p, C.c_int64, C.c_void_p, c_f32p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                      C.c_void_p]),
+    'gvd_check_masked_rows_zero': (C.c_int, [c_f32p, C.c_int, c_u8p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p]),
     'gvd_grid_sync_words': (C.c_int, []),
     'gvd_gru_bidir_layer': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p]),
@@ -123,7 +130,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 2        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 3        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

@@ -18,8 +18,9 @@ def _seg(A, W, K=None, a_bs=0, w_bs=0):
     return GemmSeg(ptr(A), A.stride(-2), a_bs, ptr(W), W.stride(-2), w_bs, K)
 
 
-def gemm_nt(A, W, bias=None, act=0, out=None):
-    """out[M,N] = act(A[M,K] @ W[N,K]^T + bias).  nn.Linear forward on the fp32 matrix cores."""
+def gemm_nt(A, W, bias=None, act=0, out=None, m_dev=None):
+    """out[M,N] = act(A[M,K] @ W[N,K]^T + bias).  nn.Linear forward on the fp32 matrix cores.
+    m_dev: optional device int32 tensor (1 element) with the live row count (<= M): rows past it are not computed."""
     require_cuda_f32(A, W, bias)
     lead = A.shape[:-1]
     A2 = A.reshape(-1, A.shape[-1])
@@ -34,6 +35,7 @@ def gemm_nt(A, W, bias=None, act=0, out=None):
     g.nbias = ptr(bias)
     g.C = ptr(out); g.ldc = out.stride(0)
     g.M, g.N, g.batch, g.act = M, N, 1, act
+    g.m_dev = ptr(m_dev)
     check(lib().gvd_gemm_nt_f32(C.byref(g), stream_ptr()), 'gvd_gemm_nt_f32')
     return out.view(*lead, N)
 
@@ -496,7 +498,7 @@ def sync_timed_out(sync):
     return int(sync.view(-1, lib().gvd_grid_sync_words())[:, 32].sum()) != 0
 
 
-def add_layernorm_unbiased(x, y, gamma, beta, eps=1e-6):
+def add_layernorm_unbiased(x, y, gamma, beta, eps=1e-6, rows_dev=None):
     """gamma * (s - mean) / (std_unbiased + eps) + beta, s = x + y: residual + the encoder LayerNorm in one pass."""
     require_cuda_f32(x, y, gamma, beta)
     D = x.shape[-1]
@@ -504,8 +506,8 @@ def add_layernorm_unbiased(x, y, gamma, beta, eps=1e-6):
     y2 = y.reshape(-1, D) if y is not None else None
     assert x2.is_contiguous() and (y2 is None or y2.is_contiguous())
     out = torch.empty_like(x2)
-    check(lib().gvd_add_layernorm_unbiased(ptr(x2), ptr(y2), ptr(gamma), ptr(beta), ptr(out), x2.shape[0], D, eps,
-                                           stream_ptr()), 'gvd_add_layernorm_unbiased')
+    check(lib().gvd_add_layernorm_unbiased(ptr(x2), ptr(y2), ptr(gamma), ptr(beta), ptr(out), x2.shape[0], ptr(rows_dev),
+                                           D, eps, stream_ptr()), 'gvd_add_layernorm_unbiased')
     return out.view_as(x)
 
 
@@ -524,7 +526,25 @@ def region_feature_rows(g_pool, loc, sim_logits_t, pnt_mask, ln_eps=1e-5, pad_to
     sim = torch.empty(B, R, n_cls, device=g_pool.device, dtype=torch.float32)
     mask_ptr = C.c_void_p(pnt_mask.data_ptr() + 1)              # skip the legacy pad column (main.py:227)
     check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(sim_logits_t), n_cls, mask_ptr, R, R + 1,
-                                        ptr(out), K, ptr(sim), B * R, G, ln_eps, stream_ptr()), 'gvd_region_feature_rows')
+                                        ptr(out), K, ptr(sim), B * R, None, G, ln_eps, stream_ptr()),
+          'gvd_region_feature_rows')
+    return out, sim
+
+
+def region_feature_rows_compact(g_pool, loc, sim_logits, row_mask, rows_dev, pad_to=32, ln_eps=1e-5):
+    """`region_feature_rows` over a compacted row set: g_pool [M,2048], loc [M,n_loc], sim_logits [M,D1], row_mask u8 [M]
+    (1 = the row is a masked proposal), live rows = *rows_dev."""
+    require_cuda_f32(g_pool, loc, sim_logits)
+    M, G = g_pool.shape
+    n_loc, n_cls = loc.shape[-1], sim_logits.shape[-1]
+    assert g_pool.is_contiguous() and loc.is_contiguous() and sim_logits.is_contiguous() and row_mask.dtype == torch.uint8
+    K = (G + n_loc + n_cls + pad_to - 1) // pad_to * pad_to
+    out = torch.empty(M, K, device=g_pool.device, dtype=torch.float32)
+    sim = torch.empty(M, n_cls, device=g_pool.device, dtype=torch.float32)
+    # mask addressing row_mask[(row / rows_per_batch) * ld + row % rows_per_batch] with one "batch" of M rows
+    check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(sim_logits), n_cls, ptr(row_mask), M, 0,
+                                        ptr(out), K, ptr(sim), M, ptr(rows_dev), G, ln_eps, stream_ptr()),
+          'gvd_region_feature_rows(compact)')
     return out, sim
 
 
@@ -545,17 +565,71 @@ def flash_attn_heads(q, k, v, head_sizes):
 HEAD_PAD = 176      # padded head width of the fused obj_interact attention (11 MFMA k-blocks of 16)
 
 
-def flash_attn_padded(qkv, n_heads, scale):
+def flash_attn_padded(qkv, n_heads, scale, ragged=None):
     """softmax(scale * q_h k_h^T) v_h for the heads of a fused, head-padded projection: qkv [B,R,3*n_heads*176] holds
     [q | k | v], head h of each in columns [176 h, 176 h + width) with zero pads (att_model packs the weights that way).
-    Returns o [B,R,n_heads*176] in the same padded layout."""
+    Returns o [B,R,n_heads*176] in the same padded layout.
+    ragged = (B, R_max, off i32 [B+1], key_w f32 [B]): qkv is [M, 3*W] with sample b in rows off[b]..off[b+1]-1, whose
+    last row counts 2^key_w[b] times as a key (compact.py)."""
     require_cuda_f32(qkv)
-    B, R, W3 = qkv.shape
     W = n_heads * HEAD_PAD
-    assert W3 == 3 * W and qkv.is_contiguous()
-    o = torch.empty(B, R, W, device=qkv.device, dtype=torch.float32)
+    assert qkv.shape[-1] == 3 * W and qkv.is_contiguous()
+    if ragged is None:
+        B, R, _ = qkv.shape
+        o = torch.empty(B, R, W, device=qkv.device, dtype=torch.float32)
+        off = kw = None
+    else:
+        B, R, off, kw = ragged
+        o = torch.empty(qkv.shape[0], W, device=qkv.device, dtype=torch.float32)
+        assert off.dtype == torch.int32 and kw.dtype == torch.float32
     base = qkv.data_ptr()
-    check(lib().gvd_flash_attn_padded_f32(C.c_void_p(base), C.c_void_p(base + 4 * W), C.c_void_p(base + 8 * W), W3,
-                                          ptr(o), W, B, R, n_heads, HEAD_PAD, scale, stream_ptr()),
+    check(lib().gvd_flash_attn_padded_f32(C.c_void_p(base), C.c_void_p(base + 4 * W), C.c_void_p(base + 8 * W), 3 * W,
+                                          ptr(o), W, B, R, n_heads, HEAD_PAD, scale, ptr(off), ptr(kw), stream_ptr()),
           'gvd_flash_attn_padded_f32')
     return o
+
+
+class CompactIndex:
+    """Device-side row maps of the masked-proposal compaction (gvd_compact_index; csrc/compact.hip)."""
+
+    def __init__(self, pnt_mask):
+        B, R1 = pnt_mask.shape
+        R = R1 - 1
+        dev = pnt_mask.device
+        assert pnt_mask.dtype == torch.uint8 and pnt_mask.is_contiguous()
+        self.B, self.R, self.cap = B, R, B * (R + 1)
+        self.off = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        self.nvalid = torch.empty(B, dtype=torch.int32, device=dev)
+        self.src_row = torch.zeros(self.cap, dtype=torch.int32, device=dev)   # (rows past the live count: row 0)
+        self.cidx = torch.empty(B * R, dtype=torch.int32, device=dev)
+        self.rep_w = torch.empty(B, dtype=torch.float32, device=dev)
+        self.cmask = torch.zeros(self.cap, dtype=torch.uint8, device=dev)
+        check(lib().gvd_compact_index(C.c_void_p(pnt_mask.data_ptr() + 1), R1, B, R, ptr(self.off), ptr(self.nvalid),
+                                      ptr(self.src_row), ptr(self.cidx), ptr(self.rep_w), ptr(self.cmask), stream_ptr()),
+              'gvd_compact_index')
+        self.m_dev = self.off[B:]                                  # live compact rows, on the device
+
+    def gather(self, x):
+        """[B,R,D] dense -> [cap, D] compact (rows past the live count are not written)."""
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D)
+        out = torch.empty(self.cap, D, device=x.device, dtype=torch.float32)
+        check(lib().gvd_gather_rows_f32(ptr(x2), x2.stride(0), ptr(self.src_row), ptr(out), D, D, self.cap, ptr(self.m_dev),
+                                        stream_ptr()), 'gvd_gather_rows_f32')
+        return out
+
+    def expand(self, xc):
+        """[cap, D] compact -> [B,R,D] dense (masked rows all receive their segment's representative row)."""
+        D = xc.shape[-1]
+        out = torch.empty(self.B, self.R, D, device=xc.device, dtype=torch.float32)
+        check(lib().gvd_gather_rows_f32(ptr(xc), xc.stride(0), ptr(self.cidx), ptr(out), D, D, self.B * self.R, None,
+                                        stream_ptr()), 'gvd_gather_rows_f32')
+        return out
+
+
+def check_masked_rows_zero(x, pnt_mask, flag):
+    """flag (int32 [1], device) |= 1 when a masked row of x [B,R,D] is not all-zero."""
+    B, R, D = x.shape
+    assert x.is_contiguous()
+    check(lib().gvd_check_masked_rows_zero(ptr(x), D, C.c_void_p(pnt_mask.data_ptr() + 1), pnt_mask.shape[1], B, R,
+                                           ptr(flag), stream_ptr()), 'gvd_check_masked_rows_zero')

@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 2
+#define GVD_ABI_VERSION 3
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -83,6 +83,7 @@ typedef struct {
   float* C; int64_t ldc; int64_t c_batch_stride;
   int M, N, batch;
   int act;                       /* 0 = identity, 1 = ReLU */
+  const int* m_dev;              /* optional: device int holding the live row count (<= M); rows / tiles past it are skipped */
 } gvd_gemm_args;
 
 int gvd_gemm_nt_f32(const gvd_gemm_args* args, gvd_stream_t stream);
@@ -150,8 +151,9 @@ int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_side* temporal
 
 /* out[row,:] = gamma * (s - mean(s)) / (std_unbiased(s) + eps) + beta with s = x[row,:] + y[row,:] (y may be NULL):
  * ResidualBlock + the encoder's custom LayerNorm (transformer.py:66-88).  D must be 1024. */
+/* rows_dev (here and below): optional device int with the live row count (<= rows), for the compacted preamble. */
 int gvd_add_layernorm_unbiased(const float* x, const float* y, const float* gamma, const float* beta, float* out,
-                               int64_t rows, int D, float eps, gvd_stream_t stream);
+                               int64_t rows, const int* rows_dev, int D, float eps, gvd_stream_t stream);
 
 /* Per proposal row (model.py:336-364): p = softmax over the n_cls similarity logits (all -1e8 when the row is
  * masked: row_mask[(row / mask_rows_per_batch) * mask_ld + row % mask_rows_per_batch] != 0), written to sim_out
@@ -161,7 +163,8 @@ int gvd_add_layernorm_unbiased(const float* x, const float* y, const float* gamm
  * variance, eps inside the sqrt, no affine). */
 int gvd_region_feature_rows(const float* g_pool, const float* loc, int n_loc, const float* sim_logits, int n_cls,
                             const uint8_t* row_mask, int64_t mask_rows_per_batch, int64_t mask_ld, float* out,
-                            int64_t out_ld, float* sim_out, int64_t rows, int G, float ln_eps, gvd_stream_t stream);
+                            int64_t out_ld, float* sim_out, int64_t rows, const int* rows_dev, int G, float ln_eps,
+                            gvd_stream_t stream);
 
 /* Fused multi-head self-attention of the obj_interact encoder (transformer.py:90-123; heads = Tensor.chunk of the
  * model width): o[b,:,c0_h:c0_h+w_h] = softmax(q_h k_h^T) v_h for every head h, flash-style in fp32 on the matrix
@@ -176,7 +179,31 @@ int gvd_flash_attn_f32(const float* q, const float* k, const float* v, float* o,
  * o: [B,R,ldo] in the same padded layout (pad columns come out zero).  scores = scale * q.k (scale = 1/sqrt(d_model),
  * transformer.py:92,104).  head_pad must be 176; ld, ldo multiples of 4; all pointers 16-byte aligned. */
 int gvd_flash_attn_padded_f32(const float* q, const float* k, const float* v, int64_t ld, float* o, int64_t ldo, int B,
-                              int R, int n_heads, int head_pad, float scale, gvd_stream_t stream);
+                              int R, int n_heads, int head_pad, float scale, const int* row_off,
+                              const float* last_key_log2_weight, gvd_stream_t stream);
+/* Ragged form (row_off != NULL, the compacted preamble below): sample b owns rows row_off[b] .. row_off[b+1]-1 (<= R of
+ * them) of q/k/v/o, and its LAST row stands for n identical rows: as a key its score gets + last_key_log2_weight[b]
+ * (= log2 n in the kernel's log2 domain; -inf = no such rows, the key is ignored).  Both arrays live on the device. */
+
+/* ---------------------------------------------------------------------------------------------
+ * Masked-proposal compaction of the per-segment preamble (csrc/compact.hip has the derivation): masked proposals are
+ * zeroed by the loader (dataloader_anet.py:343-344), so all masked rows of a segment are one row as far as the
+ * preamble is concerned; it runs on [valid rows | one representative] per segment and is expanded at the end.
+ * ------------------------------------------------------------------------------------------- */
+
+/* mask: u8 [B, >= R] (ld_mask between segments; pass pnt_mask + 1 to skip the legacy pad column), != 0 = masked.
+ * Outputs (device): off i32 [B+1] first compact row of each segment, off[B] = total compact rows; nvalid i32 [B];
+ * src_row i32 [B*(R+1)] dense row (b*R + r) of each compact row (representative = the segment's first masked row);
+ * cidx i32 [B*R] compact row of each dense row (masked rows -> the representative); rep_w f32 [B] = log2(#masked)
+ * or -inf; cmask u8 [B*(R+1)] = 1 for representative rows. */
+int gvd_compact_index(const uint8_t* mask, int64_t ld_mask, int B, int R, int* off, int* nvalid, int* src_row, int* cidx,
+                      float* rep_w, uint8_t* cmask, gvd_stream_t stream);
+/* out[i, 0:D] = in[idx[i], 0:D] for i < n_rows (or < *n_rows_dev when given): compaction of inputs, expansion of outputs */
+int gvd_gather_rows_f32(const float* in, int64_t in_ld, const int* idx, float* out, int64_t out_ld, int D, int64_t n_rows,
+                        const int* n_rows_dev, gvd_stream_t stream);
+/* flag[0] |= 1 when some masked row of x [B*R, D] is not all-zero (the precondition of the compaction) */
+int gvd_check_masked_rows_zero(const float* x, int D, const uint8_t* mask, int64_t ld_mask, int B, int R, int* flag,
+                               gvd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Frame-wise context encoder: one bidirectional GRU layer as a persistent cooperative kernel

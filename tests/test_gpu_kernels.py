@@ -417,3 +417,131 @@ def test_fused_encoder_path_matches_library_path():
     np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(got2.cpu().numpy(), ref2.cpu().numpy(), rtol=1e-4, atol=1e-4)
     assert not torch.allclose(ref, ref2, atol=1e-3)
+
+
+def _masked_inputs(B, R, D, seed, frac=0.25, full=(), none=()):
+    g = _g(seed)
+    pm = torch.zeros(B, R + 1, dtype=torch.uint8)
+    pm[:, 1:] = (torch.rand(B, R, generator=g) < frac).to(torch.uint8)
+    for b in full:
+        pm[b, 1:] = 1
+    for b in none:
+        pm[b, 1:] = 0
+    x = torch.randn(B, R, D, generator=g)
+    x = x.masked_fill(pm[:, 1:].bool().unsqueeze(-1), 0.0)
+    return pm, x
+
+
+def test_compact_index_gather_expand():
+    """gvd_compact_index / gvd_gather_rows_f32: per segment [valid rows in order | one representative masked row];
+    a fully masked segment, a segment without masked rows; gather -> expand restores every row of a tensor whose
+    masked rows are identical."""
+    B, R, D = 5, 203, 36
+    pm, x = _masked_inputs(B, R, D, 31, full=(1,), none=(3,))
+    ci = ops.CompactIndex(pm.cuda())
+    torch.cuda.synchronize()
+    off, nv = ci.off.cpu().tolist(), ci.nvalid.cpu().tolist()
+    src, cidx, repw, cm = ci.src_row.cpu(), ci.cidx.cpu().view(B, R), ci.rep_w.cpu(), ci.cmask.cpu()
+    base = 0
+    for b in range(B):
+        valid = (pm[b, 1:] == 0).nonzero().view(-1)
+        assert off[b] == base and nv[b] == valid.numel()
+        assert src[base:base + valid.numel()].tolist() == (b * R + valid).tolist()
+        assert cidx[b][valid].tolist() == list(range(base, base + valid.numel()))
+        rep = base + valid.numel()
+        nm = R - valid.numel()
+        assert int(cm[rep]) == 1 and int(cm[base:rep].sum()) == 0
+        if nm:
+            first = int((pm[b, 1:] != 0).nonzero()[0])
+            assert int(src[rep]) == b * R + first and abs(float(repw[b]) - np.log2(nm)) < 1e-6
+            assert (cidx[b][pm[b, 1:] != 0] == rep).all()
+        else:
+            assert float(repw[b]) == float('-inf')
+        base = rep + 1
+    assert off[B] == base and int(ci.m_dev.cpu()) == base
+    xc = ci.gather(x.cuda())
+    back = ci.expand(xc)
+    assert torch.equal(back.cpu(), x)
+    # non-multiple-of-4 width (the 7 proposal columns)
+    p7 = torch.randn(B, R, 7, generator=_g(1)).masked_fill(pm[:, 1:].bool().unsqueeze(-1), 0.0)
+    assert torch.equal(ci.expand(ci.gather(p7.cuda())).cpu(), p7)
+    # the precondition check
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    ops.check_masked_rows_zero(x.cuda(), pm.cuda(), flag)
+    assert int(flag) == 0
+    bad = x.clone()
+    bad[1, 7, 3] = 1.0
+    ops.check_masked_rows_zero(bad.cuda(), pm.cuda(), flag)
+    assert int(flag) == 1
+
+
+@pytest.mark.parametrize('M,N,K', [(33000, 1024, 1024), (40000, 433, 2048), (3000, 512, 1024)])
+def test_gemm_device_side_row_count(M, N, K):
+    """m_dev: tiles past the live row count are skipped (output untouched), live rows are bitwise the plain product."""
+    g = _g(M)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    full = ops.gemm_nt(A, W, b, 1)
+    for live in (M, M - 1, M * 4 // 5 + 3, 129, 1):
+        out = torch.full((M, N), 7.0, device='cuda')
+        ops.gemm_nt(A, W, b, 1, out=out, m_dev=torch.tensor([live], dtype=torch.int32, device='cuda'))
+        assert torch.equal(out[:live], full[:live])
+        assert bool((out[live:] == 7.0).all())
+
+
+@pytest.mark.parametrize('B,R', [(3, 1000), (4, 130), (2, 77)])
+def test_flash_attention_ragged_weighted_key(B, R):
+    """Ragged padded-head attention over compacted rows == the dense kernel over rows with n identical masked rows (as
+    keys: one key with weight n; as queries: one answer), incl. a fully masked and an unmasked segment."""
+    nh, HP = 6, ops.HEAD_PAD
+    pm, qkv = _masked_inputs(B, R, 3 * nh * HP, 7 * B + R, full=(1,), none=(0,))
+    # masked rows must be IDENTICAL (not necessarily zero) for the equivalence: give them a common non-zero row
+    common = torch.randn(3 * nh * HP, generator=_g(5)) * 0.5
+    qkv = torch.where(pm[:, 1:].bool().unsqueeze(-1), common.view(1, 1, -1), qkv)
+    qkv.view(B, R, 3 * nh, HP)[..., 171:] = 0
+    dense = ops.flash_attn_padded(qkv.cuda(), nh, 1.0 / 32.0)
+    ci = ops.CompactIndex(pm.cuda())
+    comp = ops.flash_attn_padded(ci.gather(qkv.cuda()), nh, 1.0 / 32.0, ragged=(B, R + 1, ci.off, ci.rep_w))
+    back = ci.expand(comp)
+    np.testing.assert_allclose(back.cpu().numpy(), dense.cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_compact_preamble_equals_dense_preamble():
+    """TopDownModel._preamble on the compacted row set (GVD_COMPACT=1, default) vs the dense path: pool / p_pool /
+    sim_mat, incl. a fully masked segment; masked rows of the dense tensors all carry their segment's representative."""
+    import os
+    from gvd_amd import att_model, synth
+    from oracle import edge_cases
+    opt, sd, inp = edge_cases.EDGE_CASES['masked_frames']()
+    m = att_model.TopDownModel(opt)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    a = [inp[k].cuda() for k in ('segs_feat', 'num', 'ppls', 'ppls_feat', 'sample_idx', 'pnt_mask')]
+    old = os.environ.get('GVD_COMPACT')
+    try:
+        with torch.no_grad():
+            os.environ['GVD_COMPACT'] = '0'
+            ref = m._preamble(*a, allow_compact=True)
+            os.environ['GVD_COMPACT'] = '1'
+            got = m._preamble(*a, allow_compact=True)
+            m.check_kernel_status()
+            # violated loader contract (a masked proposal with non-zero features) fails loudly
+            bad = [t.clone() for t in a]
+            bad[3][0, 2 * opt.num_prop_per_frm + 5, 11] = 1.0
+            m._preamble(*bad, allow_compact=True)
+            with pytest.raises(hip.GvdHipError):
+                m.check_kernel_status()
+    finally:
+        if old is None:
+            os.environ.pop('GVD_COMPACT', None)
+        else:
+            os.environ['GVD_COMPACT'] = old
+    assert got['g_pool'] is None and ref['g_pool'] is not None
+    for k in ('pool', 'p_pool', 'sim_mat_static', 'fc', 'conv', 'p_conv'):
+        np.testing.assert_allclose(got[k].cpu().numpy(), ref[k].cpu().numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
+    pmb = inp['pnt_mask'][:, 1:].bool()
+    for b in range(pmb.shape[0]):
+        rows = got['pool'][b][pmb[b].cuda()]
+        if rows.shape[0] > 1:
+            assert torch.equal(rows, rows[:1].expand_as(rows))

@@ -150,7 +150,7 @@ def test_one_optimisation_step_matches_reference(name, golden_dir):
     losses = tr.step(synth.as_args(inp, 'cuda')).cpu().numpy()
     np.testing.assert_allclose(losses, g['losses'], atol=1e-4)
     assert abs(tr.last_grad_norm - float(g['total_grad_norm'])) / float(g['total_grad_norm']) < 2e-3
-    lrs = {id(gr['params'][0]): gr['lr'] for gr in tr.optimizer.param_groups}
+    lrs = {id(p): gr['lr'] for gr in tr.optimizer.param_groups for p in gr['params']}
     params = dict(model.named_parameters())
     assert abs(lrs[id(params['ctx2pool_grd.0.weight'])] - 5e-5) < 1e-12 and abs(lrs[id(params['logit.weight'])] - 5e-4) < 1e-12
     for n, dn, mn in zip([str(x) for x in g['step_names']], g['delta_norms'], g['exp_avg_norms']):

@@ -363,7 +363,8 @@ class TopDownModel(nn.Module):
             return self._obj_interact_fused(x)
         for lay in self.obj_interact.encoder.layers:
             sa = lay.selfattn.layer
-            q, k, v = sa.wq(x), sa.wk(x), sa.wv(x)
+            # projections on the MFMA GEMM, forward and (K-strided operands) backward
+            q, k, v = self._lin(x, sa.wq), self._lin(x, sa.wk), self._lin(x, sa.wv)
             # the reference divides the [B,R,R] score maps by sqrt(d_model) = 32 (transformer.py:92,104); scaling the
             # [B,R,171] queries instead is bitwise identical when the scale is a power of two and 5.8x less traffic
             exact = scale == 2.0 ** round(math.log2(scale))
@@ -379,7 +380,7 @@ class TopDownModel(nn.Module):
                     dots = torch.matmul(qh, kh.transpose(1, 2))
                     w = F.softmax(dots if exact else dots / scale, dim=-1)
                     heads.append(torch.matmul(F.dropout(w, 0.2, self.training), vh))
-            att = sa.wo(heads[0] if len(heads) == 1 else torch.cat(heads, -1))
+            att = self._lin(heads[0] if len(heads) == 1 else torch.cat(heads, -1), sa.wo)
             ff = lay.feedforward.layer
             if fused:   # inference: residual add + custom LayerNorm as one HIP row kernel
                 ln = lay.selfattn.layernorm
@@ -389,7 +390,7 @@ class TopDownModel(nn.Module):
                 x = ops.add_layernorm_unbiased(x, y, ln.gamma, ln.beta, ln.eps)
             else:
                 x = lay.selfattn.layernorm(x + F.dropout(att, 0.2, self.training))
-                y = ff.linear2(F.relu(ff.linear1(x)))
+                y = self._lin(self._lin(x, ff.linear1, act=1), ff.linear2)
                 x = lay.feedforward.layernorm(x + F.dropout(y, 0.2, self.training))
         return x
 
@@ -436,8 +437,12 @@ class TopDownModel(nn.Module):
             sim_mat = F.softmax(sim_logits, dim=1)
             # location / class-distribution features (model.py:357-364)
             label = sim_mat.permute(0, 2, 1)
+            kpad = (-(g_pool.shape[-1] + 300 + D1)) % 32          # zero columns: 32-multiple K for the MFMA GEMM
             pool = torch.cat([F.layer_norm(g_pool, [g_pool.shape[-1]]), F.layer_norm(loc, [300]),
-                              F.layer_norm(label, [D1])], dim=2)
+                              F.layer_norm(label, [D1])] + ([label.new_zeros(B, R, kpad)] if kpad else []), dim=2)
+            pe = self.pool_embed[0]
+            pool = self._drop(ops.linear(pool, F.pad(pe.weight, (0, kpad)), pe.bias, 1))     # model.py:384
+            pool_done = True
         if not pool_done:
             pool = self._drop(F.relu(self.pool_embed[0](pool)))
         if self.has_obj_interact:

@@ -236,7 +236,9 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
   p.mask = a->mask; p.mask_ldm = a->mask_ldm; p.mask_bs = a->mask_batch_stride;
   p.C = a->C; p.ldc = a->ldc; p.cbs = a->c_batch_stride;
   p.M = a->M; p.N = a->N; p.act = a->act; p.m_dev = a->m_dev;
+  p.a_t = a->a_kstrided; p.w_t = a->w_kstrided;
   hipStream_t st = gvd_s(stream);
+  if (p.a_t || p.w_t) return gvd_gemm_pipe_launch(p, a->batch, st);      // backward products: pipelined kernel only
   if (a->M <= 16 && a->batch == 1 && !a->mbias && !a->mask && !a->m_dev) {   // decode batch: weight-streaming skinny kernel
     GemvParams v = {};
     v.nseg = a->nseg;

@@ -25,13 +25,18 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 4;
 constexpr int NLD = 4;                 // 16-byte loads per thread per operand per k tile (128 rows x 8 / 256)
 constexpr int EPI_LD = 68;             // padded row of the epilogue transpose slice (floats)
+constexpr int LDT = BM + 4;            // LDS row (floats) of a K-STRIDED operand tile [32 k][128 rows]
+// K-strided ("transposed") operands, for the backward products of nn.Linear: dX = dY W (W: [N(contraction), K]) and
+// dW = dY^T X (both operands [M(contraction), .]).  Such an operand's tile is 32 memory rows (k) of 128 contiguous
+// floats: loaded with the same 16-byte buffer loads, stored row-major [k][row] in LDS, and a lane takes its MFMA values
+// with four ds_read_b32 (LDS[8q + 4 half + t][row]) instead of one ds_read_b128 - same k order, same accumulators.
 
 struct Seg {
   __amdgpu_buffer_rsrc_t ra, rw;
   unsigned voa[NLD], vow[NLD];
 };
 
-template <bool EPI_LDS>
+template <bool EPI_LDS, bool AT = false, bool BT = false>
 __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];     // 73,728 B -> two workgroups per CU
   float* As = smem;
@@ -59,22 +64,40 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
     arow[i] = min(m0 + srow + 32 * i, M - 1) - m0;       // clamp: rows past the edge re-read the last valid row
     wrow[i] = min(n0 + srow + 32 * i, p.N - 1) - n0;
   }
+  // K-strided operands: thread covers memory rows (k) tk + 8 i, 16-byte column chunk tc (columns = output rows / cols;
+  // chunks past the edge are clamped to the last whole chunk - M, N are multiples of 4 there)
+  const int tk = tid >> 5, tc = tid & 31;
+  const int acol = min(m0 + 4 * tc, M - 4) - m0, wcol = min(n0 + 4 * tc, p.N - 4) - n0;
 
   Seg sg;
   int seg = 0, kpos = 0;                                    // position of the NEXT tile to fetch
   const int kseg1 = p.K[1], kseg2 = p.K[2], nseg = p.nseg;  // (kept in SGPRs: no kernarg reload inside the k loop)
   int kend = p.K[0];
+  const float* pa_t = nullptr;                              // K-strided operands: running base of the current k tile
+  const float* pw_t = nullptr;
   auto seg_setup = [&](int s) {
-    sg.ra = gvd_rsrc(p.A[s] + (int64_t)bz * p.abs_[s] + (int64_t)m0 * p.lda[s]);
-    sg.rw = gvd_rsrc(p.W[s] + (int64_t)bz * p.wbs[s] + (int64_t)n0 * p.ldw[s]);
     const unsigned lda4 = (unsigned)p.lda[s] * 4u, ldw4 = (unsigned)p.ldw[s] * 4u;
+    if (AT) {
+      pa_t = p.A[s] + (int64_t)bz * p.abs_[s] + m0;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      sg.voa[i] = (unsigned)arow[i] * lda4 + 16u * kq;
-      sg.vow[i] = (unsigned)wrow[i] * ldw4 + 16u * kq;
+      for (int i = 0; i < NLD; ++i) sg.voa[i] = (unsigned)(tk + 8 * i) * lda4 + 4u * (unsigned)acol;
+    } else {
+      sg.ra = gvd_rsrc(p.A[s] + (int64_t)bz * p.abs_[s] + (int64_t)m0 * p.lda[s]);
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) sg.voa[i] = (unsigned)arow[i] * lda4 + 16u * kq;
+    }
+    if (BT) {
+      pw_t = p.W[s] + (int64_t)bz * p.wbs[s] + n0;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) sg.vow[i] = (unsigned)(tk + 8 * i) * ldw4 + 4u * (unsigned)wcol;
+    } else {
+      sg.rw = gvd_rsrc(p.W[s] + (int64_t)bz * p.wbs[s] + (int64_t)n0 * p.ldw[s]);
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) sg.vow[i] = (unsigned)wrow[i] * ldw4 + 16u * kq;
     }
   };
   seg_setup(0);
+  const int64_t lda_t = p.lda[0], ldw_t = p.ldw[0];         // (K-strided operands use a single segment)
 
   int nkt = 0;
 #pragma unroll
@@ -84,12 +107,24 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   f32x4 ga[NLD], gw[NLD];
   auto fetch = [&]() {
     const unsigned so = 4u * (unsigned)kpos;
+    if (AT) {                                   // the descriptor follows the k tile (row offsets can exceed 32 bits)
+      const __amdgpu_buffer_rsrc_t ra = gvd_rsrc(pa_t + (int64_t)kpos * lda_t);
 #pragma unroll
-    for (int i = 0; i < NLD; ++i)
-      ga[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sg.ra, sg.voa[i], so, 0));
+      for (int i = 0; i < NLD; ++i) ga[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, sg.voa[i], 0, 0));
+    } else {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i)
-      gw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sg.rw, sg.vow[i], so, 0));
+      for (int i = 0; i < NLD; ++i)
+        ga[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sg.ra, sg.voa[i], so, 0));
+    }
+    if (BT) {
+      const __amdgpu_buffer_rsrc_t rw = gvd_rsrc(pw_t + (int64_t)kpos * ldw_t);
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) gw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, sg.vow[i], 0, 0));
+    } else {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        gw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sg.rw, sg.vow[i], so, 0));
+    }
     kpos += BK;
     if (kpos == kend && seg + 1 < nseg) {                  // wave-uniform, taken nseg-1 times per workgroup
       ++seg;
@@ -98,11 +133,11 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
       seg_setup(seg);
     }
   };
-  float* Ast = &As[srow * LDK + 4 * kq];
-  float* Wst = &Ws[srow * LDK + 4 * kq];
+  float* Ast = AT ? &As[tk * LDT + 4 * tc] : &As[srow * LDK + 4 * kq];
+  float* Wst = BT ? &Ws[tk * LDT + 4 * tc] : &Ws[srow * LDK + 4 * kq];
   auto stage_part = [&](int buf, int i) {      // one A row and one W row of this thread's share of the tile
-    *reinterpret_cast<f32x4*>(Ast + (buf * BM + 32 * i) * LDK) = ga[i];
-    *reinterpret_cast<f32x4*>(Wst + (buf * BN + 32 * i) * LDK) = gw[i];
+    *reinterpret_cast<f32x4*>(Ast + (AT ? buf * BM * LDK + 8 * i * LDT : (buf * BM + 32 * i) * LDK)) = ga[i];
+    *reinterpret_cast<f32x4*>(Wst + (BT ? buf * BN * LDK + 8 * i * LDT : (buf * BN + 32 * i) * LDK)) = gw[i];
   };
   auto stage = [&](int buf) {
 #pragma unroll
@@ -118,13 +153,30 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // fragment q (8 k values) of the tile in `buf`: lane (r, half) takes k = 8q + 4 half + t for MFMA step t
-  const float* Afr = &As[(wm * 64 + r) * LDK + half * 4];
-  const float* Wfr = &Ws[(wn * 64 + r) * LDK + half * 4];
+  static_assert(BK * LDT <= BM * LDK, "a K-strided tile fits the operand buffer");
+  const float* Afr = AT ? &As[half * 4 * LDT + wm * 64 + r] : &As[(wm * 64 + r) * LDK + half * 4];
+  const float* Wfr = BT ? &Ws[half * 4 * LDT + wn * 64 + r] : &Ws[(wn * 64 + r) * LDK + half * 4];
   auto frags = [&](f32x4 (&a)[2], f32x4 (&b)[2], int buf, int q) {
-    a[0] = *reinterpret_cast<const f32x4*>(Afr + buf * BM * LDK + q * 8);
-    a[1] = *reinterpret_cast<const f32x4*>(Afr + buf * BM * LDK + 32 * LDK + q * 8);
-    b[0] = *reinterpret_cast<const f32x4*>(Wfr + buf * BN * LDK + q * 8);
-    b[1] = *reinterpret_cast<const f32x4*>(Wfr + buf * BN * LDK + 32 * LDK + q * 8);
+    if (AT) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[0][t] = Afr[buf * BM * LDK + (q * 8 + t) * LDT];
+        a[1][t] = Afr[buf * BM * LDK + (q * 8 + t) * LDT + 32];
+      }
+    } else {
+      a[0] = *reinterpret_cast<const f32x4*>(Afr + buf * BM * LDK + q * 8);
+      a[1] = *reinterpret_cast<const f32x4*>(Afr + buf * BM * LDK + 32 * LDK + q * 8);
+    }
+    if (BT) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        b[0][t] = Wfr[buf * BN * LDK + (q * 8 + t) * LDT];
+        b[1][t] = Wfr[buf * BN * LDK + (q * 8 + t) * LDT + 32];
+      }
+    } else {
+      b[0] = *reinterpret_cast<const f32x4*>(Wfr + buf * BN * LDK + q * 8);
+      b[1] = *reinterpret_cast<const f32x4*>(Wfr + buf * BN * LDK + 32 * LDK + q * 8);
+    }
     __builtin_amdgcn_sched_barrier(0);     // keep the reads AHEAD of the MFMAs that follow in program order
   };
   auto mfma4 = [&](const f32x4 (&a)[2], const f32x4 (&b)[2], int t) {
@@ -216,6 +268,23 @@ int gvd_gemm_pipe_launch(KParams& p, int batch, hipStream_t st) {
   dim3 grid((unsigned)(p.ntm * p.ntn), (unsigned)batch);
   const bool lds_epi = !p.mbias && !p.rowbias && !p.mask && (p.N % 4) == 0 && (p.ldc % 4) == 0 && (p.cbs % 4) == 0 &&
                        gvd_aligned16(p.C) && (!p.nbias || gvd_aligned16(p.nbias)) && (!p.nbias2 || gvd_aligned16(p.nbias2));
+  if (p.a_t || p.w_t) {
+    // backward products: one segment, 16-byte aligned K-strided operands, whole 4-column chunks, no device row count
+    const bool ok = p.nseg == 1 && !p.m_dev && (!p.a_t || ((p.M % 4) == 0 && p.M >= 4)) &&
+                    (!p.w_t || ((p.N % 4) == 0 && p.N >= 4)) && (p.abs_[0] % 4) == 0 && (p.wbs[0] % 4) == 0;
+    if (!ok) return GVD_EINVAL;
+    if (p.a_t && p.w_t) {
+      if (lds_epi) hipLaunchKernelGGL((gemm_pipe_kernel<true, true, true>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gemm_pipe_kernel<false, true, true>), grid, dim3(256), 0, st, p);
+    } else if (p.w_t) {
+      if (lds_epi) hipLaunchKernelGGL((gemm_pipe_kernel<true, false, true>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gemm_pipe_kernel<false, false, true>), grid, dim3(256), 0, st, p);
+    } else {
+      return GVD_EINVAL;                      // (A K-strided with W K-major is not a product the path needs)
+    }
+    GVD_CHECK_LAUNCH();
+    return 0;
+  }
   if (lds_epi) hipLaunchKernelGGL(gemm_pipe_kernel<true>, grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(gemm_pipe_kernel<false>, grid, dim3(256), 0, st, p);
   GVD_CHECK_LAUNCH();

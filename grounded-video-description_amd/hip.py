@@ -33,7 +33,8 @@ class GemmArgs(C.Structure):
                 ('rowbias', c_f32p), ('rowbias_ld', C.c_int64), ('rowbias_batch_stride', C.c_int64),
                 ('mask', c_u8p), ('mask_ldm', C.c_int64), ('mask_batch_stride', C.c_int64),
                 ('C', c_f32p), ('ldc', C.c_int64), ('c_batch_stride', C.c_int64),
-                ('M', C.c_int), ('N', C.c_int), ('batch', C.c_int), ('act', C.c_int), ('m_dev', C.c_void_p)]
+                ('M', C.c_int), ('N', C.c_int), ('batch', C.c_int), ('act', C.c_int), ('m_dev', C.c_void_p),
+                ('a_kstrided', C.c_int), ('w_kstrided', C.c_int)]
 
 
 class LstmArgs(C.Structure):
@@ -130,7 +131,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 3        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 4        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

@@ -40,6 +40,51 @@ def gemm_nt(A, W, bias=None, act=0, out=None, m_dev=None):
     return out.view(*lead, N)
 
 
+def gemm_dx(dY, W):
+    """dX[M,K] = dY[M,N] @ W[N,K] (backward of y = x W^T w.r.t. x) on the pipelined MFMA kernel: W is consumed in place
+    as a K-strided operand.  Falls back (returns None) when the shape is outside what the kernel takes."""
+    M, N = dY.shape
+    K = W.shape[1]
+    tiles = ((M + 127) // 128) * ((K + 127) // 128)
+    if N % 32 or K % 4 or tiles < 256 or not (dY.is_contiguous() and W.is_contiguous()):
+        return None
+    out = torch.empty(M, K, device=dY.device, dtype=torch.float32)
+    g = GemmArgs()
+    g.nseg = 1
+    g.seg[0] = GemmSeg(ptr(dY), N, 0, ptr(W), K, 0, N)
+    g.C = ptr(out); g.ldc = K
+    g.M, g.N, g.batch, g.act = M, K, 1, 0
+    g.w_kstrided = 1
+    check(lib().gvd_gemm_nt_f32(C.byref(g), stream_ptr()), 'gvd_gemm_nt_f32(dX)')
+    return out
+
+
+def gemm_dw(dY, X):
+    """dW[N,K] = dY[M,N]^T @ X[M,K] (backward of y = x W^T w.r.t. W): both operands K-strided; the long contraction over
+    the M = B*R rows is cut into S chunks run as a batch (deterministic split-K), partial slabs summed.  None = shape not
+    taken."""
+    M, N = dY.shape
+    K = X.shape[1]
+    if N % 4 or K % 4 or not (dY.is_contiguous() and X.is_contiguous()):
+        return None
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    S = 1
+    while tiles * S < 1024 and M % (64 * S) == 0 and M // (2 * S) >= 2048:
+        S *= 2
+    if M % (32 * S) or tiles * S < 256:
+        return None
+    Mc = M // S
+    part = torch.empty(S, N, K, device=dY.device, dtype=torch.float32)
+    g = GemmArgs()
+    g.nseg = 1
+    g.seg[0] = GemmSeg(ptr(dY), N, Mc * N, ptr(X), K, Mc * K, Mc)
+    g.C = ptr(part); g.ldc = K; g.c_batch_stride = N * K
+    g.M, g.N, g.batch, g.act = N, K, S, 0
+    g.a_kstrided = g.w_kstrided = 1
+    check(lib().gvd_gemm_nt_f32(C.byref(g), stream_ptr()), 'gvd_gemm_nt_f32(dW)')
+    return part[0] if S == 1 else part.sum(0)
+
+
 def grounder_dot(xt, feats, mask, mbias=None, rowbias=None, xt_shared=False):
     """`AttModel._grounder` dot-product branch (model.py:243-280), batched over B in one launch:
     out[b,m,r] = xt[b,m,:] . feats[b,r,:] + mbias[(b,)m] + rowbias[b,m,r];  out[mask] = -1e8.
@@ -289,10 +334,16 @@ class _LinearFn(torch.autograd.Function):
         x, w, out = ctx.saved_tensors
         if ctx.act:
             dy = dy * (out > 0).to(dy.dtype)
-        dy2 = dy.reshape(-1, dy.shape[-1])
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         x2 = x.reshape(-1, x.shape[-1])
-        dx = (dy2 @ w).view_as(x) if ctx.needs_input_grad[0] else None
-        dw = dy2.t() @ x2 if ctx.needs_input_grad[1] else None
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm_dx(dy2, w.detach())                       # MFMA kernel, W in place (K-strided operand)
+            dx = (dy2 @ w if dx is None else dx).view_as(x)
+        if ctx.needs_input_grad[1]:
+            dw = gemm_dw(dy2, x2.detach()) if x2.is_contiguous() else None
+            if dw is None:
+                dw = dy2.t() @ x2
         db = dy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None
 

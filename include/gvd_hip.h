@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 3
+#define GVD_ABI_VERSION 4
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -84,6 +84,12 @@ typedef struct {
   int M, N, batch;
   int act;                       /* 0 = identity, 1 = ReLU */
   const int* m_dev;              /* optional: device int holding the live row count (<= M); rows / tiles past it are skipped */
+  /* K-strided operands (the backward products of nn.Linear; single segment, large shapes only):
+   *   w_kstrided: W is given as [K, N] (ldw >= N, N % 4 == 0)            dX[M,K'] = dY[M,N'] W[N',K']
+   *   a_kstrided (with w_kstrided): A is given as [K, M] (lda >= M)       dW[N',K'] = dY[M',N']^T X[M',K']
+   * a batch over contraction chunks (a/w_batch_stride = chunk rows * ld) gives a deterministic split-K: the caller sums
+   * the partial C slabs. */
+  int a_kstrided, w_kstrided;
 } gvd_gemm_args;
 
 int gvd_gemm_nt_f32(const gvd_gemm_args* args, gvd_stream_t stream);

@@ -564,7 +564,7 @@ def test_backward_gemms_kstrided_operands(M, N, K):
     assert dw is not None
     want = (dY.double().t() @ X.double())
     err = float((dw.double() - want).abs().max() / want.abs().max())
-    assert err < 2e-6, err
+    assert err < 1e-5, err      # fp32 accumulation over a 40k-64k long contraction
     # run-to-run bitwise reproducible (batched split-K + ordered sum, no atomics)
     assert torch.equal(dw, ops.gemm_dw(dY, X))
 

@@ -60,6 +60,8 @@ template <bool NT>
 __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   __shared__ float s_score[MAX_CHUNK];
   __shared__ float s_red[8];
+  __shared__ int s_live[MAX_CHUNK];
+  __shared__ int s_n[2];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int b = blockIdx.y;
   int c = blockIdx.x;
@@ -84,10 +86,32 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   float* lo = S.logits_out ? S.logits_out + (int64_t)b * S.ld_logits + n0 : nullptr;
   float* so = S.scores_out ? S.scores_out + (int64_t)b * S.ld_scores + n0 : nullptr;
 
-  for (int r = wave * 2; r < rows; r += 8) {
-    const bool two = (r + 1) < rows;
+  // Rows the attention mask removes (att_mask = 1: proposals below the score threshold / padding) get the score -1e8
+  // whatever their features are, and - as soon as the chunk holds one live row - the softmax weight exp(-1e8 - m) = 0
+  // exactly: neither their projection row nor their feature row is fetched.  Wave 0 compacts the chunk's live rows into
+  // s_live (the chunk has <= 64 rows: one ballot); a chunk without any live row keeps all its rows in the context pass
+  // (uniform weights; only matters when the whole sample is masked).
+  if (wave == 0) {
+    const bool in = lane < rows;
+    const bool live = in && !(am && am[lane]);
+    const unsigned long long bal = __ballot(live);
+    const int nl = __popcll(bal);
+    if (live) s_live[__popcll(bal & ((1ull << lane) - 1ull))] = lane;
+    if (in && !live) {
+      s_score[lane] = GVD_MIN_VALUE;
+      if (so) so[lane] = GVD_MIN_VALUE;
+      if (lo) lo[lane] = GVD_MIN_VALUE;
+    }
+    if (nl == 0 && in) s_live[lane] = lane;
+    if (lane == 0) { s_n[0] = nl; s_n[1] = nl ? nl : rows; }
+  }
+  __syncthreads();
+  const int nlive = s_n[0];
+  for (int i = wave * 2; i < nlive; i += 8) {
+    const bool two = (i + 1) < nlive;
+    const int r = s_live[i], r2 = two ? s_live[i + 1] : r;
     const float* p0 = pf + (int64_t)r * ATT_A;
-    const float* p1 = two ? p0 + ATT_A : p0;
+    const float* p1 = pf + (int64_t)r2 * ATT_A;
     f32x4 x00 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 4 * lane));
     f32x4 x01 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane));
     f32x4 x10 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 4 * lane));
@@ -103,15 +127,13 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
     s0 = wave_sum(s0) + ab;
     s1 = wave_sum(s1) + ab;
     if (lane == 0) {
-      float e0 = (am && am[r]) ? GVD_MIN_VALUE : s0;
-      s_score[r] = e0;
-      if (so) so[r] = e0;
-      if (lo) lo[r] = (pm && pm[r]) ? GVD_MIN_VALUE : e0;
+      s_score[r] = s0;
+      if (so) so[r] = s0;
+      if (lo) lo[r] = (pm && pm[r]) ? GVD_MIN_VALUE : s0;
       if (two) {
-        float e1 = (am && am[r + 1]) ? GVD_MIN_VALUE : s1;
-        s_score[r + 1] = e1;
-        if (so) so[r + 1] = e1;
-        if (lo) lo[r + 1] = (pm && pm[r + 1]) ? GVD_MIN_VALUE : e1;
+        s_score[r2] = s1;
+        if (so) so[r2] = s1;
+        if (lo) lo[r2] = (pm && pm[r2]) ? GVD_MIN_VALUE : s1;
       }
     }
   }
@@ -138,21 +160,26 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   // ---- phase 2: partial context.  thread owns columns [4*tid, 4*tid+4) of H = 1024
   const float* fb = S.feats + ((int64_t)fbi * S.N + n0) * ATT_H + 4 * tid;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  int r = 0;
-  for (; r + 8 <= rows; r += 8) {
+  const int nctx = s_n[1];                 // live rows (their order is the row order: same sums as over all rows)
+  int i = 0;
+  for (; i + 8 <= nctx; i += 8) {
     f32x4 v[8];
+    int rr[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)(r + u) * ATT_H));
+    for (int u = 0; u < 8; ++u) rr[u] = s_live[i + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)rr[u] * ATT_H));
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const float pw = s_score[r + u];
+      const float pw = s_score[rr[u]];
       acc[0] = fmaf(pw, v[u][0], acc[0]); acc[1] = fmaf(pw, v[u][1], acc[1]);
       acc[2] = fmaf(pw, v[u][2], acc[2]); acc[3] = fmaf(pw, v[u][3], acc[3]);
     }
   }
-  for (; r < rows; ++r) {
-    const f32x4 v = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)r * ATT_H));
-    const float pw = s_score[r];
+  for (; i < nctx; ++i) {
+    const int rr = s_live[i];
+    const f32x4 v = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)rr * ATT_H));
+    const float pw = s_score[rr];
     acc[0] = fmaf(pw, v[0], acc[0]); acc[1] = fmaf(pw, v[1], acc[1]);
     acc[2] = fmaf(pw, v[2], acc[2]); acc[3] = fmaf(pw, v[3], acc[3]);
   }

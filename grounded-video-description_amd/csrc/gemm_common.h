@@ -66,3 +66,6 @@ __device__ __forceinline__ void gemm_epilogue_plain(const KParams& p, int M, con
 
 // gemm_pipe.hip
 int gvd_gemm_pipe_launch(KParams& p, int batch, hipStream_t st);
+// gemm_small.hip: pipelined 64 x 64 kernel for the token-loop products (plain / LSTM-cell epilogue)
+bool gvd_gemm_small_ok(const KParams& p, int batch);
+int gvd_gemm_small_launch(KParams& p, bool lstm, hipStream_t st);

@@ -267,6 +267,8 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
     }
     return launch<128, 128, 2, 2, false, 1>(p, a->batch, st);
   }
+  static const int small = getenv("GVD_GEMM_SMALL") ? atoi(getenv("GVD_GEMM_SMALL")) : 1;     // A/B knob
+  if (small && gvd_gemm_small_ok(p, a->batch)) return gvd_gemm_small_launch(p, false, st);
   return launch<64, 64, 2, 2, false>(p, a->batch, st);
 }
 
@@ -303,5 +305,7 @@ extern "C" int gvd_lstm_cell_fwd(const gvd_lstm_args* a, gvd_stream_t stream) {
     return gvd_gemv_lstm(v, st);
   }
   if (a->B <= 32) return launch<32, 128, 1, 4, true>(p, 1, st);
+  static const int small = getenv("GVD_GEMM_SMALL") ? atoi(getenv("GVD_GEMM_SMALL")) : 1;
+  if (small && gvd_gemm_small_ok(p, 1) && (a->H % 16) == 0) return gvd_gemm_small_launch(p, true, st);
   return launch<64, 64, 2, 2, true>(p, 1, st);
 }

@@ -584,3 +584,19 @@ def test_linear_autograd_matches_torch():
     np.testing.assert_allclose(gx.cpu().numpy(), x.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
     assert float((gw - w.grad).abs().max() / w.grad.abs().max()) < 1e-5
     np.testing.assert_allclose(gb.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 5000, 1024), (256, 1024, 1024), (200, 4096, 3072), (96, 433, 2048), (512, 512, 1536)])
+def test_gemm_small_pipelined_kernel(M, N, K):
+    """Token-loop products (17..512 rows) run the pipelined 64 x 64 kernel (gemm_small.hip): vs fp64 and BITWISE vs the
+    general kernel (32-row slices take its 32 x 128 tiles: same k order per output element)."""
+    g = _g(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    out = ops.gemm_nt(A, W, b, 1)
+    ref = (A.double() @ W.double().t() + b.double()).clamp(min=0)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-5, atol=3e-5)
+    for r0 in range(0, M, 32):
+        part = ops.gemm_nt(A[r0:r0 + 32].contiguous(), W, b, 1)
+        assert torch.equal(part, out[r0:r0 + 32]), 'pipelined small-M kernel differs bitwise from the general kernel'

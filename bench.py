@@ -169,6 +169,9 @@ def _roofline(attn_ms, attn_n, bytes_per_launch, traffic, kernel):
             'achieved': None if achieved is None else round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic[0], 'traffic_source': traffic[1], 'bytes_per_launch': bytes_per_launch,
+            # the kernel does not fetch rows the attention mask removes (weight exactly 0), so the HBM traffic is below the
+            # algorithmic bytes (which count every row): the physical HBM rate is traffic / duration
+            'hbm_rate_from_traffic_GBs': None if (not attn_n or not traffic[0]) else round(traffic[0] / avg_s / 1e9, 1),
             'avg_launch_us': round(avg_s * 1e6, 2), 'launches_timed': attn_n}
 
 

@@ -195,6 +195,8 @@ template <int G, bool NT>
 __global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams p) {
   __shared__ float s_score[G][MAX_CHUNK];
   __shared__ float s_m[G];
+  __shared__ int s_live[MAX_CHUNK];
+  __shared__ int s_n[2];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int smp = blockIdx.y;                    // sample; its beam rows are smp*G + g
   int c = blockIdx.x;
@@ -217,8 +219,37 @@ __global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams
   const float ab = *S.alpha_bias;
   const float* pf = S.p_feats + ((int64_t)smp * S.N + n0) * ATT_A;
 
+  // Rows masked for EVERY beam of the sample are not fetched (score -1e8 whatever the features; weight exactly 0 as
+  // long as each beam has a live row in the chunk) - see attn_partial_kernel.  Wave 0 compacts the live rows.
+  if (wave == 0) {
+    const bool in = lane < rows;
+    bool all_masked = in && S.att_mask != nullptr;
+    bool each_has_live = true;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const bool mg = in && S.att_mask && S.att_mask[((int64_t)smp * G + g) * S.ld_att_mask + n0 + lane];
+      all_masked = all_masked && mg;
+      each_has_live = each_has_live && (__ballot(in && !mg) != 0ull);
+    }
+    const bool live = in && !all_masked;
+    const unsigned long long bal = __ballot(live);
+    if (live) s_live[__popcll(bal & ((1ull << lane) - 1ull))] = lane;
+    if (in && !live) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int64_t row = (int64_t)smp * G + g;
+        s_score[g][lane] = GVD_MIN_VALUE;
+        if (S.scores_out) S.scores_out[row * S.ld_scores + n0 + lane] = GVD_MIN_VALUE;
+        if (S.logits_out) S.logits_out[row * S.ld_logits + n0 + lane] = GVD_MIN_VALUE;
+      }
+    }
+    if (lane == 0) { s_n[0] = __popcll(bal); s_n[1] = each_has_live ? 1 : 0; }
+  }
+  __syncthreads();
+  const int nlive = s_n[0];
   // ---- phase 1: one projection row per wave per pass, G scores from it
-  for (int r = wave; r < rows; r += 4) {
+  for (int i = wave; i < nlive; i += 4) {
+    const int r = s_live[i];
     const float* p0 = pf + (int64_t)r * ATT_A;
     const f32x4 x0 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 4 * lane));
     const f32x4 x1 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane));
@@ -269,25 +300,31 @@ __global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams
   f32x4 acc[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int r = 0;
-  for (; r + 4 <= rows; r += 4) {
+  const bool skip = s_n[1] != 0;                 // every beam has a live row: rows masked for all beams weigh exactly 0
+  const int nctx = skip ? nlive : rows;
+  int i = 0;
+  for (; i + 4 <= nctx; i += 4) {
     f32x4 v[4];
+    int rr[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)(r + u) * ATT_H));
+    for (int u = 0; u < 4; ++u) rr[u] = skip ? s_live[i + u] : i + u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)rr[u] * ATT_H));
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const float pw = s_score[g][r + u];
+        const float pw = s_score[g][rr[u]];
         acc[g][0] = fmaf(pw, v[u][0], acc[g][0]); acc[g][1] = fmaf(pw, v[u][1], acc[g][1]);
         acc[g][2] = fmaf(pw, v[u][2], acc[g][2]); acc[g][3] = fmaf(pw, v[u][3], acc[g][3]);
       }
   }
-  for (; r < rows; ++r) {
-    const f32x4 v = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)r * ATT_H));
+  for (; i < nctx; ++i) {
+    const int rr = skip ? s_live[i] : i;
+    const f32x4 v = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)rr * ATT_H));
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const float pw = s_score[g][r];
+      const float pw = s_score[g][rr];
       acc[g][0] = fmaf(pw, v[0], acc[g][0]); acc[g][1] = fmaf(pw, v[1], acc[g][1]);
       acc[g][2] = fmaf(pw, v[2], acc[g][2]); acc[g][3] = fmaf(pw, v[3], acc[g][3]);
     }

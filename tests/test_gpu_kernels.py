@@ -597,6 +597,6 @@ def test_gemm_small_pipelined_kernel(M, N, K):
     out = ops.gemm_nt(A, W, b, 1)
     ref = (A.double() @ W.double().t() + b.double()).clamp(min=0)
     np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-5, atol=3e-5)
-    for r0 in range(0, M, 32):
+    for r0 in range(0, M - 16, 32):                     # (a last slice of <= 16 rows would take the skinny GEMV kernel)
         part = ops.gemm_nt(A[r0:r0 + 32].contiguous(), W, b, 1)
         assert torch.equal(part, out[r0:r0 + 32]), 'pipelined small-M kernel differs bitwise from the general kernel'

@@ -254,6 +254,8 @@ def main():
     if world != args.gpus:
         sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     dev = torch.device('cuda', local)
+    if world > 1:       # the ranks generate their synthetic inputs on the host at the same time: share the cores
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
 
     import gvd_amd  # noqa: F401
     from gvd_amd import att_model, hip, ops, opts, synth

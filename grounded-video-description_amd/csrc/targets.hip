@@ -110,9 +110,20 @@ __global__ __launch_bounds__(256) void masked_lsm_loss_kernel(const float* __res
   __syncthreads();
   if (tid == 0) {
     const float ct = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    if (ct > 0.f) { atomicAdd(acc, st); atomicAdd(acc + 1, ct); }
+    // per-row partials; masked_lsm_reduce_kernel adds them in row order (no atomics: run-to-run bit-reproducible)
+    acc[2 + 2 * row] = ct > 0.f ? st : 0.f;
+    acc[3 + 2 * row] = ct > 0.f ? ct : 0.f;
     if (row_lse) row_lse[row] = mx + lse;
   }
+}
+
+// acc[0] = sum of the row sums, acc[1] = sum of the row counts, in a fixed order: lane-strided partial sums of one wave,
+// then the xor-shuffle tree
+__global__ __launch_bounds__(64) void masked_lsm_reduce_kernel(float* acc, int rows) {
+  float s = 0.f, c = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 64) { s += acc[2 + 2 * r]; c += acc[3 + 2 * r]; }
+  s = wave_sum(s); c = wave_sum(c);
+  if (threadIdx.x == 0) { acc[0] = s; acc[1] = c; }
 }
 
 }  // namespace
@@ -147,6 +158,7 @@ extern "C" int gvd_masked_lsm_loss(const float* x, int64_t ldx, const float* lab
   if (!x || !label || !acc || rows <= 0 || N <= 0) return GVD_EINVAL;
   hipLaunchKernelGGL(masked_lsm_loss_kernel, dim3((unsigned)rows), dim3(256), 0, gvd_s(stream), x, ldx, label,
                      ld_label, N, acc, row_lse);
+  hipLaunchKernelGGL(masked_lsm_reduce_kernel, dim3(1), dim3(64), 0, gvd_s(stream), acc, rows);
   GVD_CHECK_LAUNCH();
   return 0;
 }

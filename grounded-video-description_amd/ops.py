@@ -310,7 +310,7 @@ def masked_lsm_loss(x, label):
     N = x.shape[-1]
     x2, l2 = x.reshape(-1, N), label.reshape(-1, N)
     assert x2.stride(-1) == 1 and l2.stride(-1) == 1
-    acc = torch.zeros(2, device=x.device, dtype=torch.float32)
+    acc = torch.empty(2 + 2 * x2.shape[0], device=x.device, dtype=torch.float32)
     lse = torch.empty(x2.shape[0], device=x.device, dtype=torch.float32)
     check(lib().gvd_masked_lsm_loss(ptr(x2), x2.stride(0), ptr(l2), l2.stride(0), x2.shape[0], N, ptr(acc),
                                     ptr(lse), stream_ptr()), 'gvd_masked_lsm_loss')

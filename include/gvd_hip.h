@@ -344,8 +344,9 @@ int gvd_step_targets(const float* overlaps, const uint8_t* mask_boxes, const uin
                      uint8_t* frm_masks, gvd_stream_t stream);
 
 /* sum and count of -log_softmax(x[row,:])[n] over entries with label[row,n] != 0 (utils.py:139,142):
- * acc[0] += sum, acc[1] += count (fp32 atomics on a zeroed 2-float buffer); row_lse (optional) keeps
- * each row's logsumexp for the backward. */
+ * acc[0] = sum, acc[1] = count; acc must hold 2 + 2*rows floats (per-row partials follow the two totals and are added
+ * in a fixed order: no atomics, bit-reproducible run to run); row_lse (optional) keeps each row's logsumexp for the
+ * backward. */
 int gvd_masked_lsm_loss(const float* x, int64_t ldx, const float* label, int64_t ld_label, int rows, int N,
                         float* acc, float* row_lse, gvd_stream_t stream);
 

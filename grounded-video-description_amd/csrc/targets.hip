@@ -126,7 +126,45 @@ __global__ __launch_bounds__(64) void masked_lsm_reduce_kernel(float* acc, int r
   if (threadIdx.x == 0) { acc[0] = s; acc[1] = c; }
 }
 
+// Region-classification loss (model.py:345-350): over the (box k, proposal r) pairs with sim_target > 0,
+// -mean( clamp(log sim_mat[b, sim_target[b,k,r], r], -100) ): gather + log + masked mean in one pass, per-block partials
+// (sum, count) reduced in a fixed order by masked_lsm_reduce_kernel.
+__global__ __launch_bounds__(256) void cls_loss_kernel(const float* __restrict__ sim, const int64_t* __restrict__ tgt,
+                                                       int D1, int R, int K, int64_t n, float* acc) {
+  __shared__ float s_red[8];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float s = 0.f, c = 0.f;
+  if (i < n) {
+    const int64_t t = tgt[i];
+    if (t > 0) {
+      const int r = (int)(i % R);
+      const int64_t b = i / ((int64_t)R * K);
+      s = -fmaxf(logf(sim[(b * D1 + t) * R + r]), -100.f);
+      c = 1.f;
+    }
+  }
+  s = wave_sum(s); c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = s; s_red[4 + (threadIdx.x >> 6)] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    acc[2 + 2 * blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    acc[3 + 2 * blockIdx.x] = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+  }
+}
+
 }  // namespace
+
+extern "C" int gvd_cls_loss(const float* sim_mat, const int64_t* sim_target, int B, int D1, int R, int K, float* acc,
+                            gvd_stream_t stream) {
+  if (!sim_mat || !sim_target || !acc || B <= 0 || D1 <= 0 || R <= 0 || K <= 0) return GVD_EINVAL;
+  const int64_t n = (int64_t)B * K * R;
+  const int nblk = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(cls_loss_kernel, dim3((unsigned)nblk), dim3(256), 0, gvd_s(stream), sim_mat, sim_target, D1, R, K, n,
+                     acc);
+  hipLaunchKernelGGL(masked_lsm_reduce_kernel, dim3(1), dim3(64), 0, gvd_s(stream), acc, nblk);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int gvd_iou_targets(const float* ppls, int ppl_ld, const float* gt, int gt_ld, const uint8_t* frm_mask,
                                const uint8_t* pnt_mask, int B, int R, int K, float* overlaps, int64_t* sim_target,

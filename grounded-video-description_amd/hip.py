@@ -126,6 +126,7 @@ _SIG = {
                                   c_f32p, c_i64p, C.c_void_p]),
     'gvd_step_targets': (C.c_int, [c_f32p, c_u8p, c_u8p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    c_f32p, c_u8p, C.c_void_p]),
+    'gvd_cls_loss': (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     'gvd_masked_lsm_loss': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, c_f32p,
                                       C.c_void_p]),
 }

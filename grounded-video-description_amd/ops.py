@@ -443,6 +443,41 @@ def masked_lsm(x, label):
     return masked_lsm_loss(x.detach(), label)[0]
 
 
+class _ClsLossFn(torch.autograd.Function):
+    """-mean(clamp(log sim_mat[b, target, r], -100)) over target > 0 (model.py:345-350): fused gather + log + masked mean."""
+
+    @staticmethod
+    def forward(ctx, sim_mat, sim_target):
+        B, D1, R = sim_mat.shape
+        K = sim_target.shape[1]
+        nblk = (B * K * R + 255) // 256
+        acc = torch.empty(2 + 2 * nblk, device=sim_mat.device, dtype=torch.float32)
+        check(lib().gvd_cls_loss(ptr(sim_mat), ptr(sim_target), B, D1, R, K, ptr(acc), stream_ptr()), 'gvd_cls_loss')
+        ctx.save_for_backward(sim_mat, sim_target, acc)
+        return acc[0] / acc[1]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        sim_mat, tgt, acc = ctx.saved_tensors
+        p = torch.gather(sim_mat, 1, tgt)
+        g = torch.where((tgt > 0) & (p > 3.7200759760208555e-44), -(dloss / acc[1]) / p, torch.zeros_like(p))
+        return torch.zeros_like(sim_mat).scatter_add_(1, tgt, g), None
+
+
+def cls_loss(sim_mat, sim_target):
+    """Region-classification loss on the HIP kernel (NaN for an empty selection, like the reference's mean over nothing)."""
+    require_cuda_f32(sim_mat)
+    assert sim_mat.is_contiguous() and sim_target.is_contiguous() and sim_target.dtype == torch.int64
+    if torch.is_grad_enabled() and sim_mat.requires_grad:
+        return _ClsLossFn.apply(sim_mat, sim_target)
+    return _ClsLossFn.forward(_NoCtx(), sim_mat.detach(), sim_target)
+
+
+class _NoCtx:
+    def save_for_backward(self, *a):
+        pass
+
+
 # --------------------------------------------------------------------------------------------------
 # backward kernels of the decoder loop (used by decoder_bwd.DecoderLoopFn)
 # --------------------------------------------------------------------------------------------------

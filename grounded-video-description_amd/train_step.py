@@ -48,8 +48,8 @@ def forward_train(model, segs_feat, input_seq, gt_seq, ppls, gt_boxes, mask_boxe
     cls_loss = cls_pred = None
     if not model.test_mode:
         if not eval_obj_ground:
-            p = torch.masked_select(torch.gather(sim_mat, 1, sim_target), sim_mask)     # model.py:348-350
-            cls_loss = -torch.clamp(torch.log(p), min=-100.0).mean()                     # BCE against ones
+            # model.py:348-350 (BCE against ones over sim_target > 0): fused gather + log + masked mean (T2)
+            cls_loss = ops.cls_loss(sim_mat.contiguous(), sim_target)
         else:
             tgt = torch.masked_select(sim_target, sim_mask)
             prd = torch.masked_select(sim_mat.max(dim=1)[1].unsqueeze(1).expand_as(sim_target), sim_mask)

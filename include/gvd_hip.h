@@ -350,6 +350,12 @@ int gvd_step_targets(const float* overlaps, const uint8_t* mask_boxes, const uin
 int gvd_masked_lsm_loss(const float* x, int64_t ldx, const float* label, int64_t ld_label, int rows, int N,
                         float* acc, float* row_lse, gvd_stream_t stream);
 
+/* Region-classification loss (model.py:345-350, T2): acc[0] = sum over (b,k,r) with sim_target > 0 of
+ * -max(log sim_mat[b, sim_target[b,k,r], r], -100), acc[1] = their count; sim_mat f32 [B,D1,R] (class softmax),
+ * sim_target i64 [B,K,R]; acc holds 2 + 2*ceil(B*K*R/256) floats (ordered partials, no atomics). */
+int gvd_cls_loss(const float* sim_mat, const int64_t* sim_target, int B, int D1, int R, int K, float* acc,
+                 gvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -600,3 +600,26 @@ def test_gemm_small_pipelined_kernel(M, N, K):
     for r0 in range(0, M - 16, 32):                     # (a last slice of <= 16 rows would take the skinny GEMV kernel)
         part = ops.gemm_nt(A[r0:r0 + 32].contiguous(), W, b, 1)
         assert torch.equal(part, out[r0:r0 + 32]), 'pipelined small-M kernel differs bitwise from the general kernel'
+
+
+def test_cls_loss_fused_matches_torch():
+    """T2: fused gather + log + masked mean of the region-classification loss (model.py:345-350), value and gradient."""
+    g = _g(17)
+    B, D1, R, K = 3, 433, 257, 5
+    logits = (torch.randn(B, D1, R, generator=g) * 4).cuda().requires_grad_(True)
+    tgt = torch.randint(0, D1, (B, K, R), generator=g)
+    tgt[torch.rand(B, K, R, generator=g) < 0.7] = 0
+    tgt = tgt.cuda()
+    sim = torch.softmax(logits, 1)
+    got = ops.cls_loss(sim, tgt)
+    got.backward()
+    g1 = logits.grad.clone()
+    logits.grad = None
+    sim2 = torch.softmax(logits, 1)
+    p = torch.masked_select(torch.gather(sim2, 1, tgt), tgt > 0)
+    want = -torch.clamp(torch.log(p), min=-100.0).mean()
+    want.backward()
+    assert abs(float(got) - float(want)) < 1e-5
+    np.testing.assert_allclose(g1.cpu().numpy(), logits.grad.cpu().numpy(), rtol=1e-4, atol=1e-7)
+    assert torch.equal(ops.cls_loss(sim.detach(), tgt), ops.cls_loss(sim.detach(), tgt))      # ordered reduction
+    assert torch.isnan(ops.cls_loss(sim.detach(), torch.zeros_like(tgt)))                      # empty selection -> NaN

@@ -506,7 +506,7 @@ class TopDownModel(nn.Module):
             else:
                 seq, lps, att2 = ops.greedy_decode(pre, P, pre['pnt_mask'], self.seq_length, self.unk_idx,
                                                     prof=getattr(self, 'kernel_timer', None), flags=self._flags())
-        if len(self._flags()) > 4096:        # a caller that never checks must not grow the list without bound
+        if len(self._flags()) + len(self.__dict__.get('_contract_flags', ())) > 4096:   # a caller that never checks must not grow the lists without bound
             self.check_kernel_status()
         return seq, lps, att2, pre['sim_mat_static']
 

@@ -271,6 +271,44 @@ class TopDownModel(nn.Module):
             cache[key] = hit
         return hit[1]
 
+    @staticmethod
+    def _add_ln(x, y, ln):
+        """ResidualBlock tail (transformer.py:79-88): add + the custom LayerNorm, one fused row kernel forward and one
+        backward for the d_model the kernels are built for; the module's elementwise form otherwise."""
+        if x.shape[-1] == 1024 and x.is_cuda and os.environ.get('GVD_LN_FUSED_BWD', '1') == '1':
+            return ops.add_layernorm(x, y, ln.gamma, ln.beta, ln.eps)
+        return ln(x + y)
+
+    def _obj_interact_train(self, x, scale):
+        """Training path of the region encoder (transformer.py:39-117) with every product on the fp32-MFMA GEMM: the
+        region axis is zero-padded to Rp (a multiple of 32) for the whole stack, q | k | v come from ONE packed projection
+        with heads padded to 192 columns (the packing is an index_copy of the parameters: gradients flow back to wq / wk /
+        wv / wo), the attention core is ops.enc_attn_core (materialised maps, fused softmax + dropout row kernels) and the
+        residual LayerNorms are fused row kernels forward and backward.  Pad rows never reach the loss (their gradients
+        are exactly zero) and are masked out of every softmax."""
+        B, R, d = x.shape
+        nh, HP = 6, ops.TRAIN_HEAD_PAD
+        Rp = -(-R // 32) * 32
+        sizes = [t.shape[-1] for t in x.reshape(-1, d)[:1].chunk(nh, -1)]
+        starts = [sum(sizes[:i]) for i in range(nh)]
+        idx = torch.cat([torch.arange(sizes[h]) + h * HP for h in range(nh)]).to(x.device)
+        idx3 = torch.cat([idx + j * nh * HP for j in range(3)])
+        xp = F.pad(x, (0, 0, 0, Rp - R)).reshape(B * Rp, d)
+        p_drop = 0.2 if self.training else 0.0
+        for lay in self.obj_interact.encoder.layers:
+            sa = lay.selfattn.layer
+            w_qkv = torch.zeros(3 * nh * HP, d, device=x.device, dtype=torch.float32).index_copy(
+                0, idx3, torch.cat([sa.wq.weight, sa.wk.weight, sa.wv.weight], 0))
+            w_o = torch.zeros(d, nh * HP, device=x.device, dtype=torch.float32).index_copy(1, idx, sa.wo.weight)
+            qkv = ops.linear(xp, w_qkv).view(B, Rp, 3 * nh * HP)
+            o = ops.enc_attn_core(qkv, R, nh, 1.0 / scale, p_drop)
+            att = ops.linear(o.view(B * Rp, nh * HP), w_o)
+            ff = lay.feedforward.layer
+            xp = self._add_ln(xp, F.dropout(att, 0.2, self.training), lay.selfattn.layernorm)
+            y = self._lin(self._lin(xp, ff.linear1, act=1), ff.linear2)
+            xp = self._add_ln(xp, F.dropout(y, 0.2, self.training), lay.feedforward.layernorm)
+        return xp.view(B, Rp, d)[:, :R]
+
     def _obj_interact_fused(self, x, ci=None):
         """Inference path of the encoder on the HIP kernels only (transformer.py:107-190): per layer ONE projection GEMM
         for q|k|v against row-permuted weights that drop every head into its own zero-padded 176-column slot (16-byte
@@ -361,6 +399,10 @@ class TopDownModel(nn.Module):
         if (fused and not self.training and self.flash_obj_interact and os.environ.get('GVD_ENC_FUSED', '1') == '1'
                 and scale == 2.0 ** round(math.log2(scale)) and d % 32 == 0 and -(-d // 6) <= ops.HEAD_PAD):
             return self._obj_interact_fused(x)
+        if (not fused and self.flash_obj_interact and x.is_cuda and os.environ.get('GVD_ENC_TRAIN_MFMA', '1') == '1'
+                and scale == 2.0 ** round(math.log2(scale)) and d % 32 == 0 and -(-d // 6) <= ops.TRAIN_HEAD_PAD
+                and x.shape[1] % 4 == 0 and x.shape[1] >= 4 and -(-x.shape[1] // 32) * 32 <= 2048):
+            return self._obj_interact_train(x, scale)
         for lay in self.obj_interact.encoder.layers:
             sa = lay.selfattn.layer
             # projections on the MFMA GEMM, forward and (K-strided operands) backward
@@ -389,9 +431,11 @@ class TopDownModel(nn.Module):
                 ln = lay.feedforward.layernorm
                 x = ops.add_layernorm_unbiased(x, y, ln.gamma, ln.beta, ln.eps)
             else:
-                x = lay.selfattn.layernorm(x + F.dropout(att, 0.2, self.training))
+                # ResidualBlock (transformer.py:79-88): dropout on the branch, then add + LayerNorm as one fused row
+                # kernel forward and one backward
+                x = self._add_ln(x, F.dropout(att, 0.2, self.training), lay.selfattn.layernorm)
                 y = self._lin(self._lin(x, ff.linear1, act=1), ff.linear2)
-                x = lay.feedforward.layernorm(x + F.dropout(y, 0.2, self.training))
+                x = self._add_ln(x, F.dropout(y, 0.2, self.training), lay.feedforward.layernorm)
         return x
 
     def _preamble(self, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, allow_compact=False):

@@ -36,7 +36,10 @@ struct Seg {
   unsigned voa[NLD], vow[NLD];
 };
 
-template <bool EPI_LDS, bool AT = false, bool BT = false>
+// EDGE: launches whose last M or N tile is at most half full (e.g. the N = 192 head blocks of the training attention
+// core) skip the MFMAs of 32 x 32 sub-tiles that lie wholly outside the output - a wave with nothing to multiply leaves its
+// SIMD's matrix pipe to the other resident workgroup, so a half-empty tile costs about half a tile.
+template <bool EPI_LDS, bool AT = false, bool BT = false, bool EDGE = false>
 __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];     // 73,728 B -> two workgroups per CU
   float* As = smem;
@@ -179,12 +182,19 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);     // keep the reads AHEAD of the MFMAs that follow in program order
   };
+  bool lv[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      lv[i][j] = !EDGE || (m0 + __builtin_amdgcn_readfirstlane(wm) * 64 + i * 32 < M &&
+                           n0 + __builtin_amdgcn_readfirstlane(wn) * 64 + j * 32 < p.N);
   auto mfma4 = [&](const f32x4 (&a)[2], const f32x4 (&b)[2], int t) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+        if (!EDGE || lv[i][j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
   };
   auto mfma16 = [&](const f32x4 (&a)[2], const f32x4 (&b)[2]) {
 #pragma unroll
@@ -262,6 +272,24 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
 
 }  // namespace
 
+namespace {
+template <bool EDGE>
+int pipe_launch_t(const KParams& p, dim3 grid, bool lds_epi, hipStream_t st) {
+  if (p.a_t && p.w_t) {
+    if (lds_epi) hipLaunchKernelGGL((gemm_pipe_kernel<true, true, true, EDGE>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_pipe_kernel<false, true, true, EDGE>), grid, dim3(256), 0, st, p);
+  } else if (p.w_t) {
+    if (lds_epi) hipLaunchKernelGGL((gemm_pipe_kernel<true, false, true, EDGE>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_pipe_kernel<false, false, true, EDGE>), grid, dim3(256), 0, st, p);
+  } else {
+    if (lds_epi) hipLaunchKernelGGL((gemm_pipe_kernel<true, false, false, EDGE>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_pipe_kernel<false, false, false, EDGE>), grid, dim3(256), 0, st, p);
+  }
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
+}  // namespace
+
 int gvd_gemm_pipe_launch(KParams& p, int batch, hipStream_t st) {
   p.ntm = (p.M + BM - 1) / BM;
   p.ntn = (p.N + BN - 1) / BN;
@@ -272,21 +300,10 @@ int gvd_gemm_pipe_launch(KParams& p, int batch, hipStream_t st) {
     // backward products: one segment, 16-byte aligned K-strided operands, whole 4-column chunks, no device row count
     const bool ok = p.nseg == 1 && !p.m_dev && (!p.a_t || ((p.M % 4) == 0 && p.M >= 4)) &&
                     (!p.w_t || ((p.N % 4) == 0 && p.N >= 4)) && (p.abs_[0] % 4) == 0 && (p.wbs[0] % 4) == 0;
-    if (!ok) return GVD_EINVAL;
-    if (p.a_t && p.w_t) {
-      if (lds_epi) hipLaunchKernelGGL((gemm_pipe_kernel<true, true, true>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gemm_pipe_kernel<false, true, true>), grid, dim3(256), 0, st, p);
-    } else if (p.w_t) {
-      if (lds_epi) hipLaunchKernelGGL((gemm_pipe_kernel<true, false, true>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gemm_pipe_kernel<false, false, true>), grid, dim3(256), 0, st, p);
-    } else {
-      return GVD_EINVAL;                      // (A K-strided with W K-major is not a product the path needs)
-    }
-    GVD_CHECK_LAUNCH();
-    return 0;
+    if (!ok || (p.a_t && !p.w_t)) return GVD_EINVAL;   // (A K-strided with W K-major is not a product the path needs)
   }
-  if (lds_epi) hipLaunchKernelGGL(gemm_pipe_kernel<true>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(gemm_pipe_kernel<false>, grid, dim3(256), 0, st, p);
-  GVD_CHECK_LAUNCH();
-  return 0;
+  // a last tile at most half full in N (few N tiles) or in M (few M tiles) is worth the sub-tile skip
+  const int remn = p.N - (p.ntn - 1) * BN, remm = p.M - (p.ntm - 1) * BM;
+  const bool edge = !p.m_dev && ((remn <= BN / 2 && p.ntn <= 4) || (remm <= BM / 2 && p.ntm <= 4));
+  return edge ? pipe_launch_t<true>(p, grid, lds_epi, st) : pipe_launch_t<false>(p, grid, lds_epi, st);
 }

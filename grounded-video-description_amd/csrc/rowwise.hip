@@ -57,6 +57,98 @@ __global__ __launch_bounds__(256) void add_ln_unbiased_kernel(const float* __res
   }
 }
 
+// Backward of out = gamma * (s - mean) / (std_unbiased + eps) + beta, s = x + y (the encoder's ResidualBlock LayerNorm,
+// transformer.py:66-88): ds (= dx = dy_branch) per row, and per-workgroup partial sums of dgamma / dbeta (a workgroup
+// walks ROWS_PER_WG rows with one wave per row; lanes keep the partials of their 16 columns in registers; the host adds
+// the [nwg, D] partials in order).  Statistics are recomputed from s: nothing but x, y is kept from the forward.
+constexpr int LNB_ROWS = 64;
+template <int D>
+__global__ __launch_bounds__(256) void add_ln_unbiased_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                  const float* __restrict__ dout,
+                                                                  const float* __restrict__ gamma, float* __restrict__ ds,
+                                                                  float* __restrict__ part, int64_t rows, float eps) {
+  constexpr int NV = D / 256;
+  __shared__ float s_acc[4][2][D / 4 + 4];      // staged one quarter of the columns at a time (see below)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 g[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    g[i] = *reinterpret_cast<const f32x4*>(gamma + i * 256 + 4 * lane);
+    dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * LNB_ROWS;
+  for (int rr = wave; rr < LNB_ROWS; rr += 4) {
+    const int64_t row = r0 + rr;
+    if (row >= rows) break;
+    f32x4 v[NV], d[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[i] = *reinterpret_cast<const f32x4*>(x + row * D + i * 256 + 4 * lane);
+      if (y) v[i] += *reinterpret_cast<const f32x4*>(y + row * D + i * 256 + 4 * lane);
+      d[i] = *reinterpret_cast<const f32x4*>(dout + row * D + i * 256 + 4 * lane);
+      sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mean = wave_sum(sum) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[i][k] -= mean; q = fmaf(v[i][k], v[i][k], q); }
+    const float stdv = sqrtf(wave_sum(q) / (D - 1));
+    const float inv = 1.0f / (stdv + eps);
+    // dxhat_j = gamma_j dout_j inv;  dstd = -sum_j gamma_j dout_j xhat_j inv^2
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gd = g[i][k] * d[i][k];
+        t = fmaf(gd, v[i][k], t);
+        dg[i][k] = fmaf(d[i][k], v[i][k] * inv, dg[i][k]);
+        db[i][k] += d[i][k];
+      }
+    const float dstd = -wave_sum(t) * inv * inv;
+    const float c = stdv > 0.f ? dstd / ((D - 1) * stdv) : 0.f;
+    // grad_j = gamma_j dout_j inv + c xhat_j; ds_j = grad_j - mean(grad)   (sum_j xhat_j = 0)
+    float gs = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[i][k] = fmaf(g[i][k] * d[i][k], inv, c * v[i][k]);
+        gs += v[i][k];
+      }
+    const float gm = wave_sum(gs) / D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f32x4 o = {v[i][0] - gm, v[i][1] - gm, v[i][2] - gm, v[i][3] - gm};
+      *reinterpret_cast<f32x4*>(ds + row * D + i * 256 + 4 * lane) = o;
+    }
+  }
+  // reduce the 4 waves' partials through LDS, one 256-column slab (index i) at a time
+  float* pg = part + (int64_t)blockIdx.x * 2 * D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(&s_acc[wave][0][4 * lane]) = dg[i];
+    *reinterpret_cast<f32x4*>(&s_acc[wave][1][4 * lane]) = db[i];
+    __syncthreads();
+    if (wave == 0) {
+      f32x4 a = *reinterpret_cast<f32x4*>(&s_acc[0][0][4 * lane]);
+      f32x4 b = *reinterpret_cast<f32x4*>(&s_acc[0][1][4 * lane]);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        a += *reinterpret_cast<f32x4*>(&s_acc[w][0][4 * lane]);
+        b += *reinterpret_cast<f32x4*>(&s_acc[w][1][4 * lane]);
+      }
+      *reinterpret_cast<f32x4*>(pg + i * 256 + 4 * lane) = a;
+      *reinterpret_cast<f32x4*>(pg + D + i * 256 + 4 * lane) = b;
+    }
+  }
+}
+
 constexpr int RF_G = 2048;   // fc7 feature size
 constexpr int RF_MAXC = 8;   // per-lane slots for the loc (<= 512) and class (<= 512) segments
 
@@ -190,6 +282,21 @@ extern "C" int gvd_add_layernorm_unbiased(const float* x, const float* y, const 
     return GVD_EINVAL;
   hipLaunchKernelGGL(add_ln_unbiased_kernel<1024>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, gvd_s(stream), x, y,
                      gamma, beta, out, rows, rows_dev, eps);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gvd_add_layernorm_unbiased_bwd_parts(int64_t rows) { return (int)((rows + LNB_ROWS - 1) / LNB_ROWS); }
+
+extern "C" int gvd_add_layernorm_unbiased_bwd(const float* x, const float* y, const float* dout, const float* gamma,
+                                              float* ds, float* partials, int64_t rows, int D, float eps,
+                                              gvd_stream_t stream) {
+  if (!x || !dout || !gamma || !ds || !partials || rows <= 0 || D != 1024) return GVD_EINVAL;
+  if (!gvd_aligned16(x) || (y && !gvd_aligned16(y)) || !gvd_aligned16(dout) || !gvd_aligned16(ds) || !gvd_aligned16(gamma) ||
+      !gvd_aligned16(partials))
+    return GVD_EINVAL;
+  hipLaunchKernelGGL(add_ln_unbiased_bwd_kernel<1024>, dim3((unsigned)((rows + LNB_ROWS - 1) / LNB_ROWS)), dim3(256), 0,
+                     gvd_s(stream), x, y, dout, gamma, ds, partials, rows, eps);
   GVD_CHECK_LAUNCH();
   return 0;
 }

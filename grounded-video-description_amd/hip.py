@@ -89,6 +89,13 @@ _SIG = {
                                c_f32p, C.c_int64, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
     'gvd_add_layernorm_unbiased': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int,
                                              C.c_float, C.c_void_p]),
+    'gvd_add_layernorm_unbiased_bwd_parts': (C.c_int, [C.c_int64]),
+    'gvd_add_layernorm_unbiased_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int,
+                                                 C.c_float, C.c_void_p]),
+    'gvd_enc_softmax_dropout_fwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
+                                              C.c_uint64, C.c_void_p]),
+    'gvd_enc_softmax_dropout_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
+                                              C.c_void_p]),
     'gvd_region_feature_rows': (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_u8p, C.c_int64, C.c_int64,
                                           c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_void_p, C.c_int, C.c_float,
                                           C.c_void_p]),

@@ -597,6 +597,124 @@ def add_layernorm_unbiased(x, y, gamma, beta, eps=1e-6, rows_dev=None):
     return out.view_as(x)
 
 
+class _AddLnFn(torch.autograd.Function):
+    """ResidualBlock + the encoder's LayerNorm (transformer.py:66-88) as ONE row kernel forward and ONE backward (training
+    path; the reference runs ~8 elementwise / reduction passes forward and ~15 backward over [B*R, 1024])."""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma, beta, eps):
+        out = add_layernorm_unbiased(x, y, gamma, beta, eps)
+        ctx.save_for_backward(x, y, gamma)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, gamma = ctx.saved_tensors
+        D = x.shape[-1]
+        x2, y2, d2 = x.reshape(-1, D), y.reshape(-1, D), dout.reshape(-1, D).contiguous()
+        rows = x2.shape[0]
+        ds = torch.empty_like(x2)
+        nparts = lib().gvd_add_layernorm_unbiased_bwd_parts(rows)
+        parts = torch.empty(nparts, 2, D, device=x.device, dtype=torch.float32)
+        check(lib().gvd_add_layernorm_unbiased_bwd(ptr(x2), ptr(y2), ptr(d2), ptr(gamma), ptr(ds), ptr(parts), rows, D,
+                                                   ctx.eps, stream_ptr()), 'gvd_add_layernorm_unbiased_bwd')
+        ps = parts.sum(0)
+        ds = ds.view_as(x)
+        return ds, ds, ps[0], ps[1], None
+
+
+def add_layernorm(x, y, gamma, beta, eps=1e-6):
+    """LayerNorm_unbiased(x + y): differentiable (fused forward + backward row kernels) when grad mode is on."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (x, y, gamma, beta)):
+        return _AddLnFn.apply(x.contiguous(), y.contiguous(), gamma, beta, eps)
+    return add_layernorm_unbiased(x.contiguous(), y.contiguous(), gamma.detach(), beta.detach(), eps)
+
+
+TRAIN_HEAD_PAD = 192      # training attention core: heads zero-padded to a multiple of the GEMM's 32-deep k tile
+
+
+def _bgemm(A, a_off, lda, a_bs, W, w_off, ldw, w_bs, K, Cout, c_off, ldc, c_bs, M, N, batch, a_t=0, w_t=0, what='bgemm'):
+    """One batched launch of the MFMA GEMM on sub-blocks of larger tensors (element offsets into A / W / Cout)."""
+    g = GemmArgs()
+    g.nseg = 1
+    g.seg[0] = GemmSeg(C.c_void_p(A.data_ptr() + 4 * a_off), lda, a_bs, C.c_void_p(W.data_ptr() + 4 * w_off), ldw, w_bs, K)
+    g.C = C.c_void_p(Cout.data_ptr() + 4 * c_off); g.ldc = ldc; g.c_batch_stride = c_bs
+    g.M, g.N, g.batch, g.act = M, N, batch, 0
+    g.a_kstrided, g.w_kstrided = a_t, w_t
+    check(lib().gvd_gemm_nt_f32(C.byref(g), stream_ptr()), 'gvd_gemm_nt_f32(%s)' % what)
+
+
+class _EncAttnCoreFn(torch.autograd.Function):
+    """Self-attention core of one encoder layer on the training path (transformer.py:90-117): per head
+    softmax(Q K^T / sqrt(d)) -> dropout -> @ V, all six products of forward + backward on the pipelined fp32-MFMA GEMM
+    over zero-padded operands, softmax + dropout (and their backward) as one row kernel each (csrc/enc_attn_train.hip).
+
+    qkv: [B, Rp, 3 * nh * HP] (packed q | k | v, heads padded to HP columns, Rp % 32 == 0; the pad rows R..Rp-1 may hold
+    anything finite).  Returns O [B, Rp, nh * HP] (pad rows zero)."""
+
+    @staticmethod
+    def forward(ctx, qkv, R, nh, scale, p_drop, seed):
+        require_cuda_f32(qkv)
+        assert qkv.is_contiguous()
+        B, Rp, W3 = qkv.shape
+        HP = W3 // (3 * nh)
+        assert W3 == 3 * nh * HP and HP % 32 == 0 and Rp % 32 == 0 and R % 4 == 0 and 4 <= R <= Rp
+        dev = qkv.device
+        Y = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
+        ko, vo = nh * HP, 2 * nh * HP
+        for h in range(nh):       # S_h = Q_h K_h^T
+            _bgemm(qkv, h * HP, W3, Rp * W3, qkv, ko + h * HP, W3, Rp * W3, HP, Y, h * Rp * Rp, Rp, nh * Rp * Rp, R, R, B,
+                   what='QK^T')
+        Pd = torch.empty_like(Y) if p_drop > 0 else None
+        check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y), ptr(Pd), B * nh, Rp, R, scale, p_drop, seed, stream_ptr()),
+              'gvd_enc_softmax_dropout_fwd')
+        P = Pd if Pd is not None else Y
+        O = torch.zeros(B, Rp, nh * HP, device=dev, dtype=torch.float32)
+        for h in range(nh):       # O_h = Pd_h V_h   (V consumed in place as a K-strided operand)
+            _bgemm(P, h * Rp * Rp, Rp, nh * Rp * Rp, qkv, vo + h * HP, W3, Rp * W3, Rp, O, h * HP, nh * HP, Rp * nh * HP,
+                   R, HP, B, w_t=1, what='PV')
+        ctx.save_for_backward(qkv, Y, Pd)
+        ctx.cfg = (R, nh, scale, p_drop)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, Y, Pd = ctx.saved_tensors
+        R, nh, scale, p_drop = ctx.cfg
+        B, Rp, W3 = qkv.shape
+        HP = W3 // (3 * nh)
+        dO = dO.contiguous()
+        dev = qkv.device
+        ko, vo = nh * HP, 2 * nh * HP
+        P = Pd if Pd is not None else Y
+        dS = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
+        dqkv = torch.zeros_like(qkv)
+        mb, ms = nh * Rp * Rp, Rp * Rp
+        for h in range(nh):
+            # dPd_h = dO_h V_h^T
+            _bgemm(dO, h * HP, nh * HP, Rp * nh * HP, qkv, vo + h * HP, W3, Rp * W3, HP, dS, h * ms, Rp, mb, R, R, B,
+                   what='dO V^T')
+            # dV_h = Pd_h^T dO_h   (both operands K-strided; pad rows of Pd are zero)
+            _bgemm(P, h * ms, Rp, mb, dO, h * HP, nh * HP, Rp * nh * HP, Rp, dqkv, vo + h * HP, W3, Rp * W3, R, HP, B,
+                   a_t=1, w_t=1, what='P^T dO')
+        check(lib().gvd_enc_softmax_dropout_bwd(ptr(dS), ptr(Pd), ptr(Y), B * nh, Rp, R, scale, p_drop, stream_ptr()),
+              'gvd_enc_softmax_dropout_bwd')
+        for h in range(nh):
+            # dQ_h = dS_h K_h ;  dK_h = dS_h^T Q_h
+            _bgemm(dS, h * ms, Rp, mb, qkv, ko + h * HP, W3, Rp * W3, Rp, dqkv, h * HP, W3, Rp * W3, R, HP, B, w_t=1,
+                   what='dS K')
+            _bgemm(dS, h * ms, Rp, mb, qkv, h * HP, W3, Rp * W3, Rp, dqkv, ko + h * HP, W3, Rp * W3, R, HP, B, a_t=1,
+                   w_t=1, what='dS^T Q')
+        return dqkv, None, None, None, None, None
+
+
+def enc_attn_core(qkv, R, n_heads, scale, p_drop=0.0):
+    """See _EncAttnCoreFn.  The dropout seed is drawn from torch's CPU generator (reproducible under torch.manual_seed)."""
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0
+    return _EncAttnCoreFn.apply(qkv, R, n_heads, scale, float(p_drop), seed)
+
+
 def region_feature_rows(g_pool, loc, sim_logits_t, pnt_mask, ln_eps=1e-5, pad_to=1):
     """[LN(g_pool) | LN(loc) | LN(softmax_classes(masked sim logits))] per proposal (model.py:336-364) in one pass.
     g_pool [B,R,2048], loc [B,R,n_loc], sim_logits_t [B,R,D1] (class-last), pnt_mask u8 [B,R+1].

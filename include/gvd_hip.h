@@ -161,6 +161,23 @@ int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_side* temporal
 int gvd_add_layernorm_unbiased(const float* x, const float* y, const float* gamma, const float* beta, float* out,
                                int64_t rows, const int* rows_dev, int D, float eps, gvd_stream_t stream);
 
+/* Backward of gvd_add_layernorm_unbiased: ds[row,:] = d loss / d (x + y)[row,:] (the gradient of both addends), and
+ * partials [gvd_add_layernorm_unbiased_bwd_parts(rows), 2, D]: per-workgroup sums of dgamma (first D) and dbeta (second D),
+ * to be added over the first axis by the caller (ordered: reproducible).  Statistics are recomputed from x (+ y). */
+int gvd_add_layernorm_unbiased_bwd_parts(int64_t rows);
+int gvd_add_layernorm_unbiased_bwd(const float* x, const float* y, const float* dout, const float* gamma, float* ds,
+                                   float* partials, int64_t rows, int D, float eps, gvd_stream_t stream);
+
+/* Training path of the encoder's self-attention core (transformer.py:90-117) over MATERIALISED, zero-padded score maps
+ * [n_maps, Rp, Rp] (Rp % 32 == 0, Rp <= 2048; rows / columns >= R are padding and are written as 0):
+ *   fwd: S <- softmax(scale * S[:, :R]) in place;  Pd <- S * keep / (1 - p_drop)   (Pd may be NULL iff p_drop == 0;
+ *        keep ~ Bernoulli(1 - p_drop) from Philox4x32-10 keyed by `seed`);
+ *   bwd: dP <- scale * Y * (dY - sum_j dY_j Y_j),  dY = dP * [Pd != 0] / (1 - p_drop)   (in place over dP). */
+int gvd_enc_softmax_dropout_fwd(float* S, float* Pd, int64_t n_maps, int Rp, int R, float scale, float p_drop,
+                                uint64_t seed, gvd_stream_t stream);
+int gvd_enc_softmax_dropout_bwd(float* dP, const float* Pd, const float* Y, int64_t n_maps, int Rp, int R, float scale,
+                                float p_drop, gvd_stream_t stream);
+
 /* Per proposal row (model.py:336-364): p = softmax over the n_cls similarity logits (all -1e8 when the row is
  * masked: row_mask[(row / mask_rows_per_batch) * mask_ld + row % mask_rows_per_batch] != 0), written to sim_out
  * [rows,n_cls] (optional); out[row] = [layer_norm(g_pool row, G=2048) | layer_norm(loc row, n_loc) |

@@ -623,3 +623,151 @@ def test_cls_loss_fused_matches_torch():
     np.testing.assert_allclose(g1.cpu().numpy(), logits.grad.cpu().numpy(), rtol=1e-4, atol=1e-7)
     assert torch.equal(ops.cls_loss(sim.detach(), tgt), ops.cls_loss(sim.detach(), tgt))      # ordered reduction
     assert torch.isnan(ops.cls_loss(sim.detach(), torch.zeros_like(tgt)))                      # empty selection -> NaN
+
+
+@pytest.mark.parametrize('rows', [1000, 130, 7])
+def test_add_layernorm_fused_backward(rows):
+    """Training ResidualBlock LayerNorm (transformer.py:66-88): the fused forward + backward row kernels against autograd
+    through the module's elementwise formulation (fp64 reference for the gradients)."""
+    from gvd_amd.att_model import _EncLayerNorm
+    g = _g(23 + rows)
+    D = 1024
+    ln = _EncLayerNorm(D).cuda()
+    with torch.no_grad():
+        ln.gamma.copy_(torch.randn(D, generator=g) * 0.5 + 1)
+        ln.beta.copy_(torch.randn(D, generator=g) * 0.1)
+    x = torch.randn(rows, D, generator=g).cuda().requires_grad_(True)
+    y = (torch.randn(rows, D, generator=g) * 0.3).cuda().requires_grad_(True)
+    dout = torch.randn(rows, D, generator=g).cuda()
+    out = ops.add_layernorm(x, y, ln.gamma, ln.beta, ln.eps)
+    out.backward(dout)
+    got = [t.grad.clone() for t in (x, y, ln.gamma, ln.beta)]
+    for t in (x, y, ln.gamma, ln.beta):
+        t.grad = None
+    ln64 = _EncLayerNorm(D).cuda().double()
+    with torch.no_grad():
+        ln64.gamma.copy_(ln.gamma.double()); ln64.beta.copy_(ln.beta.double())
+    x64, y64 = x.detach().double().requires_grad_(True), y.detach().double().requires_grad_(True)
+    ref = ln64(x64 + y64)
+    ref.backward(dout.double())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    want = [x64.grad, y64.grad, ln64.gamma.grad, ln64.beta.grad]
+    for a, b, name in zip(got, want, ('dx', 'dy', 'dgamma', 'dbeta')):
+        scale = float(b.abs().max())
+        err = float((a.double() - b).abs().max())
+        assert err <= 2e-5 * max(scale, 1.0), (name, err, scale)
+    assert torch.equal(got[0], got[1])
+
+
+@pytest.mark.parametrize('n_maps,R,Rp,p', [(5, 1000, 1024, 0.2), (3, 40, 64, 0.2), (2, 300, 320, 0.0)])
+def test_enc_softmax_dropout_row_kernels(n_maps, R, Rp, p):
+    """Training softmax + dropout over zero-padded score maps (transformer.py:100-108) and its backward."""
+    from gvd_amd.hip import check, lib, ptr, stream_ptr
+    g = _g(R + Rp)
+    scale = 1.0 / 32
+    S0 = (torch.randn(n_maps, Rp, Rp, generator=g) * 40).cuda()
+    Y = S0.clone()
+    Pd = torch.full_like(Y, float('nan')) if p > 0 else None
+    check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y), ptr(Pd), n_maps, Rp, R, scale, p, 1234567, stream_ptr()), 'fwd')
+    want = torch.softmax(S0[:, :R, :R].double() * scale, -1)
+    assert float((Y[:, :R, :R].double() - want).abs().max()) < 2e-7
+    assert not Y[:, R:].any() and not Y[:, :, R:].any()
+    if p > 0:
+        assert not Pd[:, R:].any() and not Pd[:, :, R:].any()
+        keep = Pd[:, :R, :R] != 0
+        frac = float(keep.float().mean())
+        assert abs(frac - (1 - p)) < 4 * (p * (1 - p) / keep.numel()) ** 0.5 + 1e-4, frac
+        assert torch.equal(Pd[:, :R, :R][keep], (Y[:, :R, :R] * (1.0 / (1.0 - p)))[keep])
+        # another seed: another mask; same seed: same mask
+        Y2, Pd2 = S0.clone(), torch.empty_like(S0)
+        check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y2), ptr(Pd2), n_maps, Rp, R, scale, p, 1234567, stream_ptr()), 'fwd')
+        assert torch.equal(Pd2, Pd)
+        check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y2.copy_(S0)), ptr(Pd2), n_maps, Rp, R, scale, p, 7654321, stream_ptr()), 'fwd')
+        assert not torch.equal(Pd2, Pd)
+        # rows are decorrelated (no repeated pattern across rows / maps)
+        k0 = keep.reshape(-1, R).float()
+        assert float((k0[0] == k0[1]).float().mean()) < 0.8
+    dP0 = torch.randn(n_maps, Rp, Rp, generator=g).cuda()
+    dS = dP0.clone()
+    dS[:, R:] = float('nan'); dS[:, :, R:] = float('nan')        # the GEMM leaves the pad region unwritten
+    check(lib().gvd_enc_softmax_dropout_bwd(ptr(dS), ptr(Pd), ptr(Y), n_maps, Rp, R, scale, p, stream_ptr()), 'bwd')
+    y = Y[:, :R, :R].double()
+    dY = dP0[:, :R, :R].double()
+    if p > 0:
+        dY = dY * (Pd[:, :R, :R] != 0) / (1 - p)
+    ref = scale * y * (dY - (dY * y).sum(-1, keepdim=True))
+    assert float((dS[:, :R, :R].double() - ref).abs().max()) < 1e-6
+    assert not dS[:, R:].any() and not dS[:, :, R:].any()
+
+
+@pytest.mark.parametrize('B,R', [(2, 1000), (3, 40)])
+def test_enc_attn_core_training_matches_autograd(B, R):
+    """ops.enc_attn_core (six MFMA products + the two row kernels) against the per-head torch formulation of
+    transformer.py:90-117 with dropout off: output and the gradient w.r.t. the packed q | k | v."""
+    g = _g(B * R)
+    nh, HP, d = 6, ops.TRAIN_HEAD_PAD, 1024
+    Rp = -(-R // 32) * 32
+    sizes = [t.shape[-1] for t in torch.zeros(1, d).chunk(nh, -1)]
+    qkv = torch.zeros(B, Rp, 3, nh, HP)
+    for h in range(nh):
+        qkv[:, :, :, h, :sizes[h]] = torch.randn(B, Rp, 3, sizes[h], generator=g)
+    qkv = qkv.reshape(B, Rp, 3 * nh * HP).cuda().requires_grad_(True)
+    dO = torch.randn(B, Rp, nh * HP, generator=g).cuda()
+    dO[:, R:] = 0                                        # pad rows never receive gradient
+    O = ops.enc_attn_core(qkv, R, nh, 1.0 / 32, 0.0)
+    O.backward(dO)
+    got = qkv.grad.clone()
+    q64 = qkv.detach().double().view(B, Rp, 3, nh, HP).requires_grad_(True)
+    outs = []
+    for h in range(nh):
+        qh, kh, vh = (q64[:, :R, j, h] for j in range(3))
+        w = torch.softmax(torch.matmul(qh, kh.transpose(1, 2)) / 32, -1)
+        outs.append(torch.matmul(w, vh))
+    ref = torch.stack(outs, 2).reshape(B, R, nh * HP)
+    ref.backward(dO[:, :R].double())
+    assert float((O[:, :R].double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    assert not O[:, R:].any()
+    want = q64.grad.reshape(B, Rp, 3 * nh * HP)
+    err = float((got.double() - want).abs().max())
+    assert err < 3e-5 * float(want.abs().max()), err
+    assert not got[:, R:].any()
+    # dropout on: runs, reproducible under the torch seed, and differs from the p = 0 output
+    torch.manual_seed(5)
+    o1 = ops.enc_attn_core(qkv.detach(), R, nh, 1.0 / 32, 0.2)
+    torch.manual_seed(5)
+    o2 = ops.enc_attn_core(qkv.detach(), R, nh, 1.0 / 32, 0.2)
+    assert torch.equal(o1, o2) and not torch.equal(o1, O.detach())
+
+
+def test_encoder_training_paths_agree(monkeypatch):
+    """The all-MFMA training encoder (padded region axis, packed projection, fused LayerNorm backward) against the
+    per-head library formulation in eval mode with gradients on: output and parameter gradients."""
+    from gvd_amd import att_model
+    opt = gvd_amd.opts.default_opt(vocab_size=60)
+    torch.manual_seed(3)
+    model = att_model.TopDownModel(opt).cuda().eval()
+    with torch.no_grad():                                  # LayerNorm parameters off their 1 / 0 initial values
+        for lay in model.obj_interact.encoder.layers:
+            for ln in (lay.selfattn.layernorm, lay.feedforward.layernorm):
+                ln.gamma.add_(torch.randn(1024, device='cuda') * 0.1)
+                ln.beta.add_(torch.randn(1024, device='cuda') * 0.1)
+    g = _g(9)
+    x = torch.randn(3, 40, 1024, generator=g).cuda()
+    dout = torch.randn(3, 40, 1024, generator=g).cuda()
+    params = [p for p in model.obj_interact.encoder.layers.parameters()]
+    res = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('GVD_ENC_TRAIN_MFMA', flag)
+        monkeypatch.setenv('GVD_LN_FUSED_BWD', flag)
+        for p in params:
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        with torch.enable_grad():
+            out = model._obj_interact(xi)
+            out.backward(dout)
+        res[flag] = (out.detach(), xi.grad.clone(), [p.grad.clone() for p in params])
+    a, b = res['1'], res['0']
+    assert float((a[0] - b[0]).abs().max()) < 2e-4
+    assert float((a[1] - b[1]).abs().max()) < 2e-4 * max(1.0, float(b[1].abs().max()))
+    for ga, gb in zip(a[2], b[2]):
+        assert float((ga - gb).abs().max()) < 3e-4 * max(1.0, float(gb.abs().max()))

@@ -369,7 +369,8 @@ class TopDownModel(nn.Module):
         """The region half of the inference preamble (model.py:311-391) on the COMPACTED row set: masked proposals are
         zero rows by the loader contract (dataloader_anet.py:343-344), so per segment only its valid rows plus ONE
         representative masked row are computed (csrc/compact.hip); the dense [B,R,.] tensors the token loop streams
-        are restored by a row gather at the end.  -> pool [B,R,H], p_pool [B,R,A], sim_mat [B,D1,R]."""
+        are restored by a row gather only for the consumers that need them (`_dense_regions`): the greedy token loop reads
+        the compacted rows in place through the row map.  -> ci, pool [cap,H], p_pool [cap,A], sim_mat [B,D1,R]."""
         ci = ops.CompactIndex(pm)
         flag = torch.zeros(1, dtype=torch.int32, device=pm.device)
         ops.check_masked_rows_zero(ppls_feat.contiguous(), pm, flag)
@@ -377,7 +378,12 @@ class TopDownModel(nn.Module):
         self.__dict__.setdefault('_contract_flags', []).append(flag)
         m = ci.m_dev
         fc7 = self.ctx2pool_grd[0]
-        g_pool = ops.gemm_nt(ci.gather(ppls_feat), fc7.weight.detach(), fc7.bias.detach(), 1, m_dev=m)   # [cap,2048]
+        if os.environ.get('GVD_FC7_ROWMAP', '1') == '1' and ppls_feat.numel() * 4 < (1 << 32):
+            # fc7 reads its rows of the dense fc6 tensor through the compaction map (row gather fused into the GEMM)
+            g_pool = ops.gemm_nt(ppls_feat.contiguous(), fc7.weight.detach(), fc7.bias.detach(), 1, m_dev=m,
+                                 a_row_map=ci.src_row)                                                      # [cap,2048]
+        else:
+            g_pool = ops.gemm_nt(ci.gather(ppls_feat), fc7.weight.detach(), fc7.bias.detach(), 1, m_dev=m)
         pc = ci.gather(ppls)
         loc_in = torch.cat([pc[:, :4] / 720., (pc[:, 4] * 1. / self.num_sampled_frm).unsqueeze(-1)], dim=1)
         loc = F.relu(self.loc_fc[0](loc_in)).contiguous()
@@ -388,7 +394,7 @@ class TopDownModel(nn.Module):
                            m_dev=m)
         pool = self._obj_interact_fused(pool, ci=ci)
         p_pool = ops.gemm_nt(pool, self.ctx2pool.weight.detach(), self.ctx2pool.bias.detach(), m_dev=m)
-        return ci.expand(pool), ci.expand(p_pool), ci.expand(sim_c).transpose(1, 2)
+        return ci, pool, p_pool, ci.expand(sim_c).transpose(1, 2)
 
     def _obj_interact(self, x):
         """transformer.py:135-190,244-254 as built at model.py:126-135 (6 uneven heads, scale sqrt(d_model),
@@ -454,7 +460,10 @@ class TopDownModel(nn.Module):
                    and self._fused_encoder_ok(self.rnn_size) and B * (R + 1) < (1 << 24)
                    and os.environ.get('GVD_POOL_EMBED_OWN', '1') == '1')
         if compact:
-            return self._preamble_finish(segs_feat, sample_idx, fc, pm, *self._regions_compact(ppls, ppls_feat, pm), None)
+            ci, pool_c, p_pool_c, sim_mat = self._regions_compact(ppls, ppls_feat, pm)
+            pre = self._preamble_finish(segs_feat, sample_idx, fc, pm, None, None, sim_mat, None)
+            pre.update(ci=ci, pool_c=pool_c, p_pool_c=p_pool_c)
+            return pre
         # fc7 over the raw fc6 region features: MFMA GEMM + fused bias/ReLU (model.py:311-313)
         g_pool = self._drop(self._lin(ppls_feat, self.ctx2pool_grd[0], act=1))
         vis_word = self._drop(F.relu(self.vis_embed[0].weight))
@@ -520,6 +529,14 @@ class TopDownModel(nn.Module):
         return dict(fc=fc, pool=pool, p_pool=p_pool, conv=conv, p_conv=p_conv, g_pool=g_pool,
                     sim_mat_static=sim_mat, pnt_mask=pm)
 
+    @staticmethod
+    def _dense_regions(pre):
+        """Dense [B,R,.] region features for the consumers that index them directly (beam search, multinomial sampling):
+        the compacted preamble keeps them compacted until someone asks."""
+        if pre.get('pool') is None:
+            pre['pool'], pre['p_pool'] = pre['ci'].expand(pre['pool_c']), pre['ci'].expand(pre['p_pool_c'])
+        return pre
+
     def _decode_params(self):
         c = self.core
         return dict(
@@ -543,10 +560,10 @@ class TopDownModel(nn.Module):
             P = {k: v.detach() for k, v in self._decode_params().items()}
             if not sample_max:
                 from . import sampling
-                seq, lps, att2 = sampling.multinomial_decode(self, pre, P, opt.get('temperature', 1.0))
+                seq, lps, att2 = sampling.multinomial_decode(self, self._dense_regions(pre), P, opt.get('temperature', 1.0))
             elif beam_size > 1:
                 from . import beam
-                seq, lps, att2 = beam.beam_decode(self, pre, P, beam_size)
+                seq, lps, att2 = beam.beam_decode(self, self._dense_regions(pre), P, beam_size)
             else:
                 seq, lps, att2 = ops.greedy_decode(pre, P, pre['pnt_mask'], self.seq_length, self.unk_idx,
                                                     prof=getattr(self, 'kernel_timer', None), flags=self._flags())

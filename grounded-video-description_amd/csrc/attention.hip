@@ -36,6 +36,7 @@ struct SideDev {
   const uint8_t* pnt_mask; int64_t ld_pnt_mask;
   float* logits_out; int64_t ld_logits;
   float* scores_out; int64_t ld_scores;
+  const int* row_map;    // optional [B,N]: row n of sample b lives at row row_map[b*N+n] of the FLAT feats / p_feats
   int N, chunk, nchunks, group;
 };
 
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   __shared__ float s_score[MAX_CHUNK];
   __shared__ float s_red[8];
   __shared__ int s_live[MAX_CHUNK];
+  __shared__ int s_src[MAX_CHUNK];    // row-in-chunk -> row offset from pf / fb (identity unless the side has a row map)
   __shared__ int s_n[2];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int b = blockIdx.y;
@@ -80,7 +82,10 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   const f32x4 w1 = *reinterpret_cast<const f32x4*>(S.w + 256 + 4 * lane);
   const float ab = *S.alpha_bias;
   const int fbi = S.group > 1 ? b / S.group : b;   // beams of one sample share its features
-  const float* pf = S.p_feats + ((int64_t)fbi * S.N + n0) * ATT_A;
+  // compacted features (masked-proposal compaction, csrc/compact.hip): the side's rows are looked up through row_map in
+  // the flat [rows, .] arrays - the dense [B,N,.] copies are never materialised
+  const int* rmap = S.row_map ? S.row_map + (int64_t)fbi * S.N + n0 : nullptr;
+  const float* pf = rmap ? S.p_feats : S.p_feats + ((int64_t)fbi * S.N + n0) * ATT_A;
   const uint8_t* am = S.att_mask ? S.att_mask + (int64_t)b * S.ld_att_mask + n0 : nullptr;
   const uint8_t* pm = S.pnt_mask ? S.pnt_mask + (int64_t)b * S.ld_pnt_mask + n0 : nullptr;
   float* lo = S.logits_out ? S.logits_out + (int64_t)b * S.ld_logits + n0 : nullptr;
@@ -97,6 +102,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
     const unsigned long long bal = __ballot(live);
     const int nl = __popcll(bal);
     if (live) s_live[__popcll(bal & ((1ull << lane) - 1ull))] = lane;
+    if (in) s_src[lane] = rmap ? rmap[lane] : lane;
     if (in && !live) {
       s_score[lane] = GVD_MIN_VALUE;
       if (so) so[lane] = GVD_MIN_VALUE;
@@ -110,8 +116,8 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   for (int i = wave * 2; i < nlive; i += 8) {
     const bool two = (i + 1) < nlive;
     const int r = s_live[i], r2 = two ? s_live[i + 1] : r;
-    const float* p0 = pf + (int64_t)r * ATT_A;
-    const float* p1 = pf + (int64_t)r2 * ATT_A;
+    const float* p0 = pf + (int64_t)s_src[r] * ATT_A;
+    const float* p1 = pf + (int64_t)s_src[r2] * ATT_A;
     f32x4 x00 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 4 * lane));
     f32x4 x01 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane));
     f32x4 x10 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 4 * lane));
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   __syncthreads();
 
   // ---- phase 2: partial context.  thread owns columns [4*tid, 4*tid+4) of H = 1024
-  const float* fb = S.feats + ((int64_t)fbi * S.N + n0) * ATT_H + 4 * tid;
+  const float* fb = (rmap ? S.feats : S.feats + ((int64_t)fbi * S.N + n0) * ATT_H) + 4 * tid;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int nctx = s_n[1];                 // live rows (their order is the row order: same sums as over all rows)
   int i = 0;
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) rr[u] = s_live[i + u];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)rr[u] * ATT_H));
+    for (int u = 0; u < 8; ++u) v[u] = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)s_src[rr[u]] * ATT_H));
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float pw = s_score[rr[u]];
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
   }
   for (; i < nctx; ++i) {
     const int rr = s_live[i];
-    const f32x4 v = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)rr * ATT_H));
+    const f32x4 v = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)s_src[rr] * ATT_H));
     const float pw = s_score[rr];
     acc[0] = fmaf(pw, v[0], acc[0]); acc[1] = fmaf(pw, v[1], acc[1]);
     acc[2] = fmaf(pw, v[2], acc[2]); acc[3] = fmaf(pw, v[3], acc[3]);
@@ -450,6 +456,7 @@ void fill_side(SideDev& d, const gvd_attn_side* s, int B) {
   d.alpha_bias = s->alpha_bias; d.att_mask = s->att_mask; d.ld_att_mask = s->ld_att_mask;
   d.pnt_mask = s->pnt_mask; d.ld_pnt_mask = s->ld_pnt_mask; d.logits_out = s->logits_out;
   d.ld_logits = s->ld_logits; d.scores_out = s->scores_out; d.ld_scores = s->ld_scores;
+  d.row_map = s->row_map;
   d.N = s->N; d.group = s->group; d.chunk = pick_chunk(s->N, B);
   d.nchunks = (s->N + d.chunk - 1) / d.chunk;
 }
@@ -489,6 +496,7 @@ extern "C" int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_sid
   const int G = region->group;
   const bool grouped = G >= 2 && G <= 5 && B % G == 0 && (!temporal || temporal->group == G) &&
                        tune_int("GVD_ATTN_GROUPED", 1);
+  if (grouped && (region->row_map || (temporal && temporal->row_map))) return GVD_EINVAL;   // (row kernel only)
   if (grouped) {
     const dim3 grid((unsigned)p.nctot, (unsigned)(B / G));
 #define GVD_LAUNCH_GROUP(GG)                                                                                   \

@@ -85,6 +85,7 @@ extern "C" int gvd_greedy_decode(const gvd_greedy_args* a, gvd_stream_t stream) 
     g.C = w.fc_gates; g.ldc = 4 * H; g.M = B; g.N = 4 * H; g.batch = 1;
     GVD_TRY(gvd_gemm_nt_f32(&g, stream));
   }
+  if (a->pool_row_map && gvd_pd_eligible(B, H, A, E, V, R, Ft)) return GVD_EINVAL;   // persistent kernel: dense layout
   if (gvd_pd_eligible(B, H, A, E, V, R, Ft)) {
     // decode batch: the whole token loop as ONE persistent cooperative launch (decode_persistent.hip).  The event
     // timer `prof` has no per-step attention kernel to bracket on this path and records nothing.
@@ -134,7 +135,7 @@ extern "C" int gvd_greedy_decode(const gvd_greedy_args* a, gvd_stream_t stream) 
       reg.att_mask = a->pnt_mask + 1; reg.ld_att_mask = R + 1;
       reg.pnt_mask = a->pnt_mask + 1; reg.ld_pnt_mask = R + 1;
       reg.logits_out = a->att2_weights + (int64_t)t * R; reg.ld_logits = (int64_t)L * R;
-      reg.N = R;
+      reg.N = R; reg.row_map = a->pool_row_map;
       gvd_attn_side tmp = {};
       tmp.feats = a->conv; tmp.p_feats = a->p_conv; tmp.q = w.q12; tmp.ldq = 2 * A;
       tmp.w = a->att1_alpha_w; tmp.alpha_bias = a->att1_alpha_b; tmp.N = Ft;

@@ -116,6 +116,22 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
   stage(0);
   __syncthreads();
   int buf = 0;
+  // A wave whose 16 queries all lie past the sample's last row (the tail of the last query tile; ragged batches: on
+  // average half of that tile) only helps staging the K / V tiles and keeps the barrier count: it issues no MFMA, so its
+  // SIMD's matrix pipe goes to the other resident waves.
+  if (qt * (16 * NW) + wave * 16 >= R) {
+#pragma unroll 1
+    for (int jt = 0; jt < ntiles; ++jt) {
+      const int nxt = buf == 2 ? 0 : buf + 1;
+      if (jt + 1 < ntiles) {
+        fetch((jt + 1) * TK);
+        stage(nxt);                      // (tile jt-2's buffer: every wave left it before the previous barrier)
+      }
+      __syncthreads();
+      buf = nxt;
+    }
+    return;
+  }
   // first K fragments of the next tile, read right after the barrier that publishes it (under the last 44 MFMAs)
   f32x4 kpre[2];
   kpre[0] = *reinterpret_cast<const f32x4*>(smem + c16 * LD + 4 * g);

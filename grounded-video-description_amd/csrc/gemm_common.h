@@ -19,6 +19,7 @@ struct KParams {
   float* C; int64_t ldc; int64_t cbs;
   int M, N, act;
   const int* m_dev;      // when set: the row count is read on the device (<= M; tiles past it exit)
+  const int* a_rmap;     // when set (pipelined kernel, one segment): output row m reads row a_rmap[m] of A
   int a_t, w_t;          // operand is K-strided: A given as [K, M] (lda >= M), W as [K, N] (ldw >= N)
   // LSTM epilogue
   const float* c_prev; int64_t ldcp;

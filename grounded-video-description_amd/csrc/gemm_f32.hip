@@ -238,6 +238,14 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
   p.M = a->M; p.N = a->N; p.act = a->act; p.m_dev = a->m_dev;
   p.a_t = a->a_kstrided; p.w_t = a->w_kstrided;
   hipStream_t st = gvd_s(stream);
+  if (a->a_row_map) {
+    // fused row gather: pipelined kernel only, one plain segment, row offsets within the 32-bit buffer offset
+    if (a->nseg != 1 || a->batch != 1 || p.a_t || p.w_t || a->a_src_rows <= 0 ||
+        (double)a->a_src_rows * (double)a->seg[0].lda * 4.0 >= 4294967296.0)
+      return GVD_EINVAL;
+    p.a_rmap = a->a_row_map;
+    return gvd_gemm_pipe_launch(p, a->batch, st);
+  }
   if (p.a_t || p.w_t) return gvd_gemm_pipe_launch(p, a->batch, st);      // backward products: pipelined kernel only
   if (a->M <= 16 && a->batch == 1 && !a->mbias && !a->mask && !a->m_dev) {   // decode batch: weight-streaming skinny kernel
     GemvParams v = {};

@@ -67,6 +67,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
     arow[i] = min(m0 + srow + 32 * i, M - 1) - m0;       // clamp: rows past the edge re-read the last valid row
     wrow[i] = min(n0 + srow + 32 * i, p.N - 1) - n0;
   }
+  // fused row gather (fc7 over the compacted proposal set): row m of the product reads row a_rmap[m] of A; the operand
+  // descriptor then starts at A itself (the host checked that every row offset fits the 32-bit buffer offset)
+  const bool gathered = !AT && p.a_rmap != nullptr;
+  if (gathered) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) arow[i] = p.a_rmap[m0 + arow[i]];
+  }
   // K-strided operands: thread covers memory rows (k) tk + 8 i, 16-byte column chunk tc (columns = output rows / cols;
   // chunks past the edge are clamped to the last whole chunk - M, N are multiples of 4 there)
   const int tk = tid >> 5, tc = tid & 31;
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) sg.voa[i] = (unsigned)(tk + 8 * i) * lda4 + 4u * (unsigned)acol;
     } else {
-      sg.ra = gvd_rsrc(p.A[s] + (int64_t)bz * p.abs_[s] + (int64_t)m0 * p.lda[s]);
+      sg.ra = gvd_rsrc(p.A[s] + (int64_t)bz * p.abs_[s] + (gathered ? 0 : (int64_t)m0 * p.lda[s]));
 #pragma unroll
       for (int i = 0; i < NLD; ++i) sg.voa[i] = (unsigned)arow[i] * lda4 + 16u * kq;
     }

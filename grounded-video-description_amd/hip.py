@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
                 ('mask', c_u8p), ('mask_ldm', C.c_int64), ('mask_batch_stride', C.c_int64),
                 ('C', c_f32p), ('ldc', C.c_int64), ('c_batch_stride', C.c_int64),
                 ('M', C.c_int), ('N', C.c_int), ('batch', C.c_int), ('act', C.c_int), ('m_dev', C.c_void_p),
+                ('a_row_map', C.c_void_p), ('a_src_rows', C.c_int64),
                 ('a_kstrided', C.c_int), ('w_kstrided', C.c_int)]
 
 
@@ -55,12 +56,13 @@ class AttnSide(C.Structure):
                 ('pnt_mask', c_u8p), ('ld_pnt_mask', C.c_int64),
                 ('logits_out', c_f32p), ('ld_logits', C.c_int64),
                 ('scores_out', c_f32p), ('ld_scores', C.c_int64),
+                ('row_map', C.c_void_p),
                 ('N', C.c_int), ('group', C.c_int)]
 
 
 class GreedyArgs(C.Structure):
     _fields_ = [('fc', c_f32p), ('conv', c_f32p), ('p_conv', c_f32p), ('pool', c_f32p), ('p_pool', c_f32p),
-                ('pnt_mask', c_u8p), ('embed', c_f32p),
+                ('pnt_mask', c_u8p), ('pool_row_map', C.c_void_p), ('embed', c_f32p),
                 ('att_w_ih', c_f32p), ('att_w_hh', c_f32p), ('att_b_ih', c_f32p), ('att_b_hh', c_f32p),
                 ('lang_w_ih', c_f32p), ('lang_w_hh', c_f32p), ('lang_b_ih', c_f32p), ('lang_b_hh', c_f32p),
                 ('att1_h2att_w', c_f32p), ('att1_h2att_b', c_f32p), ('att1_alpha_w', c_f32p), ('att1_alpha_b', c_f32p),
@@ -139,7 +141,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 4        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 5        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

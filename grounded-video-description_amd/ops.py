@@ -18,15 +18,20 @@ def _seg(A, W, K=None, a_bs=0, w_bs=0):
     return GemmSeg(ptr(A), A.stride(-2), a_bs, ptr(W), W.stride(-2), w_bs, K)
 
 
-def gemm_nt(A, W, bias=None, act=0, out=None, m_dev=None):
+def gemm_nt(A, W, bias=None, act=0, out=None, m_dev=None, a_row_map=None):
     """out[M,N] = act(A[M,K] @ W[N,K]^T + bias).  nn.Linear forward on the fp32 matrix cores.
-    m_dev: optional device int32 tensor (1 element) with the live row count (<= M): rows past it are not computed."""
+    m_dev: optional device int32 tensor (1 element) with the live row count (<= M): rows past it are not computed.
+    a_row_map: optional device int32 [M]: output row m reads row a_row_map[m] of A (row gather fused into the operand
+    loads); the result then has a_row_map.numel() rows."""
     require_cuda_f32(A, W, bias)
     lead = A.shape[:-1]
     A2 = A.reshape(-1, A.shape[-1])
     if A2.stride(-1) != 1:
         A2 = A2.contiguous()
     M, N = A2.shape[0], W.shape[0]
+    if a_row_map is not None:
+        assert a_row_map.dtype == torch.int32 and a_row_map.is_contiguous()
+        M, lead = a_row_map.numel(), (a_row_map.numel(),)
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
     g = GemmArgs()
@@ -36,6 +41,8 @@ def gemm_nt(A, W, bias=None, act=0, out=None, m_dev=None):
     g.C = ptr(out); g.ldc = out.stride(0)
     g.M, g.N, g.batch, g.act = M, N, 1, act
     g.m_dev = ptr(m_dev)
+    if a_row_map is not None:
+        g.a_row_map, g.a_src_rows = ptr(a_row_map), A2.shape[0]
     check(lib().gvd_gemm_nt_f32(C.byref(g), stream_ptr()), 'gvd_gemm_nt_f32')
     return out.view(*lead, N)
 
@@ -144,7 +151,7 @@ def lstm_cell(xs, ws, h_prev, w_hh, b_ih, b_hh, c_prev, rowbias=None, gates_out=
 
 
 def _side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, logits_out=None, scores_out=None,
-          group=0):
+          group=0, row_map=None):
     s = AttnSide()
     assert feats.is_contiguous() and p_feats.is_contiguous() and q.stride(-1) == 1
     s.feats, s.p_feats = ptr(feats), ptr(p_feats)
@@ -163,6 +170,10 @@ def _side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, logits
         assert scores_out.stride(-1) == 1
         s.scores_out = ptr(scores_out); s.ld_scores = scores_out.stride(0)
     s.N = feats.shape[1]
+    if row_map is not None:        # feats / p_feats are flat [rows, .] arrays indexed through row_map [B, N]
+        assert row_map.dtype == torch.int32 and row_map.is_contiguous() and feats.dim() == 2
+        s.row_map = ptr(row_map)
+        s.N = row_map.numel() // q.shape[0]
     s.group = group
     return s
 
@@ -196,9 +207,12 @@ def attention_step(region, temporal, want_separate=False):
     region / temporal: dicts(feats, p_feats, q, w, alpha_bias[, att_mask, pnt_mask, logits_out]).
     Returns att+att2 [B,H] (and the two contexts when want_separate)."""
     f = region['feats']
-    Nr, H = f.shape[1], f.shape[2]
     B = region['q'].shape[0]                      # rows (= feats.shape[0] * group)
-    assert B == f.shape[0] * max(region.get('group', 0), 1)
+    if region.get('row_map') is not None:
+        Nr, H = region['row_map'].numel() // B, f.shape[-1]
+    else:
+        Nr, H = f.shape[1], f.shape[2]
+        assert B == f.shape[0] * max(region.get('group', 0), 1)
     A = region['p_feats'].shape[-1]
     require_cuda_f32(f, region['p_feats'], region['q'])
     sr = _side(**region)
@@ -242,10 +256,20 @@ def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None, flags=None):
     `flags`: list that receives the launch's device status word (non-zero after a sync = the persistent kernel's grid
     barrier timed out and the ids are poisoned); the caller must check it before trusting the result
     (TopDownModel.check_kernel_status)."""
-    fc, conv, p_conv, pool, p_pool = (pre[k].contiguous() for k in ('fc', 'conv', 'p_conv', 'pool', 'p_pool'))
-    require_cuda_f32(fc, conv, p_conv, pool, p_pool)
+    fc, conv, p_conv = (pre[k].contiguous() for k in ('fc', 'conv', 'p_conv'))
     B, H = fc.shape
-    Ft, R, A = conv.shape[1], pool.shape[1], p_pool.shape[2]
+    row_map = None
+    if pre.get('pool') is None:
+        # compacted preamble (masked-proposal compaction): the region features are consumed in place through the row map;
+        # the decode-batch persistent kernel (B <= 4) reads the dense layout
+        if B > 4:
+            pool, p_pool, row_map = pre['pool_c'].contiguous(), pre['p_pool_c'].contiguous(), pre['ci'].cidx
+        else:
+            pool, p_pool = pre['ci'].expand(pre['pool_c']), pre['ci'].expand(pre['p_pool_c'])
+    else:
+        pool, p_pool = pre['pool'].contiguous(), pre['p_pool'].contiguous()
+    require_cuda_f32(fc, conv, p_conv, pool, p_pool)
+    Ft, R, A = conv.shape[1], pnt_mask.shape[1] - 1, p_pool.shape[-1]
     V, E = P['embed'].shape
     dev = fc.device
     seq = torch.empty(B, L, dtype=torch.int64, device=dev)
@@ -257,6 +281,7 @@ def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None, flags=None):
     a = GreedyArgs()
     a.fc, a.conv, a.p_conv, a.pool, a.p_pool = ptr(fc), ptr(conv), ptr(p_conv), ptr(pool), ptr(p_pool)
     a.pnt_mask = ptr(pm)
+    a.pool_row_map = ptr(row_map)
     for k in ('embed', 'att_w_ih', 'att_w_hh', 'att_b_ih', 'att_b_hh', 'lang_w_ih', 'lang_w_hh', 'lang_b_ih',
               'lang_b_hh', 'att1_h2att_w', 'att1_h2att_b', 'att1_alpha_w', 'att1_alpha_b', 'att2_h2att_w',
               'att2_h2att_b', 'att2_alpha_w', 'att2_alpha_b', 'logit_w', 'logit_b'):

@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 4
+#define GVD_ABI_VERSION 5
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -84,6 +84,10 @@ typedef struct {
   int M, N, batch;
   int act;                       /* 0 = identity, 1 = ReLU */
   const int* m_dev;              /* optional: device int holding the live row count (<= M); rows / tiles past it are skipped */
+  const int* a_row_map;          /* optional [M] (single segment, plain operands, >= 256-tile products): output row m reads
+                                    row a_row_map[m] of A (a_src_rows rows, a_src_rows * lda * 4 < 2^32) - a row gather
+                                    fused into the operand loads (fc7 over the compacted proposal set) */
+  int64_t a_src_rows;
   /* K-strided operands (the backward products of nn.Linear; single segment, large shapes only):
    *   w_kstrided: W is given as [K, N] (ldw >= N, N % 4 == 0)            dX[M,K'] = dY[M,N'] W[N',K']
    *   a_kstrided (with w_kstrided): A is given as [K, M] (lda >= M)       dW[N',K'] = dY[M',N']^T X[M',K']
@@ -133,6 +137,9 @@ typedef struct {
   const uint8_t* pnt_mask; int64_t ld_pnt_mask;   /* [B,N] or NULL */
   float* logits_out; int64_t ld_logits;           /* [B,N] or NULL */
   float* scores_out; int64_t ld_scores;           /* [B,N] or NULL: e[n] before the pnt_mask fill (kept for backward) */
+  const int* row_map;    /* optional [B,N] (the per-row attention kernel only): row n of sample b is row row_map[b*N+n] of
+                            the FLAT arrays feats [rows,H] / p_feats [rows,A] - the compacted preamble's features are
+                            consumed in place, no dense [B,N,.] copy (csrc/compact.hip); NULL = dense layout */
   int N;
   int group;   /* 0/1: feats/p_feats have one entry per row b.  K>1: rows b share entry b/K (the K beams of a
                   sample attend over ONE copy of its features: feats/p_feats are [B/K,N,*]) */
@@ -308,6 +315,9 @@ typedef struct {
   const float* pool;    /* [B,R,H] */
   const float* p_pool;  /* [B,R,A] */
   const uint8_t* pnt_mask; /* [B,R+1] (column 0 is the legacy pad, main.py:227) */
+  const int* pool_row_map; /* optional [B,R]: pool / p_pool are the COMPACTED flat arrays [rows,H] / [rows,A] and this maps
+                              (b, r) to their row (gvd_attn_side.row_map); B > 4 only (the persistent decode-batch kernel
+                              reads the dense layout); NULL = dense */
   /* parameters (state_dict tensors) */
   const float* embed;                                  /* embed.0.weight [V,E] */
   const float *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh;    /* core.att_lstm.*  [4H,E+H],[4H,H] */

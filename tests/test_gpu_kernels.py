@@ -524,7 +524,7 @@ def test_compact_preamble_equals_dense_preamble():
             os.environ['GVD_COMPACT'] = '0'
             ref = m._preamble(*a, allow_compact=True)
             os.environ['GVD_COMPACT'] = '1'
-            got = m._preamble(*a, allow_compact=True)
+            got = m._dense_regions(m._preamble(*a, allow_compact=True))
             m.check_kernel_status()
             # violated loader contract (a masked proposal with non-zero features) fails loudly
             bad = [t.clone() for t in a]
@@ -771,3 +771,55 @@ def test_encoder_training_paths_agree(monkeypatch):
     assert float((a[1] - b[1]).abs().max()) < 2e-4 * max(1.0, float(b[1].abs().max()))
     for ga, gb in zip(a[2], b[2]):
         assert float((ga - gb).abs().max()) < 3e-4 * max(1.0, float(gb.abs().max()))
+
+
+def test_gemm_fused_row_gather_is_bitwise_the_gathered_gemm():
+    """fc7 over the compacted proposal set: A rows read through a row map inside the pipelined GEMM vs gather + GEMM."""
+    g = _g(77)
+    src, M, N, K = 40000, 33000, 2048, 2048
+    A = torch.randn(src, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.03).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    rmap = torch.randint(0, src, (M,), generator=g).to(torch.int32).cuda()
+    m_dev = torch.tensor([M - 700], dtype=torch.int32).cuda()
+    want = ops.gemm_nt(A[rmap.long()].contiguous(), W, b, 1, m_dev=m_dev)
+    got = ops.gemm_nt(A, W, b, 1, m_dev=m_dev, a_row_map=rmap)
+    live = M - 700
+    assert got.shape == (M, N) and torch.equal(got[:live], want[:live])
+    with pytest.raises(hip.GvdHipError):                    # row offsets beyond the 32-bit buffer offset are refused
+        big = torch.empty(600000, K, device='cuda')          # 4.9 GB of rows: offsets past 2^32
+        ops.gemm_nt(big, W, b, 1, a_row_map=rmap)
+
+
+@pytest.mark.parametrize('B', [8, 70])
+def test_attention_row_map_reads_compacted_features(B):
+    """The per-row attention kernel over COMPACTED region features (row map = CompactIndex.cidx) is bitwise the kernel
+    over the dense expansion (masked rows are never fetched; a fully masked sample averages its representative)."""
+    g = _g(B)
+    R, H, A, Ft = 300, 1024, 512, 10
+    pm = torch.zeros(B, R + 1, dtype=torch.uint8)
+    pm[:, 1:] = (torch.rand(B, R, generator=g) < 0.3).to(torch.uint8)
+    pm[1, 1:] = 1                                            # a fully masked sample
+    pm[2, 1:] = 0                                            # a sample without masked rows
+    pm = pm.cuda()
+    ci = ops.CompactIndex(pm)
+    live = int(ci.m_dev.item())
+    pool_c = torch.zeros(ci.cap, H)
+    pool_c[:live] = torch.randn(live, H, generator=g)
+    p_pool_c = torch.zeros(ci.cap, A)
+    p_pool_c[:live] = torch.randn(live, A, generator=g)
+    pool_c, p_pool_c = pool_c.cuda(), p_pool_c.cuda()
+    q = torch.randn(B, 2 * A, generator=g).cuda()
+    w = (torch.randn(A, generator=g) * 0.2).cuda()
+    ab = torch.zeros(1).cuda()
+    conv, p_conv = torch.randn(B, Ft, H, generator=g).cuda(), torch.randn(B, Ft, A, generator=g).cuda()
+    outs = []
+    for compact in (False, True):
+        lo = torch.empty(B, R, device='cuda')
+        region = dict(feats=pool_c if compact else ci.expand(pool_c), p_feats=p_pool_c if compact else ci.expand(p_pool_c),
+                      q=q[:, A:], w=w, alpha_bias=ab, att_mask=pm[:, 1:], pnt_mask=pm[:, 1:], logits_out=lo)
+        if compact:
+            region['row_map'] = ci.cidx
+        temporal = dict(feats=conv, p_feats=p_conv, q=q[:, :A], w=w, alpha_bias=ab)
+        outs.append((ops.attention_step(region, temporal), lo))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -58,6 +58,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   const int tn_ = lid % p.ntn, tm_ = lid / p.ntn;
   const int bz = blockIdx.y;
   const int m0 = tm_ * BM, n0 = tn_ * BN;
+  // EDGE: an N tile with at most 64 live columns is split 4 x 1 over the waves (32 rows x 64 columns each, all four SIMDs
+  // at half the MFMA count) instead of 2 x 2 with two idle waves; `rb` / `cb` = the wave's block origin inside the tile
+  const bool narrow = EDGE && n0 + BN / 2 >= p.N;
+  const int rb = narrow ? wave * 32 : wm * 64, cb = narrow ? 0 : wn * 64;
 
   // staging role: thread covers rows srow + 32 i (i < 4), 16-byte chunk kq of the 128-byte k slice of a row
   const int srow = tid >> 3, kq = tid & 7;
@@ -164,8 +168,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
 
   // fragment q (8 k values) of the tile in `buf`: lane (r, half) takes k = 8q + 4 half + t for MFMA step t
   static_assert(BK * LDT <= BM * LDK, "a K-strided tile fits the operand buffer");
-  const float* Afr = AT ? &As[half * 4 * LDT + wm * 64 + r] : &As[(wm * 64 + r) * LDK + half * 4];
-  const float* Wfr = BT ? &Ws[half * 4 * LDT + wn * 64 + r] : &Ws[(wn * 64 + r) * LDK + half * 4];
+  const float* Afr = AT ? &As[half * 4 * LDT + rb + r] : &As[(rb + r) * LDK + half * 4];
+  const float* Wfr = BT ? &Ws[half * 4 * LDT + cb + r] : &Ws[(cb + r) * LDK + half * 4];
   auto frags = [&](f32x4 (&a)[2], f32x4 (&b)[2], int buf, int q) {
     if (AT) {
 #pragma unroll
@@ -194,8 +198,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      lv[i][j] = !EDGE || (m0 + __builtin_amdgcn_readfirstlane(wm) * 64 + i * 32 < M &&
-                           n0 + __builtin_amdgcn_readfirstlane(wn) * 64 + j * 32 < p.N);
+      lv[i][j] = !EDGE || (!(narrow && i == 1) && m0 + __builtin_amdgcn_readfirstlane(rb) + i * 32 < M &&
+                           n0 + __builtin_amdgcn_readfirstlane(cb) + j * 32 < p.N);
   auto mfma4 = [&](const f32x4 (&a)[2], const f32x4 (&b)[2], int t) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -244,7 +248,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   mfma16(a1, b1);
 
   if (!EPI_LDS) {
-    gemm_epilogue_plain<2, 2>(p, M, acc, bz, m0 + wm * 64, n0 + wn * 64, r, half);
+    // (narrow tiles: the wave's second row block is not part of the tile - push it past M so nothing is stored)
+    if (narrow) gemm_epilogue_plain<1, 2>(p, M, reinterpret_cast<const f32x16(&)[1][2]>(acc[0]), bz, m0 + rb, n0 + cb, r, half);
+    else gemm_epilogue_plain<2, 2>(p, M, acc, bz, m0 + rb, n0 + cb, r, half);
     return;
   }
   // ---- epilogue through LDS (bias / bias2 / ReLU only; N % 4 == 0, ldc % 4 == 0, C 16-byte aligned)
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
       for (int e = 0; e < 16; ++e)
         T[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * EPI_LD + j * 32 + r] = acc[i][j][e];
   const int c4 = (lane & 15) * 4, rsub = lane >> 4;
-  const int gn = n0 + wn * 64 + c4;
+  const int gn = n0 + cb + c4;
   f32x4 nb = {0.f, 0.f, 0.f, 0.f};
   if (gn < p.N) {
     if (p.nbias) nb = *reinterpret_cast<const f32x4*>(p.nbias + gn);
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int row = it * 4 + rsub;
-    const int gm = m0 + wm * 64 + row;
+    const int gm = (narrow && row >= 32) ? M : m0 + rb + row;        // narrow tiles: 32 rows per wave
     f32x4 v = *reinterpret_cast<const f32x4*>(&T[row * EPI_LD + c4]) + nb;
     if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
     if (gm < M && gn < p.N) *reinterpret_cast<f32x4*>(Cb + (int64_t)gm * p.ldc + gn) = v;
@@ -311,6 +317,6 @@ int gvd_gemm_pipe_launch(KParams& p, int batch, hipStream_t st) {
   }
   // a last tile at most half full in N (few N tiles) or in M (few M tiles) is worth the sub-tile skip
   const int remn = p.N - (p.ntn - 1) * BN, remm = p.M - (p.ntm - 1) * BM;
-  const bool edge = !p.m_dev && ((remn <= BN / 2 && p.ntn <= 4) || (remm <= BM / 2 && p.ntm <= 4));
+  const bool edge = (remn <= BN / 2 && p.ntn <= 4) || (!p.m_dev && remm <= BM / 2 && p.ntm <= 4);
   return edge ? pipe_launch_t<true>(p, grid, lds_epi, st) : pipe_launch_t<false>(p, grid, lds_epi, st);
 }

@@ -484,8 +484,21 @@ class TopDownModel(nn.Module):
                 pool = self._drop(ops.gemm_nt(pool, self._pool_weight_padded(pool.shape[-1]),
                                               self.pool_embed[0].bias.detach(), 1))
                 pool_done = True
+        elif (os.environ.get('GVD_P5_FUSED_TRAIN', '1') == '1' and g_pool.shape[-1] == 2048 and D1 <= 512
+              and loc.shape[-1] <= 512):
+            # training: the same class-last similarity GEMM + fused row kernel as inference, with a fused backward row
+            # kernel (three layer-norm backwards + class-softmax backward, ops._RegionRowsFn).  The class axis is
+            # zero-padded to a 32-multiple so that dX / dW of the similarity GEMM run on the K-strided MFMA kernel; the
+            # pad classes never enter the softmax (n_cls = D1) and receive zero gradient.
+            cpad = (-D1) % 32
+            logits_t = ops.linear(g_pool, F.pad(vis_word, (0, 0, 0, cpad)), F.pad(self.vis_classifiers_bias, (0, cpad)))
+            pool, sim_t = ops.region_feature_rows_train(g_pool, loc, logits_t, pm, D1, pad_to=32)
+            sim_mat = sim_t.transpose(1, 2)          # [B,D1,R] view of the class-last tensor
+            pe = self.pool_embed[0]
+            pool = self._drop(ops.linear(pool, F.pad(pe.weight, (0, pool.shape[-1] - pe.weight.shape[1])), pe.bias, 1))
+            pool_done = True
         else:
-            # region-class similarity: batched grounder GEMM with fused bias + proposal mask (model.py:321-340)
+            # (GVD_P5_FUSED_TRAIN=0) region-class similarity: batched grounder GEMM with fused bias + proposal mask (model.py:321-340)
             sim_logits = ops.grounder(vis_word, g_pool, pm[:, 1:], mbias=self.vis_classifiers_bias, xt_shared=True)
             sim_mat = F.softmax(sim_logits, dim=1)
             # location / class-distribution features (model.py:357-364)
@@ -516,6 +529,11 @@ class TopDownModel(nn.Module):
         if not torch.is_grad_enabled():
             # inference: persistent cooperative HIP GRU (one launch per layer instead of ~6 per step/direction)
             c = ops.gru_bidir_2layer(c, self.context_enc, flags=self._flags())
+        elif (os.environ.get('GVD_GRU_TRAIN', '1') == '1' and self.context_enc.hidden_size == 512
+              and self.context_enc.bidirectional and self.context_enc.batch_first):
+            # training: persistent-kernel forward + hand-scheduled BPTT (gru_fn.py) instead of the library RNN
+            from . import gru_fn
+            c = gru_fn.gru_bidir_2layer_train(c, self.context_enc, flags=self._flags())
         elif not self.training:
             # MIOpen's fused RNN has no backward in eval mode; the native GRU does (parity tests differentiate in eval)
             with torch.backends.cudnn.flags(enabled=False):

@@ -197,7 +197,57 @@ int gru_cus() {
   return cus;
 }
 
+// One reverse step of the layer's BPTT for BOTH directions (training; nn.GRU backward).  Direction d handles time
+// t_d (forward direction walks T-1..0, backward direction 0..T-1).  With the gates recomputed from gi (saved) and
+// gh = h_{t-1} W_hh^T + b_hh (one GEMM over all steps, the hidden sequence IS the layer output):
+//   dh  = dout[t] + carry_mm + carry_z        (carry_mm = d_gh[t'] W_hh of the step before, carry_z = dh' z')
+//   dn  = dh (1-z) (1-n^2) ; dz = dh (h_prev - n) z (1-z) ; dr = dn gh_n r (1-r)
+//   d_gi[t] = [dr, dz, dn] ; d_gh[t] = [dr, dz, dn r] ; carry_z = dh z
+// One thread per (direction, row, hidden unit); latency-trivial (2*B*Hh threads), exists to replace ~15 library
+// launches per (step, direction).
+__global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restrict__ dout, const float* __restrict__ gi,
+                                                           const float* __restrict__ gh, const float* __restrict__ out,
+                                                           const float* __restrict__ carry_mm, float* __restrict__ carry_z,
+                                                           float* __restrict__ d_gi, float* __restrict__ d_gh, int B, int T,
+                                                           int Hh, int t_fw, int t_bw, int first) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)2 * B * Hh) return;
+  const int j = (int)(i % Hh);
+  const int b = (int)((i / Hh) % B);
+  const int d = (int)(i / ((int64_t)Hh * B));
+  const int t = d ? t_bw : t_fw;
+  const int tp = d ? t + 1 : t - 1;
+  const int64_t g0 = (((int64_t)b * T + t) * 2 + d) * 3 * Hh + j;
+  const float ghn = gh[g0 + 2 * Hh];
+  const float r = 1.f / (1.f + expf(-(gi[g0] + gh[g0])));
+  const float z = 1.f / (1.f + expf(-(gi[g0 + Hh] + gh[g0 + Hh])));
+  const float n = tanhf(fmaf(r, ghn, gi[g0 + 2 * Hh]));
+  const float hp = (tp >= 0 && tp < T) ? out[((int64_t)b * T + tp) * 2 * Hh + d * Hh + j] : 0.f;
+  const int64_t ci = ((int64_t)d * B + b) * Hh + j;
+  float dh = dout[((int64_t)b * T + t) * 2 * Hh + d * Hh + j];
+  if (!first) dh += carry_mm[ci] + carry_z[ci];
+  const float dn = dh * (1.f - z) * (1.f - n * n);
+  const float dz = dh * (hp - n) * z * (1.f - z);
+  const float dr = dn * ghn * r * (1.f - r);
+  d_gi[g0] = dr; d_gi[g0 + Hh] = dz; d_gi[g0 + 2 * Hh] = dn;
+  d_gh[g0] = dr; d_gh[g0 + Hh] = dz; d_gh[g0 + 2 * Hh] = dn * r;
+  carry_z[ci] = dh * z;
+}
+
 }  // namespace
+
+extern "C" int gvd_gru_bwd_step(const float* dout, const float* gi, const float* gh, const float* out,
+                                const float* carry_mm, float* carry_z, float* d_gi, float* d_gh, int B, int T, int Hh,
+                                int t_fw, int t_bw, int first, gvd_stream_t stream) {
+  if (!dout || !gi || !gh || !out || !carry_z || !d_gi || !d_gh || (!first && !carry_mm) || B <= 0 || T <= 0 || Hh <= 0 ||
+      t_fw < 0 || t_fw >= T || t_bw < 0 || t_bw >= T)
+    return GVD_EINVAL;
+  const int64_t n = (int64_t)2 * B * Hh;
+  hipLaunchKernelGGL(gru_bwd_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, gvd_s(stream), dout, gi, gh, out,
+                     carry_mm, carry_z, d_gi, d_gh, B, T, Hh, t_fw, t_bw, first);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const float* b_hh_fw, const float* w_hh_bw,
                                    const float* b_hh_bw, float* out, int B, int T, int Hh, void* sync_ws,

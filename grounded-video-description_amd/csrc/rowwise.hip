@@ -155,6 +155,7 @@ constexpr int RF_MAXC = 8;   // per-lane slots for the loc (<= 512) and class (<
 __global__ __launch_bounds__(256) void region_feature_rows_kernel(const float* __restrict__ g_pool,
                                                                   const float* __restrict__ loc, int n_loc,
                                                                   const float* __restrict__ logits, int n_cls,
+                                                                  int64_t logits_ld,
                                                                   const uint8_t* __restrict__ row_mask,
                                                                   int64_t mask_row_div, int64_t mask_ld,
                                                                   float* __restrict__ out, int64_t out_ld,
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void region_feature_rows_kernel(const float* _
   }
   // ---- segment 3: class softmax of the (masked) similarity logits, then layer_norm of the distribution
   {
-    const float* sr = logits + row * n_cls;
+    const float* sr = logits + row * logits_ld;
     const bool masked = row_mask && row_mask[(row / mask_row_div) * mask_ld + (row % mask_row_div)];
     float v[RF_MAXC];
     float mx = -INFINITY;
@@ -272,6 +273,133 @@ __global__ __launch_bounds__(256) void region_feature_rows_kernel(const float* _
   }
 }
 
+// Backward of region_feature_rows_kernel (training): per proposal row, from d_out [2048 | n_loc | n_cls | pads] and the
+// optional direct gradient of the class distribution (the region-classification loss reads sim_out):
+//   F.layer_norm without affine:  dx = rstd (dy - mean(dy) - y mean(dy y)),  y = (x - mean) rstd  (statistics recomputed)
+//   class softmax:                dl = p (dp - sum p dp),  dp = LN-backward + d_sim;  masked rows had constant logits: dl = 0
+// Reads g_pool / loc / p / d_out once, writes d_gpool / d_loc / d_logits once (one wave per row, values in registers).
+__global__ __launch_bounds__(256) void region_feature_rows_bwd_kernel(
+    const float* __restrict__ g_pool, const float* __restrict__ loc, int n_loc, const float* __restrict__ sim, int n_cls,
+    const uint8_t* __restrict__ row_mask, int64_t mask_row_div, int64_t mask_ld, const float* __restrict__ dout,
+    int64_t dout_ld, const float* __restrict__ dsim, float* __restrict__ d_gpool, float* __restrict__ d_loc,
+    float* __restrict__ d_logits, int64_t dl_ld, int64_t rows, float ln_eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* dor = dout + row * dout_ld;
+  {
+    const float* gr = g_pool + row * RF_G;
+    f32x4 v[8], d[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] = *reinterpret_cast<const f32x4*>(gr + i * 256 + 4 * lane);
+      d[i] = *reinterpret_cast<const f32x4*>(dor + i * 256 + 4 * lane);
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mean = wave_sum(s) / RF_G;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[i][k] -= mean; q = fmaf(v[i][k], v[i][k], q); }
+    const float rstd = rsqrtf(wave_sum(q) / RF_G + ln_eps);
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[i][k] *= rstd; a += d[i][k]; c = fmaf(d[i][k], v[i][k], c); }
+    const float m1 = wave_sum(a) / RF_G, m2 = wave_sum(c) / RF_G;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = rstd * (d[i][k] - m1 - v[i][k] * m2);
+      *reinterpret_cast<f32x4*>(d_gpool + row * RF_G + i * 256 + 4 * lane) = o;
+    }
+  }
+  {
+    const float* lr = loc + row * n_loc;
+    float v[RF_MAXC], d[RF_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int cc = i * 64 + lane;
+      v[i] = cc < n_loc ? lr[cc] : 0.f;
+      d[i] = cc < n_loc ? dor[RF_G + cc] : 0.f;
+      s += v[i];
+    }
+    const float mean = wave_sum(s) / n_loc;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int cc = i * 64 + lane;
+      v[i] = cc < n_loc ? v[i] - mean : 0.f;
+      q = fmaf(v[i], v[i], q);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / n_loc + ln_eps);
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) { v[i] *= rstd; a += d[i]; c = fmaf(d[i], v[i], c); }
+    const float m1 = wave_sum(a) / n_loc, m2 = wave_sum(c) / n_loc;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int cc = i * 64 + lane;
+      if (cc < n_loc) d_loc[row * n_loc + cc] = rstd * (d[i] - m1 - v[i] * m2);
+    }
+  }
+  {
+    const bool masked = row_mask && row_mask[(row / mask_row_div) * mask_ld + (row % mask_row_div)];
+    float* dl = d_logits + row * dl_ld;
+    for (int cc = n_cls + lane; cc < dl_ld; cc += 64) dl[cc] = 0.f;       // pad classes of the K-padded operand
+    if (masked) {
+#pragma unroll
+      for (int i = 0; i < RF_MAXC; ++i) {
+        const int cc = i * 64 + lane;
+        if (cc < n_cls) dl[cc] = 0.f;
+      }
+      return;
+    }
+    float pv[RF_MAXC], v[RF_MAXC], d[RF_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int cc = i * 64 + lane;
+      pv[i] = cc < n_cls ? sim[row * n_cls + cc] : 0.f;
+      d[i] = cc < n_cls ? dor[RF_G + n_loc + cc] : 0.f;
+      s += pv[i];
+    }
+    const float mean = wave_sum(s) / n_cls;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int cc = i * 64 + lane;
+      v[i] = cc < n_cls ? pv[i] - mean : 0.f;
+      q = fmaf(v[i], v[i], q);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / n_cls + ln_eps);
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) { v[i] *= rstd; a += d[i]; c = fmaf(d[i], v[i], c); }
+    const float m1 = wave_sum(a) / n_cls, m2 = wave_sum(c) / n_cls;
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int cc = i * 64 + lane;
+      float dp = cc < n_cls ? rstd * (d[i] - m1 - v[i] * m2) : 0.f;
+      if (dsim && cc < n_cls) dp += dsim[row * n_cls + cc];
+      d[i] = dp;
+      dot = fmaf(pv[i], dp, dot);
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < RF_MAXC; ++i) {
+      const int cc = i * 64 + lane;
+      if (cc < n_cls) dl[cc] = pv[i] * (d[i] - dot);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int gvd_add_layernorm_unbiased(const float* x, const float* y, const float* gamma, const float* beta,
@@ -302,17 +430,34 @@ extern "C" int gvd_add_layernorm_unbiased_bwd(const float* x, const float* y, co
 }
 
 extern "C" int gvd_region_feature_rows(const float* g_pool, const float* loc, int n_loc, const float* sim_logits,
-                                       int n_cls, const uint8_t* row_mask, int64_t mask_rows_per_batch,
+                                       int n_cls, int64_t logits_ld, const uint8_t* row_mask, int64_t mask_rows_per_batch,
                                        int64_t mask_ld, float* out, int64_t out_ld, float* sim_out, int64_t rows,
                                        const int* rows_dev, int G, float ln_eps, gvd_stream_t stream) {
   if (!g_pool || !loc || !sim_logits || !out || rows <= 0 || G != RF_G || n_loc <= 0 || n_loc > 64 * RF_MAXC ||
-      n_cls <= 0 || n_cls > 64 * RF_MAXC || !gvd_aligned16(g_pool) || out_ld < G + n_loc + n_cls ||
+      n_cls <= 0 || n_cls > 64 * RF_MAXC || logits_ld < n_cls || !gvd_aligned16(g_pool) || out_ld < G + n_loc + n_cls ||
       ((out_ld & 3) == 0 && !gvd_aligned16(out)))
     return GVD_EINVAL;
   if (row_mask && mask_rows_per_batch <= 0) return GVD_EINVAL;
   hipLaunchKernelGGL(region_feature_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, gvd_s(stream), g_pool,
-                     loc, n_loc, sim_logits, n_cls, row_mask, row_mask ? mask_rows_per_batch : 1, mask_ld, out, out_ld,
-                     sim_out, rows, rows_dev, ln_eps);
+                     loc, n_loc, sim_logits, n_cls, logits_ld, row_mask, row_mask ? mask_rows_per_batch : 1, mask_ld, out,
+                     out_ld, sim_out, rows, rows_dev, ln_eps);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gvd_region_feature_rows_bwd(const float* g_pool, const float* loc, int n_loc, const float* sim, int n_cls,
+                                           const uint8_t* row_mask, int64_t mask_rows_per_batch, int64_t mask_ld,
+                                           const float* d_out, int64_t d_out_ld, const float* d_sim, float* d_gpool,
+                                           float* d_loc, float* d_logits, int64_t d_logits_ld, int64_t rows, int G,
+                                           float ln_eps, gvd_stream_t stream) {
+  if (!g_pool || !loc || !sim || !d_out || !d_gpool || !d_loc || !d_logits || rows <= 0 || G != RF_G || n_loc <= 0 ||
+      n_loc > 64 * RF_MAXC || n_cls <= 0 || n_cls > 64 * RF_MAXC || d_out_ld < G + n_loc + n_cls || (d_out_ld & 3) ||
+      d_logits_ld < n_cls || !gvd_aligned16(g_pool) || !gvd_aligned16(d_out) || !gvd_aligned16(d_gpool))
+    return GVD_EINVAL;
+  if (row_mask && mask_rows_per_batch <= 0) return GVD_EINVAL;
+  hipLaunchKernelGGL(region_feature_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, gvd_s(stream), g_pool,
+                     loc, n_loc, sim, n_cls, row_mask, row_mask ? mask_rows_per_batch : 1, mask_ld, d_out, d_out_ld, d_sim,
+                     d_gpool, d_loc, d_logits, d_logits_ld, rows, ln_eps);
   GVD_CHECK_LAUNCH();
   return 0;
 }

@@ -129,8 +129,9 @@ __global__ __launch_bounds__(64) void masked_lsm_reduce_kernel(float* acc, int r
 // Region-classification loss (model.py:345-350): over the (box k, proposal r) pairs with sim_target > 0,
 // -mean( clamp(log sim_mat[b, sim_target[b,k,r], r], -100) ): gather + log + masked mean in one pass, per-block partials
 // (sum, count) reduced in a fixed order by masked_lsm_reduce_kernel.
-__global__ __launch_bounds__(256) void cls_loss_kernel(const float* __restrict__ sim, const int64_t* __restrict__ tgt,
-                                                       int D1, int R, int K, int64_t n, float* acc) {
+__global__ __launch_bounds__(256) void cls_loss_kernel(const float* __restrict__ sim, int64_t sb, int64_t sc, int64_t sr,
+                                                       const int64_t* __restrict__ tgt, int R, int K, int64_t n,
+                                                       float* acc) {
   __shared__ float s_red[8];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float s = 0.f, c = 0.f;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void cls_loss_kernel(const float* __restrict__
     if (t > 0) {
       const int r = (int)(i % R);
       const int64_t b = i / ((int64_t)R * K);
-      s = -fmaxf(logf(sim[(b * D1 + t) * R + r]), -100.f);
+      s = -fmaxf(logf(sim[b * sb + t * sc + r * sr]), -100.f);
       c = 1.f;
     }
   }
@@ -154,13 +155,13 @@ __global__ __launch_bounds__(256) void cls_loss_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int gvd_cls_loss(const float* sim_mat, const int64_t* sim_target, int B, int D1, int R, int K, float* acc,
-                            gvd_stream_t stream) {
+extern "C" int gvd_cls_loss(const float* sim_mat, int64_t stride_b, int64_t stride_cls, int64_t stride_r,
+                            const int64_t* sim_target, int B, int D1, int R, int K, float* acc, gvd_stream_t stream) {
   if (!sim_mat || !sim_target || !acc || B <= 0 || D1 <= 0 || R <= 0 || K <= 0) return GVD_EINVAL;
   const int64_t n = (int64_t)B * K * R;
   const int nblk = (int)((n + 255) / 256);
-  hipLaunchKernelGGL(cls_loss_kernel, dim3((unsigned)nblk), dim3(256), 0, gvd_s(stream), sim_mat, sim_target, D1, R, K, n,
-                     acc);
+  hipLaunchKernelGGL(cls_loss_kernel, dim3((unsigned)nblk), dim3(256), 0, gvd_s(stream), sim_mat, stride_b, stride_cls,
+                     stride_r, sim_target, R, K, n, acc);
   hipLaunchKernelGGL(masked_lsm_reduce_kernel, dim3(1), dim3(64), 0, gvd_s(stream), acc, nblk);
   GVD_CHECK_LAUNCH();
   return 0;

@@ -15,6 +15,14 @@ import torch
 from . import decoder_fn
 
 
+def _tn(dY, X):
+    """dY^T X (a weight gradient over the stacked [Lc*B, .] activations): the K-strided MFMA kernel when the shape is one
+    it takes, the library product otherwise."""
+    f = getattr(decoder_fn.K, 'gemm_dw', None)
+    r = f(dY, X) if (f is not None and dY.is_contiguous() and X.is_contiguous()) else None
+    return dY.t() @ X if r is None else r
+
+
 class DecoderLoopFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, att_mask, pnt_masks, keys, fc, conv, p_conv, pool, p_pool, xt_all, *params):
@@ -51,40 +59,46 @@ class DecoderLoopFn(torch.autograd.Function):
         dG_lang = torch.empty(Lc, B, 4 * H, device=dev, dtype=fc.dtype)
         dG_att = torch.empty(Lc, B, 4 * H, device=dev, dtype=fc.dtype)
         dq12_all = torch.empty(Lc, B, 2 * A, device=dev, dtype=fc.dtype)
-        dctx_all = torch.empty(Lc, B, H, device=dev, dtype=fc.dtype)
+        dX_all = torch.empty(Lc, B, 2 * H, device=dev, dtype=fc.dtype)      # [d(att+att2) | d h_att] of the lang-LSTM input
         de_r_all = torch.empty(Lc, B, R, device=dev, dtype=fc.dtype)
         de_t_all = torch.empty(Lc, B, Ft, device=dev, dtype=fc.dtype)
-        dw_r = torch.zeros(A, device=dev, dtype=fc.dtype); dw_t = torch.zeros(A, device=dev, dtype=fc.dtype)
-        dab_r = torch.zeros(1, device=dev, dtype=fc.dtype); dab_t = torch.zeros(1, device=dev, dtype=fc.dtype)
+        # per-chunk partials of the alpha_net gradients of every step: reduced ONCE after the loop
+        nc_r, nc_t = K.attn_bwd_chunks(R, B), K.attn_bwd_chunks(Ft, B)
+        dw_r_all = torch.empty(Lc, B, nc_r, A, device=dev, dtype=fc.dtype)
+        dw_t_all = torch.empty(Lc, B, nc_t, A, device=dev, dtype=fc.dtype)
+        dab_r_all = torch.empty(Lc, B, nc_r, device=dev, dtype=fc.dtype)
+        dab_t_all = torch.empty(Lc, B, nc_t, device=dev, dtype=fc.dtype)
         dh_att_next = dh_lang_next = None
         dc_att_next = dc_lang_next = None
         w_lang_ih, w_lang_hh, w_att_hh = P['lang_w_ih'], P['lang_w_hh'], P['att_w_hh']
         for t in range(Lc - 1, -1, -1):
+            # every kernel writes its step's slice of the [Lc, ...] arrays in place: no per-step copies / partial sums
             dh_lang = d_h_all[:, t] if dh_lang_next is None else d_h_all[:, t] + dh_lang_next
-            dg, dc_lang_next = K.lstm_cell_bwd(dh_lang, dc_lang_next, S['gates_lang'][t], S['c_lang'][t], S['c_lang'][t + 1])
-            dG_lang[t].copy_(dg)
-            dX = dg @ w_lang_ih                                  # [B,2H] = [d(att+att2) | d h_att]
+            dg, dc_lang_next = K.lstm_cell_bwd(dh_lang, dc_lang_next, S['gates_lang'][t], S['c_lang'][t], S['c_lang'][t + 1],
+                                               dg_out=dG_lang[t])
+            dX = torch.mm(dg, w_lang_ih, out=dX_all[t])         # [B,2H] = [d(att+att2) | d h_att]
             dh_lang_next = dg @ w_lang_hh
-            d_att_sum = dX[:, :H].contiguous()
-            dctx_all[t].copy_(d_att_sum)
+            d_att_sum = dX[:, :H]
             pmask = (pnt_masks[:, t] if per_step_mask else pnt_masks)[:, 1:]
             q12 = S['q12'][t]
             region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P['a2_ab'], att_mask=am,
                           pnt_mask=pmask)
             temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab'])
             dl = d_att2w[:, t] if d_att2w is not None else None
-            de_r, dq_r, dwr, dabr = K.attn_bwd_step(region, alpha_r[:, t], S['ctx_r'][t], d_att_sum, dl)
-            de_t, dq_t, dwt, dabt = K.attn_bwd_step(temporal, alpha_t[:, t], S['ctx_t'][t], d_att_sum, None)
-            de_r_all[t].copy_(de_r); de_t_all[t].copy_(de_t)
-            dw_r += dwr.sum(0); dw_t += dwt.sum(0); dab_r += dabr.sum(); dab_t += dabt.sum()
-            dq12 = torch.cat([dq_t, dq_r], dim=1)
-            dq12_all[t].copy_(dq12)
-            dh_att = dX[:, H:] + dq12 @ w_stack
+            dq12 = dq12_all[t]
+            K.attn_bwd_step(region, alpha_r[:, t], S['ctx_r'][t], d_att_sum, dl, de_out=de_r_all[t],
+                            dq_out=dq12[:, A:], dw_part=dw_r_all[t], dab_part=dab_r_all[t])
+            K.attn_bwd_step(temporal, alpha_t[:, t], S['ctx_t'][t], d_att_sum, None, de_out=de_t_all[t],
+                            dq_out=dq12[:, :A], dw_part=dw_t_all[t], dab_part=dab_t_all[t])
+            dh_att = torch.addmm(dX[:, H:], dq12, w_stack)
             if dh_att_next is not None:
-                dh_att = dh_att + dh_att_next
-            dg, dc_att_next = K.lstm_cell_bwd(dh_att, dc_att_next, S['gates_att'][t], S['c_att'][t], S['c_att'][t + 1])
-            dG_att[t].copy_(dg)
+                dh_att += dh_att_next
+            dg, dc_att_next = K.lstm_cell_bwd(dh_att, dc_att_next, S['gates_att'][t], S['c_att'][t], S['c_att'][t + 1],
+                                              dg_out=dG_att[t])
             dh_att_next = dg @ w_att_hh
+        dw_r, dw_t = dw_r_all.sum((0, 1, 2)), dw_t_all.sum((0, 1, 2))
+        dab_r, dab_t = dab_r_all.sum().view(1), dab_t_all.sum().view(1)
+        dctx_all = dX_all[:, :, :H]
 
         # ---- gradients formed once for all steps
         dGa = dG_att.view(Lc * B, 4 * H)
@@ -99,16 +113,16 @@ class DecoderLoopFn(torch.autograd.Function):
         g = {}
         g['fc'] = sumG @ w_att_ih[:, :H]
         g['xt_all'] = (dGa @ w_att_ih[:, H:]).view(Lc, B, E).transpose(0, 1).contiguous()
-        g['att_w_ih'] = torch.cat([sumG.t() @ fc, dGa.t() @ xt_flat], dim=1)
-        g['att_w_hh'] = dGa.t() @ h_att_prev
+        g['att_w_ih'] = torch.cat([_tn(sumG, fc), _tn(dGa, xt_flat)], dim=1)
+        g['att_w_hh'] = _tn(dGa, h_att_prev)
         g['att_b_ih'] = dGa.sum(0)
         g['att_b_hh'] = g['att_b_ih']
-        g['lang_w_ih'] = torch.cat([dGl.t() @ att_sum, dGl.t() @ h_att_new], dim=1)
-        g['lang_w_hh'] = dGl.t() @ h_lang_prev
+        g['lang_w_ih'] = torch.cat([_tn(dGl, att_sum), _tn(dGl, h_att_new)], dim=1)
+        g['lang_w_hh'] = _tn(dGl, h_lang_prev)
         g['lang_b_ih'] = dGl.sum(0)
         g['lang_b_hh'] = g['lang_b_ih']
         dq_flat = dq12_all.view(Lc * B, 2 * A)
-        d_wstack = dq_flat.t() @ h_att_new                       # [2A,H]
+        d_wstack = _tn(dq_flat, h_att_new)                       # [2A,H]
         d_bstack = dq_flat.sum(0)
         g['a1_w'], g['a2_w'] = d_wstack[:A], d_wstack[A:]
         g['a1_b'], g['a2_b'] = d_bstack[:A], d_bstack[A:]

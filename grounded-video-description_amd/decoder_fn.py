@@ -56,30 +56,36 @@ def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks,
                     w_stack=w_stack)
         for k in ('c_att', 'c_lang', 'h_att', 'h_lang'):
             save[k][0].zero_()
+    if save is not None:
+        # training: every kernel writes its step's slice of the saved-state arrays in place (no per-step copies)
+        for t in range(Lc):
+            h_att, c_att = K.lstm_cell([xt_all[:, t]], [w_ih_xt], save['h_att'][t], P['att_w_hh'], None, None,
+                                       save['c_att'][t], rowbias=fc_gates, gates_out=save['gates_att'][t],
+                                       h_out=save['h_att'][t + 1], c_out=save['c_att'][t + 1])
+            q12 = K.gemm_nt(h_att, w_stack, b_stack, out=save['q12'][t])
+            pmask = (pnt_masks[:, t] if per_step_mask else pnt_masks)[:, 1:]
+            region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P['a2_ab'], att_mask=am,
+                          pnt_mask=pmask, logits_out=att2_w[:, t], scores_out=save['scores_r'][:, t])
+            temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab'],
+                            scores_out=save['scores_t'][:, t])
+            att_sum, _, _ = K.attention_step(region, temporal, want_separate=True, out=save['att_sum'][t],
+                                             cr_out=save['ctx_r'][t], ct_out=save['ctx_t'][t])
+            K.lstm_cell([att_sum, h_att], [w_ih_att, w_ih_h], save['h_lang'][t], P['lang_w_hh'], P['lang_b_ih'],
+                        P['lang_b_hh'], save['c_lang'][t], gates_out=save['gates_lang'][t],
+                        h_out=save['h_lang'][t + 1], c_out=save['c_lang'][t + 1])
+        h_all.copy_(save['h_lang'][1:].transpose(0, 1))
+        return h_all, att2_w
     for t in range(Lc):
         xt = xt_all[:, t]
-        g_att = save['gates_att'][t] if save is not None else None
-        h_att, c_att = K.lstm_cell([xt], [w_ih_xt], h_att, P['att_w_hh'], None, None, c_att,
-                                     rowbias=fc_gates, gates_out=g_att)
-        q12 = K.gemm_nt(h_att, w_stack, b_stack, out=save['q12'][t] if save is not None else None)
+        h_att, c_att = K.lstm_cell([xt], [w_ih_xt], h_att, P['att_w_hh'], None, None, c_att, rowbias=fc_gates)
+        q12 = K.gemm_nt(h_att, w_stack, b_stack)
         pmask = (pnt_masks[:, t] if per_step_mask else pnt_masks)[:, 1:]
         region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P['a2_ab'], att_mask=am,
                       pnt_mask=pmask, logits_out=att2_w[:, t])
         temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab'])
-        if save is not None:
-            region['scores_out'] = save['scores_r'][:, t]
-            temporal['scores_out'] = save['scores_t'][:, t]
-            att_sum, cr, ct = K.attention_step(region, temporal, want_separate=True)
-            save['ctx_r'][t].copy_(cr); save['ctx_t'][t].copy_(ct); save['att_sum'][t].copy_(att_sum)
-        else:
-            att_sum = K.attention_step(region, temporal)
-        g_lang = save['gates_lang'][t] if save is not None else None
+        att_sum = K.attention_step(region, temporal)
         h_lang, c_lang = K.lstm_cell([att_sum, h_att], [w_ih_att, w_ih_h], h_lang, P['lang_w_hh'],
-                                       P['lang_b_ih'], P['lang_b_hh'], c_lang, gates_out=g_lang)
-        h_all[:, t].copy_(h_lang)
-        if save is not None:
-            save['h_att'][t + 1].copy_(h_att); save['c_att'][t + 1].copy_(c_att)
-            save['h_lang'][t + 1].copy_(h_lang); save['c_lang'][t + 1].copy_(c_lang)
+                                     P['lang_b_ih'], P['lang_b_hh'], c_lang, h_out=h_all[:, t])
     return h_all, att2_w
 
 

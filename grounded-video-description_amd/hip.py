@@ -98,9 +98,12 @@ _SIG = {
                                               C.c_uint64, C.c_void_p]),
     'gvd_enc_softmax_dropout_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
                                               C.c_void_p]),
-    'gvd_region_feature_rows': (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_u8p, C.c_int64, C.c_int64,
+    'gvd_region_feature_rows': (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int64, c_u8p, C.c_int64, C.c_int64,
                                           c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_void_p, C.c_int, C.c_float,
                                           C.c_void_p]),
+    'gvd_region_feature_rows_bwd': (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_u8p, C.c_int64, C.c_int64,
+                                              c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64,
+                                              C.c_int, C.c_float, C.c_void_p]),
     'gvd_flash_attn_f32': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int64, C.c_int,
                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
     'gvd_flash_attn_padded_f32': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int,
@@ -114,6 +117,8 @@ _SIG = {
     'gvd_grid_sync_words': (C.c_int, []),
     'gvd_gru_bidir_layer': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p]),
+    'gvd_gru_bwd_step': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'gvd_lstm_cell_bwd': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64,
                                     c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int64,
                                     C.c_void_p]),
@@ -135,13 +140,14 @@ _SIG = {
                                   c_f32p, c_i64p, C.c_void_p]),
     'gvd_step_targets': (C.c_int, [c_f32p, c_u8p, c_u8p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    c_f32p, c_u8p, C.c_void_p]),
-    'gvd_cls_loss': (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
+    'gvd_cls_loss': (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
+                               C.c_void_p]),
     'gvd_masked_lsm_loss': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, c_f32p,
                                       C.c_void_p]),
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 5        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 6        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

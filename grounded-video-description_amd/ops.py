@@ -125,13 +125,15 @@ def grounder_dot(xt, feats, mask, mbias=None, rowbias=None, xt_shared=False):
     return out
 
 
-def lstm_cell(xs, ws, h_prev, w_hh, b_ih, b_hh, c_prev, rowbias=None, gates_out=None):
+def lstm_cell(xs, ws, h_prev, w_hh, b_ih, b_hh, c_prev, rowbias=None, gates_out=None, h_out=None, c_out=None):
     """Fused nn.LSTMCell forward.  xs/ws: lists of input blocks [B,K_s] and the matching column blocks
-    of weight_ih ([4H,K_s] views, row stride = full weight_ih width).  Returns (h, c)."""
+    of weight_ih ([4H,K_s] views, row stride = full weight_ih width).  Returns (h, c); `h_out` / `c_out` ([B,H] views
+    with unit inner stride, e.g. one step of the BPTT's saved-state arrays) receive them in place when given."""
     B, H = c_prev.shape
     require_cuda_f32(h_prev, c_prev, w_hh, *xs, *ws)
-    h = torch.empty(B, H, device=c_prev.device, dtype=torch.float32)
-    c = torch.empty(B, H, device=c_prev.device, dtype=torch.float32)
+    h = torch.empty(B, H, device=c_prev.device, dtype=torch.float32) if h_out is None else h_out
+    c = torch.empty(B, H, device=c_prev.device, dtype=torch.float32) if c_out is None else c_out
+    assert h.stride(-1) == 1 and c.stride(-1) == 1 and h.shape == (B, H) and c.shape == (B, H)
     a = LstmArgs()
     segs = list(zip(xs, ws)) + [(h_prev, w_hh)]
     a.nseg = len(segs)
@@ -141,8 +143,8 @@ def lstm_cell(xs, ws, h_prev, w_hh, b_ih, b_hh, c_prev, rowbias=None, gates_out=
     if rowbias is not None:
         a.rowbias = ptr(rowbias); a.rowbias_ld = rowbias.stride(0)
     a.c_prev = ptr(c_prev); a.ldc_prev = c_prev.stride(0)
-    a.h_out = ptr(h); a.ldh = H
-    a.c_out = ptr(c); a.ldc_out = H
+    a.h_out = ptr(h); a.ldh = h.stride(0)
+    a.c_out = ptr(c); a.ldc_out = c.stride(0)
     if gates_out is not None:
         a.gates_out = ptr(gates_out); a.ldg = gates_out.stride(0)
     a.B, a.H = B, H
@@ -201,11 +203,12 @@ def set_kernel_timer(timer):
     _kernel_timer = timer
 
 
-def attention_step(region, temporal, want_separate=False):
+def attention_step(region, temporal, want_separate=False, out=None, cr_out=None, ct_out=None):
     """Both additive attentions of one decoder step (AttModel.py:33-53,71-108) in one streaming pass.
 
     region / temporal: dicts(feats, p_feats, q, w, alpha_bias[, att_mask, pnt_mask, logits_out]).
-    Returns att+att2 [B,H] (and the two contexts when want_separate)."""
+    Returns att+att2 [B,H] (and the two contexts when want_separate); `out` ([B,H], unit inner stride) and the contiguous
+    `cr_out` / `ct_out` receive them in place when given."""
     f = region['feats']
     B = region['q'].shape[0]                      # rows (= feats.shape[0] * group)
     if region.get('row_map') is not None:
@@ -219,11 +222,16 @@ def attention_step(region, temporal, want_separate=False):
     st = _side(**temporal) if temporal is not None else None
     Nt = temporal['feats'].shape[1] if temporal is not None else 0
     ws = _workspace(lib().gvd_attn_workspace_bytes(B, Nr, Nt, H), f.device)
-    out = torch.empty(B, H, device=f.device, dtype=torch.float32)
-    cr = torch.empty(B, H, device=f.device, dtype=torch.float32) if want_separate else None
-    ct = torch.empty(B, H, device=f.device, dtype=torch.float32) if (want_separate and st is not None) else None
+    if out is None:
+        out = torch.empty(B, H, device=f.device, dtype=torch.float32)
+    cr = ct = None
+    if want_separate:
+        cr = torch.empty(B, H, device=f.device, dtype=torch.float32) if cr_out is None else cr_out
+        if st is not None:
+            ct = torch.empty(B, H, device=f.device, dtype=torch.float32) if ct_out is None else ct_out
+    assert out.stride(-1) == 1 and out.shape == (B, H) and all(t is None or t.is_contiguous() for t in (cr, ct))
     prof = _kernel_timer.h if _kernel_timer is not None else None
-    check(lib().gvd_attn_fwd_prof(C.byref(sr), C.byref(st) if st is not None else None, B, A, H, ptr(out), H,
+    check(lib().gvd_attn_fwd_prof(C.byref(sr), C.byref(st) if st is not None else None, B, A, H, ptr(out), out.stride(0),
                                   ptr(cr), ptr(ct), ptr(ws), prof, stream_ptr()), 'gvd_attn_fwd')
     return (out, cr, ct) if want_separate else out
 
@@ -477,7 +485,8 @@ class _ClsLossFn(torch.autograd.Function):
         K = sim_target.shape[1]
         nblk = (B * K * R + 255) // 256
         acc = torch.empty(2 + 2 * nblk, device=sim_mat.device, dtype=torch.float32)
-        check(lib().gvd_cls_loss(ptr(sim_mat), ptr(sim_target), B, D1, R, K, ptr(acc), stream_ptr()), 'gvd_cls_loss')
+        check(lib().gvd_cls_loss(ptr(sim_mat), sim_mat.stride(0), sim_mat.stride(1), sim_mat.stride(2), ptr(sim_target),
+                                 B, D1, R, K, ptr(acc), stream_ptr()), 'gvd_cls_loss')
         ctx.save_for_backward(sim_mat, sim_target, acc)
         return acc[0] / acc[1]
 
@@ -486,13 +495,19 @@ class _ClsLossFn(torch.autograd.Function):
         sim_mat, tgt, acc = ctx.saved_tensors
         p = torch.gather(sim_mat, 1, tgt)
         g = torch.where((tgt > 0) & (p > 3.7200759760208555e-44), -(dloss / acc[1]) / p, torch.zeros_like(p))
+        if sim_mat.stride(1) == 1:      # class-last in memory (training path): build the gradient in that layout
+            B, D1, R = sim_mat.shape
+            gt = torch.zeros(B, R, D1, device=sim_mat.device, dtype=sim_mat.dtype)
+            gt.scatter_add_(2, tgt.transpose(1, 2), g.transpose(1, 2))
+            return gt.transpose(1, 2), None
         return torch.zeros_like(sim_mat).scatter_add_(1, tgt, g), None
 
 
 def cls_loss(sim_mat, sim_target):
-    """Region-classification loss on the HIP kernel (NaN for an empty selection, like the reference's mean over nothing)."""
+    """Region-classification loss on the HIP kernel (NaN for an empty selection, like the reference's mean over nothing).
+    sim_mat [B,D1,R] in any memory layout (the training path hands in the transposed view of the class-last tensor)."""
     require_cuda_f32(sim_mat)
-    assert sim_mat.is_contiguous() and sim_target.is_contiguous() and sim_target.dtype == torch.int64
+    assert sim_mat.dim() == 3 and sim_target.is_contiguous() and sim_target.dtype == torch.int64
     if torch.is_grad_enabled() and sim_mat.requires_grad:
         return _ClsLossFn.apply(sim_mat, sim_target)
     return _ClsLossFn.forward(_NoCtx(), sim_mat.detach(), sim_target)
@@ -506,24 +521,34 @@ class _NoCtx:
 # --------------------------------------------------------------------------------------------------
 # backward kernels of the decoder loop (used by decoder_bwd.DecoderLoopFn)
 # --------------------------------------------------------------------------------------------------
-def lstm_cell_bwd(dh, dc_next, gates, c_prev, c_new):
-    """Pointwise LSTMCell backward -> (d pre-activation gates [B,4H], dc_prev [B,H])."""
+def lstm_cell_bwd(dh, dc_next, gates, c_prev, c_new, dg_out=None):
+    """Pointwise LSTMCell backward -> (d pre-activation gates [B,4H], dc_prev [B,H]); `dg_out` ([B,4H], unit inner
+    stride) receives the gate gradients in place when given."""
     require_cuda_f32(dh, dc_next, gates, c_prev, c_new)
     B, H = c_prev.shape
     dh = dh if dh.stride(-1) == 1 else dh.contiguous()
-    dg = torch.empty(B, 4 * H, device=dh.device, dtype=torch.float32)
+    dg = torch.empty(B, 4 * H, device=dh.device, dtype=torch.float32) if dg_out is None else dg_out
+    assert dg.stride(-1) == 1 and dg.shape == (B, 4 * H)
     dcp = torch.empty(B, H, device=dh.device, dtype=torch.float32)
     check(lib().gvd_lstm_cell_bwd(ptr(dh), dh.stride(0), ptr(dc_next), dc_next.stride(0) if dc_next is not None else 0,
                                   ptr(gates), gates.stride(0), ptr(c_prev), c_prev.stride(0), ptr(c_new),
-                                  c_new.stride(0), B, H, ptr(dg), 4 * H, ptr(dcp), H, stream_ptr()),
+                                  c_new.stride(0), B, H, ptr(dg), dg.stride(0), ptr(dcp), H, stream_ptr()),
           'gvd_lstm_cell_bwd')
     return dg, dcp
 
 
-def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None):
+def attn_bwd_chunks(N, B):
+    """Number of per-chunk partial slabs gvd_attn_bwd_step writes for N rows and B samples."""
+    return lib().gvd_attn_bwd_chunks(N, B)
+
+
+def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None, de_out=None, dq_out=None, dw_part=None, dab_part=None):
     """One attention side, one step.  side: dict like attention_step's (feats, p_feats, q, w, alpha_bias
     [, att_mask, pnt_mask]).  Returns de [B,N], d_q [B,A], d_w [B,A] (per-sample partial of the alpha_net weight
-    gradient), d_alpha_bias [B]."""
+    gradient), d_alpha_bias [B].
+    In-place form for the BPTT loop: `de_out` [B,N] contiguous receives de, `dq_out` [B,A] (any strides) the summed
+    query gradient, and `dw_part` [B,NC,A] / `dab_part` [B,NC] (NC = attn_bwd_chunks(N, B), contiguous) the UNSUMMED
+    per-chunk partials — the caller reduces them once for all steps; they are then returned as such."""
     f = side['feats']
     B, N, H = f.shape
     A = side['p_feats'].shape[-1]
@@ -534,15 +559,18 @@ def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None):
         d_logits = d_logits.contiguous()
     assert alpha.stride(-1) == 1 and ctx.stride(-1) == 1
     nc = lib().gvd_attn_bwd_chunks(N, B)
-    de = torch.empty(B, N, device=f.device, dtype=torch.float32)
+    de = torch.empty(B, N, device=f.device, dtype=torch.float32) if de_out is None else de_out
     dq = torch.empty(B, nc, A, device=f.device, dtype=torch.float32)
-    dw = torch.empty(B, nc, A, device=f.device, dtype=torch.float32)
-    dab = torch.empty(B, nc, device=f.device, dtype=torch.float32)
+    dw = torch.empty(B, nc, A, device=f.device, dtype=torch.float32) if dw_part is None else dw_part
+    dab = torch.empty(B, nc, device=f.device, dtype=torch.float32) if dab_part is None else dab_part
+    assert de.is_contiguous() and dw.is_contiguous() and dab.is_contiguous()
+    assert de.shape == (B, N) and dw.shape == (B, nc, A) and dab.shape == (B, nc)
     check(lib().gvd_attn_bwd_step(C.byref(s), B, A, H, ptr(alpha), alpha.stride(0), ptr(ctx), ctx.stride(0),
                                   ptr(d_ctx), d_ctx.stride(0), ptr(d_logits),
                                   d_logits.stride(0) if d_logits is not None else 0, ptr(de), N, ptr(dq), ptr(dw),
                                   ptr(dab), stream_ptr()), 'gvd_attn_bwd_step')
-    return de, dq.sum(1), dw.sum(1), dab.sum(1)
+    dq_sum = torch.sum(dq, 1, out=dq_out) if dq_out is not None else dq.sum(1)
+    return de, dq_sum, (dw.sum(1) if dw_part is None else dw), (dab.sum(1) if dab_part is None else dab)
 
 
 def attn_bwd_pfeats(p_feats, q_all, de_all, w):
@@ -562,6 +590,32 @@ def attn_bwd_pfeats(p_feats, q_all, de_all, w):
 GRU_BARRIER = os.environ.get('GVD_GRU_BARRIER', 'counter')   # 'counter' (hand-rolled) | 'cg' (library grid sync)
 
 
+def gru_layer(gi, w_f, b_f, w_b, b_b, B, T, Hh, flags=None, barrier=None):
+    """The recurrence of one bidirectional GRU layer as ONE persistent cooperative kernel (gvd_gru_bidir_layer).
+    gi [B*T, 2*3*Hh] input projections of both directions (incl. b_ih) -> out [B,T,2*Hh].  `flags` (list) receives the
+    launch's barrier-timeout words (TopDownModel.check_kernel_status)."""
+    require_cuda_f32(gi, w_f, b_f, w_b, b_b)
+    assert gi.is_contiguous() and w_f.is_contiguous() and w_b.is_contiguous() and b_f.is_contiguous() and b_b.is_contiguous()
+    out = torch.empty(B, T, 2 * Hh, device=gi.device, dtype=torch.float32)
+    sync = None
+    if (barrier or GRU_BARRIER) == 'counter':
+        sync = torch.zeros(lib().gvd_grid_sync_words() * ((B + 255) // 256), dtype=torch.int32, device=gi.device)
+    check(lib().gvd_gru_bidir_layer(ptr(gi), ptr(w_f), ptr(b_f), ptr(w_b), ptr(b_b), ptr(out), B, T, Hh,
+                                    ptr(sync), stream_ptr()), 'gvd_gru_bidir_layer')
+    gru_layer.last_sync = sync
+    if flags is not None and sync is not None:      # word 32 of every barrier object latches a spin timeout
+        flags.append(sync.view(-1, lib().gvd_grid_sync_words())[:, 32])
+    return out
+
+
+def gru_bwd_step(dout, gi, gh, out, carry_mm, carry_z, d_gi, d_gh, B, T, Hh, t_fw, t_bw, first):
+    """One reverse step of a GRU layer's BPTT for both directions (gvd_gru_bwd_step); all tensors contiguous."""
+    require_cuda_f32(dout, gi, gh, out, carry_mm, carry_z, d_gi, d_gh)
+    assert all(t.is_contiguous() for t in (dout, gi, gh, out, carry_mm, carry_z, d_gi, d_gh))
+    check(lib().gvd_gru_bwd_step(ptr(dout), ptr(gi), ptr(gh), ptr(out), ptr(carry_mm), ptr(carry_z), ptr(d_gi), ptr(d_gh),
+                                 B, T, Hh, t_fw, t_bw, 1 if first else 0, stream_ptr()), 'gvd_gru_bwd_step')
+
+
 def gru_bidir_2layer(x, gru, barrier=None, flags=None):
     """Inference forward of the frame encoder nn.GRU(1024, 512, 2, bidirectional, batch_first) (model.py:399):
     per layer one MFMA GEMM for both directions' input projections + one persistent cooperative kernel for the
@@ -577,19 +631,11 @@ def gru_bidir_2layer(x, gru, barrier=None, flags=None):
         w_ih = torch.cat([g('weight_ih'), gr('weight_ih')], 0)
         b_ih = torch.cat([g('bias_ih'), gr('bias_ih')], 0)
         gi = gemm_nt(inp.view(B * T, -1), w_ih, b_ih)                      # [B*T, 6*Hh]
-        out = torch.empty(B, T, 2 * Hh, device=x.device, dtype=torch.float32)
-        w_f, w_b = g('weight_hh').contiguous(), gr('weight_hh').contiguous()
-        b_f, b_b = g('bias_hh').contiguous(), gr('bias_hh').contiguous()
-        sync = None
-        if (barrier or GRU_BARRIER) == 'counter':
-            sync = torch.zeros(lib().gvd_grid_sync_words() * ((B + 255) // 256), dtype=torch.int32, device=x.device)
-            syncs.append(sync)
-        check(lib().gvd_gru_bidir_layer(ptr(gi), ptr(w_f), ptr(b_f), ptr(w_b), ptr(b_b), ptr(out), B, T, Hh,
-                                        ptr(sync), stream_ptr()), 'gvd_gru_bidir_layer')
-        inp = out
+        inp = gru_layer(gi, g('weight_hh').contiguous(), g('bias_hh').contiguous(), gr('weight_hh').contiguous(),
+                        gr('bias_hh').contiguous(), B, T, Hh, flags=flags, barrier=barrier)
+        if gru_layer.last_sync is not None:
+            syncs.append(gru_layer.last_sync)
     gru_bidir_2layer.last_sync = syncs     # tests read the timeout flags (sync_timed_out) after a device sync
-    if flags is not None:                  # word 32 of every barrier object latches a spin timeout
-        flags.extend(s.view(-1, lib().gvd_grid_sync_words())[:, 32] for s in syncs)
     return inp
 
 
@@ -754,10 +800,60 @@ def region_feature_rows(g_pool, loc, sim_logits_t, pnt_mask, ln_eps=1e-5, pad_to
     out = torch.empty(B, R, K, device=g_pool.device, dtype=torch.float32)
     sim = torch.empty(B, R, n_cls, device=g_pool.device, dtype=torch.float32)
     mask_ptr = C.c_void_p(pnt_mask.data_ptr() + 1)              # skip the legacy pad column (main.py:227)
-    check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(sim_logits_t), n_cls, mask_ptr, R, R + 1,
+    check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(sim_logits_t), n_cls, n_cls, mask_ptr, R, R + 1,
                                         ptr(out), K, ptr(sim), B * R, None, G, ln_eps, stream_ptr()),
           'gvd_region_feature_rows')
     return out, sim
+
+
+class _RegionRowsFn(torch.autograd.Function):
+    """Training form of `region_feature_rows`: forward = the same row kernel (logits rows `n_cls_ld` apart: the class
+    axis is zero-padded to a 32-multiple so that the backward products of the similarity GEMM run on the MFMA kernel),
+    backward = gvd_region_feature_rows_bwd (three layer-norm backwards + the class-softmax backward in one pass, taking
+    the direct gradient of the class distribution from the region-classification loss as well)."""
+
+    @staticmethod
+    def forward(ctx, g_pool, loc, logits_pad, pnt_mask, n_cls, pad_to, ln_eps):
+        B, R, G = g_pool.shape
+        n_loc, ld = loc.shape[-1], logits_pad.shape[-1]
+        K = (G + n_loc + n_cls + pad_to - 1) // pad_to * pad_to
+        out = torch.empty(B, R, K, device=g_pool.device, dtype=torch.float32)
+        sim = torch.empty(B, R, n_cls, device=g_pool.device, dtype=torch.float32)
+        mask_ptr = C.c_void_p(pnt_mask.data_ptr() + 1)
+        check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(logits_pad), n_cls, ld, mask_ptr, R, R + 1,
+                                            ptr(out), K, ptr(sim), B * R, None, G, ln_eps, stream_ptr()),
+              'gvd_region_feature_rows(train)')
+        ctx.save_for_backward(g_pool, loc, sim, pnt_mask)
+        ctx.dims = (n_cls, ld, ln_eps)
+        return out, sim
+
+    @staticmethod
+    def backward(ctx, d_out, d_sim):
+        g_pool, loc, sim, pnt_mask = ctx.saved_tensors
+        n_cls, ld, ln_eps = ctx.dims
+        B, R, G = g_pool.shape
+        n_loc = loc.shape[-1]
+        d_out = d_out.contiguous()
+        d_sim = None if d_sim is None else d_sim.contiguous()
+        d_g = torch.empty_like(g_pool)
+        d_loc = torch.empty_like(loc)
+        d_logits = torch.empty(B, R, ld, device=g_pool.device, dtype=torch.float32)
+        mask_ptr = C.c_void_p(pnt_mask.data_ptr() + 1)
+        check(lib().gvd_region_feature_rows_bwd(ptr(g_pool), ptr(loc), n_loc, ptr(sim), n_cls, mask_ptr, R, R + 1,
+                                                ptr(d_out), d_out.shape[-1], ptr(d_sim), ptr(d_g), ptr(d_loc),
+                                                ptr(d_logits), ld, B * R, G, ln_eps, stream_ptr()),
+              'gvd_region_feature_rows_bwd')
+        return d_g, d_loc, d_logits, None, None, None, None
+
+
+def region_feature_rows_train(g_pool, loc, logits_pad, pnt_mask, n_cls, pad_to=32, ln_eps=1e-5):
+    """Differentiable `region_feature_rows` (see _RegionRowsFn).  logits_pad [B,R,ld >= n_cls] class-last similarity
+    logits (columns >= n_cls ignored; they receive zero gradient).  Returns pool_in [B,R,K], sim_t [B,R,n_cls]."""
+    require_cuda_f32(g_pool, loc, logits_pad)
+    B, R, _ = g_pool.shape
+    assert pnt_mask.dtype == torch.uint8 and pnt_mask.is_contiguous() and pnt_mask.shape == (B, R + 1)
+    return _RegionRowsFn.apply(g_pool.contiguous(), loc.contiguous(), logits_pad.contiguous(), pnt_mask, n_cls, pad_to,
+                               ln_eps)
 
 
 def region_feature_rows_compact(g_pool, loc, sim_logits, row_mask, rows_dev, pad_to=32, ln_eps=1e-5):
@@ -771,7 +867,7 @@ def region_feature_rows_compact(g_pool, loc, sim_logits, row_mask, rows_dev, pad
     out = torch.empty(M, K, device=g_pool.device, dtype=torch.float32)
     sim = torch.empty(M, n_cls, device=g_pool.device, dtype=torch.float32)
     # mask addressing row_mask[(row / rows_per_batch) * ld + row % rows_per_batch] with one "batch" of M rows
-    check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(sim_logits), n_cls, ptr(row_mask), M, 0,
+    check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(sim_logits), n_cls, n_cls, ptr(row_mask), M, 0,
                                         ptr(out), K, ptr(sim), M, ptr(rows_dev), G, ln_eps, stream_ptr()),
           'gvd_region_feature_rows(compact)')
     return out, sim

@@ -60,5 +60,9 @@ class Trainer:
         loss.backward()
         self.reducer.finish()
         self.last_grad_norm = float(nn.utils.clip_grad_norm_(self.model.parameters(), self.opt.grad_clip))
+        if hasattr(self.model, 'check_kernel_status'):
+            # the GRU of the frame encoder runs as a persistent cooperative kernel in training too: a grid-barrier timeout
+            # (workgroups not co-resident) must not reach the optimizer silently
+            self.model.check_kernel_status()
         self.optimizer.step()
         return torch.cat([l.detach() for l in losses])

@@ -49,7 +49,7 @@ def forward_train(model, segs_feat, input_seq, gt_seq, ppls, gt_boxes, mask_boxe
     if not model.test_mode:
         if not eval_obj_ground:
             # model.py:348-350 (BCE against ones over sim_target > 0): fused gather + log + masked mean (T2)
-            cls_loss = ops.cls_loss(sim_mat.contiguous(), sim_target)
+            cls_loss = ops.cls_loss(sim_mat, sim_target)
         else:
             tgt = torch.masked_select(sim_target, sim_mask)
             prd = torch.masked_select(sim_mat.max(dim=1)[1].unsqueeze(1).expand_as(sim_target), sim_mask)
@@ -84,4 +84,6 @@ def forward_train(model, segs_feat, input_seq, gt_seq, ppls, gt_boxes, mask_boxe
     lm_loss = -(logp_t * tmask.to(logp_t.dtype)).sum() / tmask.sum()
     att2_loss = ops.masked_lsm(att2_weights, roi_labels)
     ground_loss = ops.masked_lsm(ground, roi_labels)
+    if len(model._flags()) > 4096:      # a caller that never checks must not grow the list without bound
+        model.check_kernel_status()
     return lm_loss.unsqueeze(0), att2_loss.unsqueeze(0), ground_loss.unsqueeze(0), cls_loss.unsqueeze(0)

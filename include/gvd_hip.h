@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 5
+#define GVD_ABI_VERSION 6
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -187,14 +187,25 @@ int gvd_enc_softmax_dropout_bwd(float* dP, const float* Pd, const float* Y, int6
 
 /* Per proposal row (model.py:336-364): p = softmax over the n_cls similarity logits (all -1e8 when the row is
  * masked: row_mask[(row / mask_rows_per_batch) * mask_ld + row % mask_rows_per_batch] != 0), written to sim_out
- * [rows,n_cls] (optional); out[row] = [layer_norm(g_pool row, G=2048) | layer_norm(loc row, n_loc) |
+ * [rows,n_cls] (optional; logits rows are logits_ld >= n_cls apart); out[row] = [layer_norm(g_pool row, G=2048) | layer_norm(loc row, n_loc) |
  * layer_norm(p, n_cls) | zeros] with out leading dimension out_ld >= G + n_loc + n_cls (the zero pad makes the row a
  * 16-byte-aligned, 32-multiple K operand for the pool_embed GEMM, model.py:384).  F.layer_norm semantics (biased
  * variance, eps inside the sqrt, no affine). */
 int gvd_region_feature_rows(const float* g_pool, const float* loc, int n_loc, const float* sim_logits, int n_cls,
-                            const uint8_t* row_mask, int64_t mask_rows_per_batch, int64_t mask_ld, float* out,
-                            int64_t out_ld, float* sim_out, int64_t rows, const int* rows_dev, int G, float ln_eps,
-                            gvd_stream_t stream);
+                            int64_t logits_ld, const uint8_t* row_mask, int64_t mask_rows_per_batch, int64_t mask_ld,
+                            float* out, int64_t out_ld, float* sim_out, int64_t rows, const int* rows_dev, int G,
+                            float ln_eps, gvd_stream_t stream);
+
+/* Backward of gvd_region_feature_rows for the training path (autograd of model.py:336-364): from d_out [rows,d_out_ld]
+ * (gradient of the concatenated row; d_out_ld a multiple of 4, 16-byte aligned) and the optional direct gradient d_sim
+ * [rows,n_cls] of the class distribution (the region-classification loss reads it), with sim = the distribution the
+ * forward wrote: d_gpool [rows,G], d_loc [rows,n_loc], d_logits [rows,d_logits_ld] (columns >= n_cls zeroed; masked rows
+ * zero: their logits were the constant -1e8).  Layer-norm statistics are recomputed from the inputs. */
+int gvd_region_feature_rows_bwd(const float* g_pool, const float* loc, int n_loc, const float* sim, int n_cls,
+                                const uint8_t* row_mask, int64_t mask_rows_per_batch, int64_t mask_ld,
+                                const float* d_out, int64_t d_out_ld, const float* d_sim, float* d_gpool, float* d_loc,
+                                float* d_logits, int64_t d_logits_ld, int64_t rows, int G, float ln_eps,
+                                gvd_stream_t stream);
 
 /* Fused multi-head self-attention of the obj_interact encoder (transformer.py:90-123; heads = Tensor.chunk of the
  * model width): o[b,:,c0_h:c0_h+w_h] = softmax(q_h k_h^T) v_h for every head h, flash-style in fp32 on the matrix
@@ -251,6 +262,15 @@ int gvd_grid_sync_words(void);
 int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const float* b_hh_fw, const float* w_hh_bw,
                         const float* b_hh_bw, float* out, int B, int T, int Hh, void* sync_ws,
                         gvd_stream_t stream);
+
+/* One reverse step of a layer's BPTT, both directions at once (training backward of nn.GRU, model.py:150-154,399).
+ * Direction 0 is at time t_fw (walking T-1..0), direction 1 at t_bw (walking 0..T-1).  gi / gh / d_gi / d_gh are
+ * [B,T,2,3*Hh] (gh = h_{t-1} W_hh^T + b_hh for every step, formed by one GEMM per direction from the layer output),
+ * dout / out [B,T,2*Hh], carry_mm / carry_z [2,B,Hh]: carry_mm = d_gh[previous step] W_hh (caller's GEMM), carry_z is
+ * read and rewritten (dh z); first != 0 ignores both carries.  Gate order r,z,n. */
+int gvd_gru_bwd_step(const float* dout, const float* gi, const float* gh, const float* out, const float* carry_mm,
+                     float* carry_z, float* d_gi, float* d_gh, int B, int T, int Hh, int t_fw, int t_bw, int first,
+                     gvd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward of the teacher-forced decoder loop (hand-scheduled BPTT; replaces autograd's per-op backward of
@@ -378,10 +398,11 @@ int gvd_masked_lsm_loss(const float* x, int64_t ldx, const float* label, int64_t
                         float* acc, float* row_lse, gvd_stream_t stream);
 
 /* Region-classification loss (model.py:345-350, T2): acc[0] = sum over (b,k,r) with sim_target > 0 of
- * -max(log sim_mat[b, sim_target[b,k,r], r], -100), acc[1] = their count; sim_mat f32 [B,D1,R] (class softmax),
+ * -max(log sim_mat[b, sim_target[b,k,r], r], -100), acc[1] = their count; sim_mat f32 [B,D1,R] (class softmax) addressed
+ * through its three element strides (the training path keeps it class-last in memory),
  * sim_target i64 [B,K,R]; acc holds 2 + 2*ceil(B*K*R/256) floats (ordered partials, no atomics). */
-int gvd_cls_loss(const float* sim_mat, const int64_t* sim_target, int B, int D1, int R, int K, float* acc,
-                 gvd_stream_t stream);
+int gvd_cls_loss(const float* sim_mat, int64_t stride_b, int64_t stride_cls, int64_t stride_r, const int64_t* sim_target,
+                 int B, int D1, int R, int K, float* acc, gvd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -200,3 +200,114 @@ def test_bench_under_torchrun_single_rank(mode):
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     j = json.loads(line)
     assert j['n_gpus'] == 1 and j['value'] > 0 and j['steps'] == 2
+
+
+@pytest.mark.parametrize('B,R', [(2, 40), (3, 100)])
+def test_region_feature_rows_train_forward_and_backward(B, R):
+    """ops.region_feature_rows_train (fused row kernel forward + fused backward) against autograd through the ATen form
+    of model.py:336-364 (masked class softmax, three F.layer_norm, concat), incl. the direct gradient of the class
+    distribution and a fully masked sample."""
+    import torch.nn.functional as F
+    g = _g(7 + R)
+    D1, nl, cpad = 433, 300, 15
+    g_pool = torch.relu(torch.randn(B, R, 2048, generator=g)).cuda().requires_grad_(True)
+    loc = torch.relu(torch.randn(B, R, nl, generator=g)).cuda().requires_grad_(True)
+    logits = (torch.randn(B, R, D1 + cpad, generator=g) * 2).cuda().requires_grad_(True)
+    pm = (torch.rand(B, R + 1, generator=g) < 0.3).to(torch.uint8)
+    pm[:, 0] = 0
+    pm[0, 1:] = 1
+    pm = pm.cuda()
+    Gout = torch.randn(B, R, 2784, generator=g).cuda()
+    Gsim = torch.randn(B, R, D1, generator=g).cuda()
+    # reference
+    lm = logits[:, :, :D1].masked_fill(pm[:, 1:].bool().unsqueeze(-1), -1e8)
+    p = F.softmax(lm, dim=-1)
+    ref = torch.cat([F.layer_norm(g_pool, [2048]), F.layer_norm(loc, [nl]), F.layer_norm(p, [D1])], -1)
+    ((ref * Gout[:, :, :2781]).sum() + (p * Gsim).sum()).backward()
+    rg = [t.grad.clone() for t in (g_pool, loc, logits)]
+    for t in (g_pool, loc, logits):
+        t.grad = None
+    out, sim = ops.region_feature_rows_train(g_pool, loc, logits, pm, D1, pad_to=32)
+    assert out.shape == (B, R, 2784) and sim.shape == (B, R, D1)
+    np.testing.assert_allclose(out[:, :, :2781].detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=2e-5)
+    assert float(out[:, :, 2781:].abs().max()) == 0.0
+    np.testing.assert_allclose(sim.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=1e-5, atol=1e-7)
+    ((out * Gout).sum() + (sim * Gsim).sum()).backward()
+    for t, r, tol in zip((g_pool, loc, logits), rg, (2e-4, 2e-4, 2e-4)):
+        a, b = t.grad.cpu().numpy(), r.cpu().numpy()
+        assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (np.abs(a - b).max(), np.abs(b).max())
+    assert float(logits.grad[:, :, D1:].abs().max()) == 0.0 and float(logits.grad[0].abs().max()) == 0.0
+
+
+def test_cls_loss_class_last_layout():
+    """gvd_cls_loss through element strides: the transposed view of a class-last tensor gives the same loss and the same
+    gradient as the contiguous [B,D1,R] tensor."""
+    g = _g(11)
+    B, D1, R, K = 3, 433, 200, 5
+    p = torch.softmax(torch.randn(B, D1, R, generator=g), 1).cuda()
+    tgt = torch.randint(0, D1, (B, K, R), generator=g)
+    tgt[torch.rand(B, K, R, generator=g) < 0.7] = 0
+    tgt = tgt.cuda()
+    a = p.clone().requires_grad_(True)
+    la = ops.cls_loss(a, tgt)
+    la.backward()
+    bt = p.transpose(1, 2).contiguous().requires_grad_(True)      # class-last in memory
+    lb = ops.cls_loss(bt.transpose(1, 2), tgt)
+    lb.backward()
+    assert float(la) == float(lb)
+    assert torch.equal(bt.grad.transpose(1, 2), a.grad)
+
+
+@pytest.mark.parametrize('B,T', [(5, 10), (64, 10), (3, 1), (40, 7)])
+def test_gru_train_matches_library_gru(B, T):
+    """gru_fn (persistent-kernel forward + hand-scheduled BPTT with gvd_gru_bwd_step) against autograd through the
+    native torch GRU on the GPU (eval mode: no inter-layer dropout)."""
+    from gvd_amd import gru_fn
+    torch.manual_seed(3)
+    gru = torch.nn.GRU(1024, 512, 2, dropout=0.2, bidirectional=True, batch_first=True).cuda().eval()
+    x = torch.randn(B, T, 1024, device='cuda')
+    G = torch.randn(B, T, 1024, device='cuda')
+    xr = x.clone().requires_grad_(True)
+    with torch.backends.cudnn.flags(enabled=False):
+        yr = gru(xr)[0]
+        (yr * G).sum().backward()
+    ref = {n: p.grad.clone() for n, p in gru.named_parameters()}
+    gru.zero_grad(set_to_none=True)
+    xm = x.clone().requires_grad_(True)
+    flags = []
+    ym = gru_fn.gru_bidir_2layer_train(xm, gru, flags=flags)
+    np.testing.assert_allclose(ym.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-4, atol=2e-5)
+    (ym * G).sum().backward()
+    assert all(int(f.sum()) == 0 for f in flags)
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-12))
+    assert rel(xm.grad, xr.grad) < 1e-4
+    for n, p in gru.named_parameters():
+        assert rel(p.grad, ref[n]) < 1e-4, (n, rel(p.grad, ref[n]))
+
+
+def test_train_step_fused_paths_equal_library_paths_in_eval_mode(monkeypatch):
+    """Eval-mode 'MLE' losses and gradients with the fused training kernels (P5 row kernel, GRU BPTT) equal those of the
+    library paths they replace (GVD_P5_FUSED_TRAIN=0, GVD_GRU_TRAIN=0)."""
+    opt = gvd_amd.opts.default_opt(vocab_size=300, t_attn_size=6)
+    sd = synth.init_state_dict(opt, seed=1, profile='trained_like')
+    inp = synth.trim_to_batch(synth.make_inputs(opt, 3, seed=5, train=True))
+    a = synth.as_args(inp, torch.device('cuda'))
+    res = {}
+    for fused in ('1', '0'):
+        monkeypatch.setenv('GVD_P5_FUSED_TRAIN', fused)
+        monkeypatch.setenv('GVD_GRU_TRAIN', fused)
+        model = att_model.TopDownModel(opt)
+        model.load_state_dict(sd)
+        model = model.cuda().eval()
+        losses = model(*a, 'MLE')
+        train.combine_losses(losses, opt).backward()
+        res[fused] = (torch.cat([l.detach() for l in losses]).cpu(),
+                      {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None})
+    np.testing.assert_allclose(res['1'][0].numpy(), res['0'][0].numpy(), rtol=2e-5, atol=1e-6)
+    assert res['1'][1].keys() == res['0'][1].keys()
+    gmax = max(float(v.norm()) for v in res['0'][1].values())
+    for n, gsel in res['1'][1].items():
+        ref = res['0'][1][n]
+        # gradients that are mathematically zero (the temporal alpha_net bias: softmax is shift invariant) are rounding noise
+        err = float((gsel - ref).norm() / ref.norm().clamp_min(1e-6 * gmax))
+        assert err < 2e-3, (n, err)

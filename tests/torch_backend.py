@@ -18,7 +18,7 @@ def gemm_nt(A, W, bias=None, act=0, out=None):
     return y
 
 
-def lstm_cell(xs, ws, h_prev, w_hh, b_ih, b_hh, c_prev, rowbias=None, gates_out=None):
+def lstm_cell(xs, ws, h_prev, w_hh, b_ih, b_hh, c_prev, rowbias=None, gates_out=None, h_out=None, c_out=None):
     g = h_prev @ w_hh.t()
     for x, w in zip(xs, ws):
         g = g + x @ w.t()
@@ -31,6 +31,10 @@ def lstm_cell(xs, ws, h_prev, w_hh, b_ih, b_hh, c_prev, rowbias=None, gates_out=
     h = o * torch.tanh(c)
     if gates_out is not None:
         gates_out.copy_(torch.cat([i, f, gg, o], 1))
+    if h_out is not None:
+        h = h_out.copy_(h)
+    if c_out is not None:
+        c = c_out.copy_(c)
     return h, c
 
 
@@ -47,23 +51,36 @@ def _one_side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, lo
     return torch.bmm(a.unsqueeze(1), feats).squeeze(1)
 
 
-def attention_step(region, temporal, want_separate=False):
+def attention_step(region, temporal, want_separate=False, out=None, cr_out=None, ct_out=None):
     cr = _one_side(**region)
     ct = _one_side(**temporal) if temporal is not None else torch.zeros_like(cr)
-    return (cr + ct, cr, ct) if want_separate else cr + ct
+    s = cr + ct
+    if out is not None:
+        s = out.copy_(s)
+    if cr_out is not None:
+        cr = cr_out.copy_(cr)
+    if ct_out is not None:
+        ct = ct_out.copy_(ct)
+    return (s, cr, ct) if want_separate else s
 
 
-def lstm_cell_bwd(dh, dc_next, gates, c_prev, c_new):
+def lstm_cell_bwd(dh, dc_next, gates, c_prev, c_new, dg_out=None):
     i, f, g, o = gates.chunk(4, 1)
     tc = torch.tanh(c_new)
     dc = dh * o * (1 - tc * tc)
     if dc_next is not None:
         dc = dc + dc_next
     dg = torch.cat([dc * g * i * (1 - i), dc * c_prev * f * (1 - f), dc * i * (1 - g * g), dh * tc * o * (1 - o)], 1)
+    if dg_out is not None:
+        dg = dg_out.copy_(dg)
     return dg, dc * f
 
 
-def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None):
+def attn_bwd_chunks(N, B):
+    return 3        # the HIP kernel's per-chunk partial slabs; any count checks the caller's reduction
+
+
+def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None, de_out=None, dq_out=None, dw_part=None, dab_part=None):
     feats, p_feats, q, w = side['feats'], side['p_feats'], side['q'], side['w']
     am, pm = side.get('att_mask'), side.get('pnt_mask')
     da = torch.bmm(feats, d_ctx.unsqueeze(2)).squeeze(2)
@@ -81,7 +98,17 @@ def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None):
     t = torch.tanh(p_feats + q.unsqueeze(1))
     dq = ((de.unsqueeze(2) * w) * (1 - t * t)).sum(1)
     dw = (de.unsqueeze(2) * t).sum(1)
-    return de, dq, dw, de.sum(1)
+    dab = de.sum(1)
+    if de_out is not None:
+        de = de_out.copy_(de)
+    if dq_out is not None:
+        dq = dq_out.copy_(dq)
+    if dw_part is not None:         # partial slabs: split the value unevenly over the chunks
+        nc = dw_part.shape[1]
+        wts = torch.arange(1, nc + 1, dtype=dw.dtype) / (nc * (nc + 1) / 2)
+        dw = dw_part.copy_(dw.unsqueeze(1) * wts.view(1, nc, 1))
+        dab = dab_part.copy_(dab.unsqueeze(1) * wts.view(1, nc))
+    return de, dq, dw, dab
 
 
 def attn_bwd_pfeats(p_feats, q_all, de_all, w):
@@ -90,3 +117,40 @@ def attn_bwd_pfeats(p_feats, q_all, de_all, w):
         th = torch.tanh(p_feats + q_all[t].unsqueeze(1))
         out += de_all[t].unsqueeze(2) * w * (1 - th * th)
     return out
+
+
+def gru_layer(gi, w_f, b_f, w_b, b_b, B, T, Hh, flags=None, barrier=None):
+    """Time loop of one bidirectional GRU layer; gi [B*T, 2*3*Hh] -> out [B,T,2*Hh] (gate order r,z,n)."""
+    gi = gi.view(B, T, 2, 3 * Hh)
+    out = torch.zeros(B, T, 2 * Hh, dtype=gi.dtype)
+    for d, (w, b) in enumerate(((w_f, b_f), (w_b, b_b))):
+        h = torch.zeros(B, Hh, dtype=gi.dtype)
+        for t in (range(T) if d == 0 else range(T - 1, -1, -1)):
+            gh = h @ w.t() + b
+            g = gi[:, t, d]
+            r = torch.sigmoid(g[:, :Hh] + gh[:, :Hh])
+            z = torch.sigmoid(g[:, Hh:2 * Hh] + gh[:, Hh:2 * Hh])
+            n = torch.tanh(g[:, 2 * Hh:] + r * gh[:, 2 * Hh:])
+            h = (1 - z) * n + z * h
+            out[:, t, d * Hh:(d + 1) * Hh] = h
+    return out
+
+
+def gru_bwd_step(dout, gi, gh, out, carry_mm, carry_z, d_gi, d_gh, B, T, Hh, t_fw, t_bw, first):
+    gi, gh = gi.view(B, T, 2, 3 * Hh), gh.view(B, T, 2, 3 * Hh)
+    for d, t in ((0, t_fw), (1, t_bw)):
+        tp = t + 1 if d else t - 1
+        g, h = gi[:, t, d], gh[:, t, d]
+        r = torch.sigmoid(g[:, :Hh] + h[:, :Hh])
+        z = torch.sigmoid(g[:, Hh:2 * Hh] + h[:, Hh:2 * Hh])
+        n = torch.tanh(g[:, 2 * Hh:] + r * h[:, 2 * Hh:])
+        hp = out[:, tp, d * Hh:(d + 1) * Hh] if 0 <= tp < T else torch.zeros(B, Hh, dtype=gi.dtype)
+        dh = dout[:, t, d * Hh:(d + 1) * Hh]
+        if not first:
+            dh = dh + carry_mm[d] + carry_z[d]
+        dn = dh * (1 - z) * (1 - n * n)
+        dz = dh * (hp - n) * z * (1 - z)
+        dr = dn * h[:, 2 * Hh:] * r * (1 - r)
+        d_gi[:, t, d] = torch.cat([dr, dz, dn], 1)
+        d_gh[:, t, d] = torch.cat([dr, dz, dn * r], 1)
+        carry_z[d] = dh * z

@@ -2,6 +2,7 @@
 
   python tools/parse_rocprof.py stats <dir> <out.md> [title]     # --kernel-trace --stats run
   python tools/parse_rocprof.py pmc <dir> <kernel-substr> <out.json> <COUNTER> [<COUNTER>...]
+  python tools/parse_rocprof.py trace <dir> <out.md> [title]     # per (kernel, grid) groups + idle gaps of the timeline
 """
 import csv
 import glob
@@ -56,8 +57,55 @@ def pmc(d, substr, out, counters):
     print(json.dumps(res))
 
 
+def _short(name):
+    name = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    return name.split('(')[0][:70]
+
+
+def trace(d, out, title):
+    """Per (kernel, grid, workgroup) groups of a --kernel-trace run, and how much of the span the GPU sat idle between
+    dispatches (a launch-bound stretch shows up as gap time)."""
+    ev = []
+    for f in find(d, '*kernel_trace.csv'):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                g = tuple(int(r.get(k, 0) or 0) for k in ('Grid_Size_X', 'Grid_Size_Y', 'Grid_Size_Z'))
+                w = int(r.get('Workgroup_Size_X', 0) or 0)
+                ev.append((float(r['Start_Timestamp']), float(r['End_Timestamp']), _short(r.get('Kernel_Name') or r.get('Name')), g, w))
+    ev.sort()
+    if not ev:
+        print('no kernel trace under', d)
+        return
+    agg = defaultdict(lambda: [0, 0.0])
+    busy, gaps, gap_n, last_end = 0.0, 0.0, 0, ev[0][0]
+    small_n, small_t = 0, 0.0
+    for s0, e0, k, g, w in ev:
+        agg[(k, g, w)][0] += 1
+        agg[(k, g, w)][1] += e0 - s0
+        busy += e0 - s0
+        if e0 - s0 < 10e3:
+            small_n += 1
+            small_t += e0 - s0
+        if s0 > last_end:
+            gaps += s0 - last_end
+            gap_n += 1
+        last_end = max(last_end, e0)
+    span = last_end - ev[0][0]
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    with open(out, 'w') as fh:
+        fh.write('# %s\n\n%d dispatches; span %.3f ms; kernel time %.3f ms; idle between dispatches %.3f ms (%d gaps); '
+                 'dispatches under 10 us: %d = %.3f ms\n\n' % (title, len(ev), span / 1e6, busy / 1e6, gaps / 1e6, gap_n,
+                                                                small_n, small_t / 1e6))
+        fh.write('| kernel | grid (threads) | wg | calls | total ms | avg us |\n|---|---|---|---|---|---|\n')
+        for (k, g, w), (n, t) in rows[:70]:
+            fh.write('| `%s` | %s | %d | %d | %.3f | %.2f |\n' % (k, 'x'.join(str(x) for x in g), w, n, t / 1e6, t / n / 1e3))
+    print(open(out).read()[:6000])
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'stats':
+    if sys.argv[1] == 'trace':
+        trace(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else 'kernel trace')
+    elif sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else 'kernel stats')
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5:])

@@ -21,6 +21,8 @@ struct KParams {
   const int* m_dev;      // when set: the row count is read on the device (<= M; tiles past it exit)
   const int* a_rmap;     // when set (pipelined kernel, one segment): output row m reads row a_rmap[m] of A
   int a_t, w_t;          // operand is K-strided: A given as [K, M] (lda >= M), W as [K, N] (ldw >= N)
+  int binner;            // two-level batch: b = outer * binner + inner (0 / 1 = flat)
+  int64_t abs2, wbs2, cbs2;   // inner strides of A / W (every segment) / C
   // LSTM epilogue
   const float* c_prev; int64_t ldcp;
   float* h_out; int64_t ldh;
@@ -31,12 +33,21 @@ struct KParams {
 };
 
 
+// Base offset of batch entry bz: flat (bz * s1) or two-level (outer * s1 + inner * s2).
+__device__ __forceinline__ int64_t gvd_boff(const KParams& p, int bz, int64_t s1, int64_t s2) {
+  if (p.binner > 1) {
+    const int bo = bz / p.binner;
+    return (int64_t)bo * s1 + (int64_t)(bz - bo * p.binner) * s2;
+  }
+  return (int64_t)bz * s1;
+}
+
 // Plain epilogue of a wave's TM x TN grid of 32x32 accumulator tiles (bias / per-row bias / 2-D bias / ReLU / masked
 // fill), straight from the MFMA layout: lane (r = l&31, half = l>>5) holds column r, rows (e&3) + 8(e>>2) + 4 half.
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_plain(const KParams& p, int M, const f32x16 (&acc)[TM][TN], int bz, int mw0,
                                                     int nw0, int r, int half) {
-  float* Cb = p.C + (int64_t)bz * p.cbs;
+  float* Cb = p.C + gvd_boff(p, bz, p.cbs, p.cbs2);
   const float* rb = p.rowbias ? p.rowbias + (int64_t)bz * p.rowbias_bs : nullptr;
   const float* mb = p.mbias ? p.mbias + (int64_t)bz * p.mbias_bs : nullptr;
   const uint8_t* mk = p.mask ? p.mask + (int64_t)bz * p.mask_bs : nullptr;

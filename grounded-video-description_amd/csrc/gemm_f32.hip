@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const KParams p) {
   auto load_tile = [&](int kt) {
     int s = 0, k0 = kt * BK;
     while (s + 1 < p.nseg && k0 >= p.K[s]) { k0 -= p.K[s]; ++s; }
-    const float* Ab = p.A[s] + (int64_t)bz * p.abs_[s] + k0 + kq4;
-    const float* Wb = p.W[s] + (int64_t)bz * p.wbs[s] + k0 + kq4;
+    const float* Ab = p.A[s] + gvd_boff(p, bz, p.abs_[s], p.abs2) + k0 + kq4;
+    const float* Wb = p.W[s] + gvd_boff(p, bz, p.wbs[s], p.wbs2) + k0 + kq4;
     const int64_t lda = p.lda[s], ldw = p.ldw[s];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -237,6 +237,12 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
   p.C = a->C; p.ldc = a->ldc; p.cbs = a->c_batch_stride;
   p.M = a->M; p.N = a->N; p.act = a->act; p.m_dev = a->m_dev;
   p.a_t = a->a_kstrided; p.w_t = a->w_kstrided;
+  if (a->batch_inner > 1) {
+    if (a->batch % a->batch_inner || a->mbias || a->rowbias || a->mask || a->a_row_map || (a->a_inner_stride % 4) ||
+        (a->w_inner_stride % 4) || (a->c_inner_stride % 4))
+      return GVD_EINVAL;
+    p.binner = a->batch_inner; p.abs2 = a->a_inner_stride; p.wbs2 = a->w_inner_stride; p.cbs2 = a->c_inner_stride;
+  }
   hipStream_t st = gvd_s(stream);
   if (a->a_row_map) {
     // fused row gather: pipelined kernel only, one plain segment, row offsets within the 32-bit buffer offset

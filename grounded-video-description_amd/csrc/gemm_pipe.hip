@@ -92,20 +92,20 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   auto seg_setup = [&](int s) {
     const unsigned lda4 = (unsigned)p.lda[s] * 4u, ldw4 = (unsigned)p.ldw[s] * 4u;
     if (AT) {
-      pa_t = p.A[s] + (int64_t)bz * p.abs_[s] + m0;
+      pa_t = p.A[s] + gvd_boff(p, bz, p.abs_[s], p.abs2) + m0;
 #pragma unroll
       for (int i = 0; i < NLD; ++i) sg.voa[i] = (unsigned)(tk + 8 * i) * lda4 + 4u * (unsigned)acol;
     } else {
-      sg.ra = gvd_rsrc(p.A[s] + (int64_t)bz * p.abs_[s] + (gathered ? 0 : (int64_t)m0 * p.lda[s]));
+      sg.ra = gvd_rsrc(p.A[s] + gvd_boff(p, bz, p.abs_[s], p.abs2) + (gathered ? 0 : (int64_t)m0 * p.lda[s]));
 #pragma unroll
       for (int i = 0; i < NLD; ++i) sg.voa[i] = (unsigned)arow[i] * lda4 + 16u * kq;
     }
     if (BT) {
-      pw_t = p.W[s] + (int64_t)bz * p.wbs[s] + n0;
+      pw_t = p.W[s] + gvd_boff(p, bz, p.wbs[s], p.wbs2) + n0;
 #pragma unroll
       for (int i = 0; i < NLD; ++i) sg.vow[i] = (unsigned)(tk + 8 * i) * ldw4 + 4u * (unsigned)wcol;
     } else {
-      sg.rw = gvd_rsrc(p.W[s] + (int64_t)bz * p.wbs[s] + (int64_t)n0 * p.ldw[s]);
+      sg.rw = gvd_rsrc(p.W[s] + gvd_boff(p, bz, p.wbs[s], p.wbs2) + (int64_t)n0 * p.ldw[s]);
 #pragma unroll
       for (int i = 0; i < NLD; ++i) sg.vow[i] = (unsigned)wrow[i] * ldw4 + 16u * kq;
     }
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
     if (p.nbias) nb = *reinterpret_cast<const f32x4*>(p.nbias + gn);
     if (p.nbias2) nb += *reinterpret_cast<const f32x4*>(p.nbias2 + gn);
   }
-  float* Cb = p.C + (int64_t)bz * p.cbs;
+  float* Cb = p.C + gvd_boff(p, bz, p.cbs, p.cbs2);
   const bool relu = p.act == 1;
   // (DS operations of one wave execute in order: its reads below see its own writes above)
 #pragma unroll

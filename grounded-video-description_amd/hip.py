@@ -35,7 +35,9 @@ class GemmArgs(C.Structure):
                 ('C', c_f32p), ('ldc', C.c_int64), ('c_batch_stride', C.c_int64),
                 ('M', C.c_int), ('N', C.c_int), ('batch', C.c_int), ('act', C.c_int), ('m_dev', C.c_void_p),
                 ('a_row_map', C.c_void_p), ('a_src_rows', C.c_int64),
-                ('a_kstrided', C.c_int), ('w_kstrided', C.c_int)]
+                ('a_kstrided', C.c_int), ('w_kstrided', C.c_int),
+                ('batch_inner', C.c_int), ('a_inner_stride', C.c_int64), ('w_inner_stride', C.c_int64),
+                ('c_inner_stride', C.c_int64)]
 
 
 class LstmArgs(C.Structure):

@@ -705,15 +705,32 @@ def add_layernorm(x, y, gamma, beta, eps=1e-6):
 TRAIN_HEAD_PAD = 192      # training attention core: heads zero-padded to a multiple of the GEMM's 32-deep k tile
 
 
-def _bgemm(A, a_off, lda, a_bs, W, w_off, ldw, w_bs, K, Cout, c_off, ldc, c_bs, M, N, batch, a_t=0, w_t=0, what='bgemm'):
-    """One batched launch of the MFMA GEMM on sub-blocks of larger tensors (element offsets into A / W / Cout)."""
+def _bgemm(A, a_off, lda, a_bs, W, w_off, ldw, w_bs, K, Cout, c_off, ldc, c_bs, M, N, batch, a_t=0, w_t=0, what='bgemm',
+           inner=0, a_is=0, w_is=0, c_is=0):
+    """One batched launch of the MFMA GEMM on sub-blocks of larger tensors (element offsets into A / W / Cout).
+    inner > 1: two-level batch of `batch` entries = outer x inner, bases outer * (a|w|c)_bs + inner * (a|w|c)_is."""
     g = GemmArgs()
     g.nseg = 1
     g.seg[0] = GemmSeg(C.c_void_p(A.data_ptr() + 4 * a_off), lda, a_bs, C.c_void_p(W.data_ptr() + 4 * w_off), ldw, w_bs, K)
     g.C = C.c_void_p(Cout.data_ptr() + 4 * c_off); g.ldc = ldc; g.c_batch_stride = c_bs
     g.M, g.N, g.batch, g.act = M, N, batch, 0
     g.a_kstrided, g.w_kstrided = a_t, w_t
+    if inner > 1:
+        g.batch_inner, g.a_inner_stride, g.w_inner_stride, g.c_inner_stride = inner, a_is, w_is, c_is
     check(lib().gvd_gemm_nt_f32(C.byref(g), stream_ptr()), 'gvd_gemm_nt_f32(%s)' % what)
+
+
+def _heads_bgemm(nh, A, a_off, lda, a_bs, a_hs, W, w_off, ldw, w_bs, w_hs, K, Cout, c_off, ldc, c_bs, c_hs, M, N, B, a_t=0,
+                 w_t=0, what='bgemm'):
+    """The same product for every (sample, head): ONE launch over the two-level batch B x nh (heads live at stride *_hs
+    inside the sample's block) — or, with GVD_ENC_HEADS_MERGED=0, one launch per head over the B samples."""
+    if os.environ.get('GVD_ENC_HEADS_MERGED', '1') == '1':
+        _bgemm(A, a_off, lda, a_bs, W, w_off, ldw, w_bs, K, Cout, c_off, ldc, c_bs, M, N, B * nh, a_t=a_t, w_t=w_t, what=what,
+               inner=nh, a_is=a_hs, w_is=w_hs, c_is=c_hs)
+        return
+    for h in range(nh):
+        _bgemm(A, a_off + h * a_hs, lda, a_bs, W, w_off + h * w_hs, ldw, w_bs, K, Cout, c_off + h * c_hs, ldc, c_bs, M, N, B,
+               a_t=a_t, w_t=w_t, what=what)
 
 
 class _EncAttnCoreFn(torch.autograd.Function):
@@ -734,17 +751,17 @@ class _EncAttnCoreFn(torch.autograd.Function):
         dev = qkv.device
         Y = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
         ko, vo = nh * HP, 2 * nh * HP
-        for h in range(nh):       # S_h = Q_h K_h^T
-            _bgemm(qkv, h * HP, W3, Rp * W3, qkv, ko + h * HP, W3, Rp * W3, HP, Y, h * Rp * Rp, Rp, nh * Rp * Rp, R, R, B,
-                   what='QK^T')
+        # S_h = Q_h K_h^T for all (sample, head) pairs
+        _heads_bgemm(nh, qkv, 0, W3, Rp * W3, HP, qkv, ko, W3, Rp * W3, HP, HP, Y, 0, Rp, nh * Rp * Rp, Rp * Rp, R, R, B,
+                     what='QK^T')
         Pd = torch.empty_like(Y) if p_drop > 0 else None
         check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y), ptr(Pd), B * nh, Rp, R, scale, p_drop, seed, stream_ptr()),
               'gvd_enc_softmax_dropout_fwd')
         P = Pd if Pd is not None else Y
         O = torch.zeros(B, Rp, nh * HP, device=dev, dtype=torch.float32)
-        for h in range(nh):       # O_h = Pd_h V_h   (V consumed in place as a K-strided operand)
-            _bgemm(P, h * Rp * Rp, Rp, nh * Rp * Rp, qkv, vo + h * HP, W3, Rp * W3, Rp, O, h * HP, nh * HP, Rp * nh * HP,
-                   R, HP, B, w_t=1, what='PV')
+        # O_h = Pd_h V_h   (V consumed in place as a K-strided operand)
+        _heads_bgemm(nh, P, 0, Rp, nh * Rp * Rp, Rp * Rp, qkv, vo, W3, Rp * W3, HP, Rp, O, 0, nh * HP, Rp * nh * HP, HP, R, HP,
+                     B, w_t=1, what='PV')
         ctx.save_for_backward(qkv, Y, Pd)
         ctx.cfg = (R, nh, scale, p_drop)
         return O
@@ -762,21 +779,19 @@ class _EncAttnCoreFn(torch.autograd.Function):
         dS = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
         dqkv = torch.zeros_like(qkv)
         mb, ms = nh * Rp * Rp, Rp * Rp
-        for h in range(nh):
-            # dPd_h = dO_h V_h^T
-            _bgemm(dO, h * HP, nh * HP, Rp * nh * HP, qkv, vo + h * HP, W3, Rp * W3, HP, dS, h * ms, Rp, mb, R, R, B,
-                   what='dO V^T')
-            # dV_h = Pd_h^T dO_h   (both operands K-strided; pad rows of Pd are zero)
-            _bgemm(P, h * ms, Rp, mb, dO, h * HP, nh * HP, Rp * nh * HP, Rp, dqkv, vo + h * HP, W3, Rp * W3, R, HP, B,
-                   a_t=1, w_t=1, what='P^T dO')
+        # dPd_h = dO_h V_h^T
+        _heads_bgemm(nh, dO, 0, nh * HP, Rp * nh * HP, HP, qkv, vo, W3, Rp * W3, HP, HP, dS, 0, Rp, mb, ms, R, R, B,
+                     what='dO V^T')
+        # dV_h = Pd_h^T dO_h   (both operands K-strided; pad rows of Pd are zero)
+        _heads_bgemm(nh, P, 0, Rp, mb, ms, dO, 0, nh * HP, Rp * nh * HP, HP, Rp, dqkv, vo, W3, Rp * W3, HP, R, HP, B,
+                     a_t=1, w_t=1, what='P^T dO')
         check(lib().gvd_enc_softmax_dropout_bwd(ptr(dS), ptr(Pd), ptr(Y), B * nh, Rp, R, scale, p_drop, stream_ptr()),
               'gvd_enc_softmax_dropout_bwd')
-        for h in range(nh):
-            # dQ_h = dS_h K_h ;  dK_h = dS_h^T Q_h
-            _bgemm(dS, h * ms, Rp, mb, qkv, ko + h * HP, W3, Rp * W3, Rp, dqkv, h * HP, W3, Rp * W3, R, HP, B, w_t=1,
-                   what='dS K')
-            _bgemm(dS, h * ms, Rp, mb, qkv, h * HP, W3, Rp * W3, Rp, dqkv, ko + h * HP, W3, Rp * W3, R, HP, B, a_t=1,
-                   w_t=1, what='dS^T Q')
+        # dQ_h = dS_h K_h ;  dK_h = dS_h^T Q_h
+        _heads_bgemm(nh, dS, 0, Rp, mb, ms, qkv, ko, W3, Rp * W3, HP, Rp, dqkv, 0, W3, Rp * W3, HP, R, HP, B, w_t=1,
+                     what='dS K')
+        _heads_bgemm(nh, dS, 0, Rp, mb, ms, qkv, 0, W3, Rp * W3, HP, Rp, dqkv, ko, W3, Rp * W3, HP, R, HP, B, a_t=1, w_t=1,
+                     what='dS^T Q')
         return dqkv, None, None, None, None, None
 
 

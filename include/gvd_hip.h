@@ -94,6 +94,11 @@ typedef struct {
    * a batch over contraction chunks (a/w_batch_stride = chunk rows * ld) gives a deterministic split-K: the caller sums
    * the partial C slabs. */
   int a_kstrided, w_kstrided;
+  /* Two-level batch (batch_inner > 1): batch index b = outer * batch_inner + inner; operand / output bases are
+   * outer * (a|w|c)_batch_stride + inner * (a|w|c)_inner_stride (e.g. outer = sample, inner = attention head living at a
+   * column offset of a packed [B,R,heads*HP] tensor).  mbias / rowbias / mask must be NULL then.  0 or 1 = flat batch. */
+  int batch_inner;
+  int64_t a_inner_stride, w_inner_stride, c_inner_stride;
 } gvd_gemm_args;
 
 int gvd_gemm_nt_f32(const gvd_gemm_args* args, gvd_stream_t stream);

@@ -701,7 +701,7 @@ def test_enc_softmax_dropout_row_kernels(n_maps, R, Rp, p):
 
 
 @pytest.mark.parametrize('B,R', [(2, 1000), (3, 40)])
-def test_enc_attn_core_training_matches_autograd(B, R):
+def test_enc_attn_core_training_matches_autograd(B, R, monkeypatch):
     """ops.enc_attn_core (six MFMA products + the two row kernels) against the per-head torch formulation of
     transformer.py:90-117 with dropout off: output and the gradient w.r.t. the packed q | k | v."""
     g = _g(B * R)
@@ -731,6 +731,13 @@ def test_enc_attn_core_training_matches_autograd(B, R):
     err = float((got.double() - want).abs().max())
     assert err < 3e-5 * float(want.abs().max()), err
     assert not got[:, R:].any()
+    # one launch per product over the two-level (sample, head) batch == one launch per head, bit for bit
+    monkeypatch.setenv('GVD_ENC_HEADS_MERGED', '0')
+    qkv.grad = None
+    O2 = ops.enc_attn_core(qkv, R, nh, 1.0 / 32, 0.0)
+    O2.backward(dO)
+    assert torch.equal(O2, O) and torch.equal(qkv.grad, got)
+    monkeypatch.delenv('GVD_ENC_HEADS_MERGED')
     # dropout on: runs, reproducible under the torch seed, and differs from the p = 0 output
     torch.manual_seed(5)
     o1 = ops.enc_attn_core(qkv.detach(), R, nh, 1.0 / 32, 0.2)

@@ -310,4 +310,5 @@ def test_train_step_fused_paths_equal_library_paths_in_eval_mode(monkeypatch):
         ref = res['0'][1][n]
         # gradients that are mathematically zero (the temporal alpha_net bias: softmax is shift invariant) are rounding noise
         err = float((gsel - ref).norm() / ref.norm().clamp_min(1e-6 * gmax))
-        assert err < 2e-3, (n, err)
+        # (the scalar alpha_net biases are sums with heavy cancellation over B*Lc*R terms: looser)
+        assert err < (1e-2 if ref.numel() == 1 else 2e-3), (n, err)

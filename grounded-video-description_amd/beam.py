@@ -16,9 +16,13 @@ B*K rows, the attention kernel reads each sample's region features ONCE for its 
 indirection, no expanded copies), top-K per row is a HIP kernel, and the K*K candidate merge + state
 gathers are a handful of batched device ops — no host synchronisation inside the loop.
 """
+import ctypes as C
+import os
+
 import torch
 
 from . import ops
+from .hip import BeamStepArgs, check, lib, ptr, stream_ptr
 
 
 def _core_rows(P, st, xt, fc_gates, pre, pmask_rows, K, att2_out):
@@ -71,7 +75,26 @@ def beam_decode(model, pre, P, K):
     base = (torch.arange(B, device=dev) * K).view(B, 1)
     kk = torch.arange(K, device=dev)
 
-    for t in range(L):
+    fused = os.environ.get('GVD_BEAM_FUSED', '1') == '1' and K <= 8
+    if fused:
+        parent = torch.empty(rows, dtype=torch.int64, device=dev)
+        word_rows = torch.empty(rows, dtype=torch.int64, device=dev)
+        a = BeamStepArgs()
+        a.sums, a.beam_seq, a.beam_lps, a.beam_att = ptr(sums), ptr(beam_seq), ptr(beam_lps), ptr(beam_att)
+        a.best_p, a.best_seq, a.best_lps, a.best_vix = ptr(best_p), ptr(best_seq), ptr(best_lps), ptr(best_vix)
+        a.parent, a.word = ptr(parent), ptr(word_rows)
+        a.B, a.K, a.L = B, K, L
+    for t in range(L if fused else 0):
+        # one launch for the candidate merge / history fork / finished-beam record of all samples (csrc/beam.hip)
+        logits = ops.gemm_nt(st['h_lang'], P['logit_w'], P['logit_b'])
+        _, _, ys, ix = ops.logsoftmax_rows(logits, topk=K)
+        a.ys, a.ix, a.att2_ind, a.t = ptr(ys), ptr(ix), ptr(att2_ind), t
+        check(lib().gvd_beam_step(C.byref(a), stream_ptr()), 'gvd_beam_step')
+        st = {k: v.index_select(0, parent) for k, v in st.items()}
+        st = _core_rows(P, st, ops.embed_relu(word_rows, P['embed']), fc_gates, pre, pm_rows, K, att2_w)
+        att2_ind = att2_w.view(B, K, R).max(dim=2)[1].contiguous()   # CaptionModelBU.py:182
+
+    for t in range(0 if fused else L):
         logits = ops.gemm_nt(st['h_lang'], P['logit_w'], P['logit_b'])
         _, _, ys, ix = ops.logsoftmax_rows(logits, topk=K)          # sorted log-probs / word ids per beam row
         ys, ix = ys.view(B, K, K), ix.view(B, K, K)                  # [b, q, c]

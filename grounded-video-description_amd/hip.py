@@ -76,6 +76,14 @@ class GreedyArgs(C.Structure):
                 ('prof', C.c_void_p), ('status', C.c_void_p), ('trace', C.c_void_p)]
 
 
+class BeamStepArgs(C.Structure):
+    _fields_ = [('ys', c_f32p), ('ix', c_i64p), ('sums', c_f32p), ('att2_ind', c_i64p),
+                ('beam_seq', c_i64p), ('beam_lps', c_f32p), ('beam_att', c_i64p),
+                ('best_p', c_f32p), ('best_seq', c_i64p), ('best_lps', c_f32p), ('best_vix', c_i64p),
+                ('parent', c_i64p), ('word', c_i64p),
+                ('B', C.c_int), ('K', C.c_int), ('L', C.c_int), ('t', C.c_int)]
+
+
 # every symbol include/gvd_hip.h declares: (restype, argtypes)
 _SIG = {
     'gvd_version': (C.c_char_p, []),
@@ -135,6 +143,7 @@ _SIG = {
     'gvd_embed_relu': (C.c_int, [c_i64p, C.c_int64, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int64, C.c_void_p]),
     'gvd_logsoftmax_rows': (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, c_i64p, c_f32p, C.c_int,
                                       c_f32p, c_i64p, C.c_void_p]),
+    'gvd_beam_step': (C.c_int, [C.POINTER(BeamStepArgs), C.c_void_p]),
     'gvd_greedy_workspace_bytes': (C.c_size_t, [C.c_int] * 7),
     'gvd_greedy_decode': (C.c_int, [C.POINTER(GreedyArgs), C.c_void_p]),
     'gvd_zero_masked_rows': (C.c_int, [c_f32p, C.c_int64, C.c_int, c_u8p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),

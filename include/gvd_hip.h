@@ -328,6 +328,24 @@ int gvd_logsoftmax_rows(const float* logits, int64_t ld_logits, int rows, int V,
                         const int64_t* target, float* picked, int topk, float* topk_val, int64_t* topk_idx,
                         gvd_stream_t stream);
 
+/* Beam-search bookkeeping of decode step t for all samples in one launch (CaptionModelBU.py:49-96,154-166; replaces the
+ * reference's per-sample host-side sort): merges the K x K candidates (ys / ix = the sorted top-K log-probs / word ids of
+ * every beam row, from gvd_logsoftmax_rows), stable-sorts them by descending summed log-prob, forks the histories
+ * beam_seq / beam_lps / beam_att [L,B,K] from the chosen parents, records beam_att[t] = att2_ind[parent], tracks the best
+ * finished beam (best_p [B] starts at -inf; best_seq / best_lps [B,L], best_vix [B]) and writes parent [B*K] (row of the
+ * recurrent state each new beam continues from) and word [B*K] (its token).  sums [B,K] is updated in place (finished
+ * beams: -1000).  Only beam 0 expands at t = 0.  K <= 8. */
+typedef struct {
+  const float* ys; const int64_t* ix;          /* [B,K,K] */
+  float* sums; const int64_t* att2_ind;        /* [B,K] */
+  int64_t* beam_seq; float* beam_lps; int64_t* beam_att;   /* [L,B,K] */
+  float* best_p; int64_t* best_seq; float* best_lps; int64_t* best_vix;
+  int64_t* parent; int64_t* word;              /* [B*K] */
+  int B, K, L, t;
+} gvd_beam_step_args;
+
+int gvd_beam_step(const gvd_beam_step_args* args, gvd_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Whole greedy decode: L x (embed, att-LSTM, 2 attentions, lang-LSTM, logit, token rule) on one stream,
  * no host round trip per token (AttModel._sample, model.py:580-624, sample_max=1, beam_size=1).

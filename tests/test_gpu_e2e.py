@@ -200,6 +200,30 @@ def test_beam_search_matches_oracle(B, K, seed):
     np.testing.assert_allclose(lps.cpu().numpy(), olps.numpy(), atol=2e-4)
 
 
+@pytest.mark.parametrize('K', [2, 5, 8])
+def test_beam_step_kernel_equals_batched_torch_bookkeeping(K, monkeypatch):
+    """gvd_beam_step (one launch per step: candidate merge, history fork, finished-beam record) against the batched torch
+    formulation it replaces (GVD_BEAM_FUSED=0): ids, log-probs and attended regions bit for bit, on logits shaped so that
+    beams finish at different steps (END-heavy profile) and with exact score ties (K = 8 > distinct top words)."""
+    opt = gvd_amd.opts.default_opt(vocab_size=40, t_attn_size=6)
+    inp = synth.make_inputs(opt, 5, seed=9, train=False)
+    args = [inp[k].cuda() for k in ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')]
+    nonzero = 0
+    for end_bias in (0.0, 0.4, 0.8):               # END more and more competitive: beams finish earlier / at different steps
+        sd = synth.init_state_dict(opt, seed=4, profile='trained_like')
+        sd['logit.bias'][0] += end_bias
+        model = _model(opt, sd)
+        res = {}
+        for fused in ('1', '0'):
+            monkeypatch.setenv('GVD_BEAM_FUSED', fused)
+            with torch.no_grad():
+                res[fused] = model._sample(*args, {'beam_size': K})[:3]
+        for a, b in zip(res['1'], res['0']):
+            assert torch.equal(a, b)
+        nonzero += int((res['1'][0] != 0).sum())
+    assert nonzero > 0
+
+
 @pytest.mark.parametrize('name', BEAM)
 def test_beam_search_matches_reference_with_shim(name, golden_dir):
     """BASELINE configs[4] (beam=5, 20 frames x 100 regions) against outputs of the reference's OWN beam_search run under

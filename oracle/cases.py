@@ -40,6 +40,11 @@ CASES = {
     # the synthetic dataset of oracle/ingest_oracle.write_synthetic_dataset(seed) (oracle/ref_dataloader_harness.py)
     'ingest_train_ft480_seed3': dict(mode='ingest', Ft=480, seed=3, V=61),
     'ingest_train_ft10_seed5': dict(mode='ingest', Ft=10, seed=5, V=61),
+    # BASELINE configs[3]: batch-DP training, B=256 as 8 replicas x 32 segments.  The reference is run
+    # shard by shard ('MLE' forward + backward in eval-mode arithmetic); stored: the per-shard losses and the per-parameter
+    # norms of the gradient AVERAGED over the shards = what nn.DataParallel's backward (main.py:654-655, loss .sum() /
+    # numel()) and a gradient all-reduce(sum)/N produce (mean over replicas of per-replica means)
+    'dp8x32_v5000_ft10_trained': dict(mode='dp', B=256, shards=8, V=5000, Ft=10, seed=13, profile='trained_like'),
     # BASELINE configs[2]: training step batch 64 (losses only)
     'mle_b64_v5000_ft10_trained': dict(mode='MLE', B=64, V=5000, Ft=10, seed=5, profile='trained_like'),
 }

@@ -59,7 +59,7 @@ def run_case(name):
     if spec['mode'] == 'ingest':
         return run_ingest_case(name)
     opt, sd, inp = cases.build_case(name)
-    need_grad = (spec['mode'] == 'MLE' and spec['B'] <= 8) or spec['mode'] == 'step'
+    need_grad = (spec['mode'] == 'MLE' and spec['B'] <= 8) or spec['mode'] in ('step', 'dp')
     ref = ref_harness.build_reference_model(opt, sd, need_grad=need_grad).eval()
     args = pkg.synth.as_args(inp)
     out = dict(weight_fp=np.int64(cases.weight_fingerprint(sd)),
@@ -105,6 +105,28 @@ def run_case(name):
             with torch.no_grad():
                 lm, a2, gl, cl = ref(*args, 'MLE')
         out['losses'] = np.array([lm.item(), a2.item(), gl.item(), cl.item()], dtype=np.float32)
+    elif spec['mode'] == 'dp':
+        # one replica per shard, exactly what nn.DataParallel scatters (main.py:654-655): per-shard masked-mean losses,
+        # total loss = sum over replicas / n_replicas (main.py:238-255), gradients accumulate over the replicas
+        w = cases.GRAD_WEIGHTS
+        n = spec['shards']
+        per = spec['B'] // n
+        ref.zero_grad()
+        shard_losses = []
+        for r in range(n):
+            sub = {k: v[r * per:(r + 1) * per].contiguous() for k, v in inp.items()}     # scatter of the trimmed batch
+            lm, a2, gl, cl = ref(*pkg.synth.as_args(sub), 'MLE')
+            ((lm.sum() + w['w_att2'] * a2.sum() + w['w_grd'] * gl.sum() + w['w_cls'] * cl.sum()) / n).backward()
+            shard_losses.append([lm.item(), a2.item(), gl.item(), cl.item()])
+            print('   shard %d/%d  %.1fs  losses %s' % (r + 1, n, time.time() - t0, shard_losses[-1]), flush=True)
+        names, norms = [], []
+        for pn, p in ref.named_parameters():
+            if p.grad is not None:
+                names.append(pn)
+                norms.append(float(p.grad.double().norm()))
+        out.update(shard_losses=np.array(shard_losses, dtype=np.float32), grad_names=np.array(names),
+                   grad_norms=np.array(norms, dtype=np.float64),
+                   losses=np.array(shard_losses, dtype=np.float64).mean(0).astype(np.float32))
     elif spec['mode'] == 'step':
         # main.train (main.py:234-266) with eval-mode arithmetic (dropout off, BN running stats: the only mode in which
         # CPU and GPU runs are comparable); optimizer exactly as main.py:660-677 builds it

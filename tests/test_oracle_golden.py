@@ -72,6 +72,21 @@ def test_mle_losses_match_reference(name, golden_dir):
                 assert v.grad is None or float(v.grad.abs().sum()) == 0.0, n   # i2h_2/h2h_2: unused
 
 
+@pytest.mark.parametrize('name', [n for n, s in cases.CASES.items() if s['mode'] == 'dp'])
+def test_dp_shard_losses_match_reference(name, golden_dir):
+    """BASELINE configs[3] fixture (8 replicas x 32 segments, reference run shard by shard): the oracle reproduces the
+    per-replica losses of two of the shards (the GPU test runs all eight and checks the averaged gradient)."""
+    g = _load(golden_dir, name)
+    opt, sd, inp = _build(name, g)
+    per = cases.CASES[name]['B'] // cases.CASES[name]['shards']
+    for r in (0, 5):
+        sub = {k: v[r * per:(r + 1) * per].contiguous() for k, v in inp.items()}
+        with torch.no_grad():
+            lm, a2, gl, cl, _ = O.forward_train(sd, opt, *[sub[k] for k in gvd_amd.synth.FORWARD_ORDER])
+        np.testing.assert_allclose(np.array([lm.item(), a2.item(), gl.item(), cl.item()], dtype=np.float32),
+                                   g['shard_losses'][r], rtol=0, atol=1e-4)
+
+
 @pytest.mark.parametrize('name', GRD)
 def test_grd_matches_reference(name, golden_dir):
     g = _load(golden_dir, name)

@@ -97,7 +97,7 @@ def trace(d, out, title):
                  'dispatches under 10 us: %d = %.3f ms\n\n' % (title, len(ev), span / 1e6, busy / 1e6, gaps / 1e6, gap_n,
                                                                 small_n, small_t / 1e6))
         fh.write('| kernel | grid (threads) | wg | calls | total ms | avg us |\n|---|---|---|---|---|---|\n')
-        for (k, g, w), (n, t) in rows[:70]:
+        for (k, g, w), (n, t) in rows[:400]:
             fh.write('| `%s` | %s | %d | %d | %.3f | %.2f |\n' % (k, 'x'.join(str(x) for x in g), w, n, t / 1e6, t / n / 1e3))
     print(open(out).read()[:6000])
 

@@ -14,6 +14,7 @@
 // Arithmetic is the 16x16x4 fp32-MFMA scheme of flash_attn16_kernel (swapped products S^T = K Q^T, O^T = V^T P^T,
 // lane-local online softmax in the log2 domain, exact skip of the identity rescale): same values.
 #include "gvd_common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -28,6 +29,34 @@ constexpr int NSB = DP / 16;        // 11
 constexpr int F4_PER_TILE = TK * DP / 4;              // 1408 16-byte pieces per operand tile
 constexpr int NLD = (F4_PER_TILE + NT - 1) / NT;      // 3 loads per thread per operand (the last round is partial)
 
+// Reduction over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 lane-swap instructions:
+// v_permlane16_swap a, b exchanges the odd rows of a with the even rows of b -> [a0 b0 a2 b2] / [a1 b1 a3 b3]; with
+// a = b = x one max (add) of the two registers reduces row pairs, v_permlane32_swap does the same for the 32-lane halves.
+// No LDS traffic, no dependent LDS round trips.  Written as inline assembly: through the clang 22 builtin
+// (__builtin_amdgcn_permlane16_swap) the second result was dropped when both operands held the same value (the ISA
+// showed `v_mov b, a'` right after the swap); the `s_nop 1` is the wait state the hazard recogniser puts between a VALU
+// write and these instructions (tools/permlane_probe.hip checks the semantics on the device).
+__device__ __forceinline__ void row_swap16(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void row_swap32(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float rows_max(float v) {
+  float a = v, b = v;
+  row_swap16(a, b);
+  float m = fmaxf(a, b), n = m;
+  row_swap32(m, n);
+  return fmaxf(m, n);
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  float a = v, b = v;
+  row_swap16(a, b);
+  float m = a + b, n = m;
+  row_swap32(m, n);
+  return m + n;
+}
+
 struct PParams {
   const float* q; const float* k; const float* v; float* o;
   int64_t ld, ldo;       // row strides (floats) of q/k/v and of o
@@ -36,8 +65,13 @@ struct PParams {
   // ragged (compacted) batches: sample b owns rows off[b] .. off[b+1]-1 of q/k/v/o (at most R of them); its LAST row
   // stands for n identical rows: as a key its score gets + key_w[b] = log2(n) (-inf: no such rows, key ignored)
   const int* off; const float* key_w;
+  int skew;              // phase-skew the two waves of every SIMD (see the kernel); 0 = all waves take the barrier mid-PV
 };
 
+// ABL (profiling only, tools/flash_ablate.py): 0 = the kernel; 1 = no online softmax (scores used as they are: wrong
+// values, same MFMA / LDS / staging work); 2 = no K/V staging and no barrier after the first tile (every tile re-reads
+// buffer 0); 3 = both.  Shows where the matrix pipe's idle quarter goes.
+template <int ABL>
 __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) {
   __shared__ __attribute__((aligned(16))) float smem[3 * 2 * TK * LD];       // [buf][K|V][32][180] = 138,240 B
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -120,6 +154,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
   // average half of that tile) only helps staging the K / V tiles and keeps the barrier count: it issues no MFMA, so its
   // SIMD's matrix pipe goes to the other resident waves.
   if (qt * (16 * NW) + wave * 16 >= R) {
+    if (ABL & 2) return;
 #pragma unroll 1
     for (int jt = 0; jt < ntiles; ++jt) {
       const int nxt = buf == 2 ? 0 : buf + 1;
@@ -132,6 +167,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     }
     return;
   }
+  const bool skew = p.skew && wave >= NW / 2;      // wave-uniform
   // first K fragments of the next tile, read right after the barrier that publishes it (under the last 44 MFMAs)
   f32x4 kpre[2];
   kpre[0] = *reinterpret_cast<const f32x4*>(smem + c16 * LD + 4 * g);
@@ -140,7 +176,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
   for (int jt = 0; jt < ntiles; ++jt) {
     const int key0 = jt * TK;
     const bool more = jt + 1 < ntiles;                                     // wave-uniform
-    if (more) fetch(key0 + TK);                                            // flies under this tile's MFMAs
+    if (more && !(ABL & 2)) fetch(key0 + TK);                              // flies under this tile's MFMAs
     const float* sk = smem + buf * (2 * TK * LD);
     const float* sv = sk + TK * LD;
 
@@ -178,19 +214,26 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
       for (int dt = 0; dt < NSB; ++dt) dst[dt] = vp[16 * dt];
     };
     vload(vf[0], 0);
+    if (!(ABL & 1)) {
     // ---- online softmax: this lane holds keys 16 u + 4 g + reg of its query
     float mt = -INFINITY;
+    // masks only where they can apply (wave-uniform): the sample's last key tile (keys past R, the weighted key)
+    if (key0 + TK > R || (wkey >= key0 && wkey < key0 + TK)) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + 16 * u + 4 * g + r;
+          if (key >= R) sacc[u][r] = -INFINITY;
+          else if (key == wkey) sacc[u][r] += wval;        // n identical keys = one key with n times the weight
+        }
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key0 + 16 * u + 4 * g + r;
-        if (key >= R) sacc[u][r] = -INFINITY;
-        else if (key == wkey) sacc[u][r] += wval;        // n identical keys = one key with n times the weight
-        mt = fmaxf(mt, sacc[u][r]);
-      }
-    mt = fmaxf(mt, __shfl_xor(mt, 16, GVD_WAVE));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, GVD_WAVE));
+      for (int r = 0; r < 4; ++r) mt = fmaxf(mt, sacc[u][r]);
+    // max over the four 16-lane rows (g): gfx950 lane-swap instructions instead of two dependent LDS-permute round trips
+    mt = rows_max(mt);
     const float m_new = fmaxf(m_run, mt);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
@@ -207,10 +250,27 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
 #pragma unroll
       for (int dt = 0; dt < NSB; ++dt) oacc[dt] *= alpha;
     }
+    }
     // ---- O^T += V^T P^T: step = 4 u + s4 contracts key 16 u + 4 g + s4 = score register s4 of sub-tile u; the V
     // fragments of step+1 are read while step multiplies.  Between steps 3 and 4: LDS write pass of the next tile +
     // the tile's only barrier (the reads of step 4 are already in flight; steps 4..7 still read `buf`).
-    const int nxt = buf == 2 ? 0 : buf + 1;
+    const int nxt = (ABL & 2) ? 0 : (buf == 2 ? 0 : buf + 1);
+    auto publish_next = [&]() {
+      if (ABL & 2) return;
+      if (more) stage(nxt);                // held tile jt-2: every wave finished it before arriving at the last barrier
+      __syncthreads();
+      const float* nk = smem + nxt * (2 * TK * LD) + c16 * LD + 4 * g;       // (stale but harmless after the last tile)
+      kpre[0] = *reinterpret_cast<const f32x4*>(nk);
+      kpre[1] = *reinterpret_cast<const f32x4*>(nk + 16 * LD);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // PHASE SKEW.  The tile's one barrier aligns all eight waves at the program point where they execute it.  If both
+    // waves of a SIMD (w and w + 4) execute it at the same point, they run their softmax phases at the same time and the
+    // matrix pipe idles through both (77 % MFMA-busy).  Waves 4..7 therefore take the barrier BEFORE the PV product and
+    // waves 0..3 in its middle: per SIMD one wave's softmax now falls into the other's 88-MFMA stretch.  The buffer
+    // protocol is unchanged: every wave still passes exactly one barrier per tile, after its last read of tile jt-1's
+    // buffer and before its first read of tile jt+1's.
+    if (skew) publish_next();
 #pragma unroll
     for (int step = 0; step < 8; ++step) {
       if (step + 1 < 8) vload(vf[(step + 1) & 1], step + 1);
@@ -219,20 +279,12 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
       for (int dt = 0; dt < NSB; ++dt)
         oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[step & 1][dt], sacc[step >> 2][step & 3], oacc[dt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (step == 3) {
-        if (more) stage(nxt);              // held tile jt-2: every wave finished it before arriving at the last barrier
-        __syncthreads();
-        const float* nk = smem + nxt * (2 * TK * LD) + c16 * LD + 4 * g;     // (stale but harmless after the last tile)
-        kpre[0] = *reinterpret_cast<const f32x4*>(nk);
-        kpre[1] = *reinterpret_cast<const f32x4*>(nk + 16 * LD);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      if (step == 3 && !skew) publish_next();
     }
     buf = nxt;
   }
 
-  float l_tot = l_run + __shfl_xor(l_run, 16, GVD_WAVE);
-  l_tot += __shfl_xor(l_tot, 32, GVD_WAVE);
+  const float l_tot = rows_sum(l_run);
   const float inv = 1.0f / l_tot;
   if (qrow < R) {
     float* orow = p.o + (row0 + qrow) * p.ldo + h * DP + 4 * g;
@@ -254,8 +306,16 @@ extern "C" int gvd_flash_attn_padded_f32(const float* q, const float* k, const f
   p.q = q; p.k = k; p.v = v; p.o = o; p.ld = ld; p.ldo = ldo; p.B = B; p.R = R; p.n_heads = n_heads;
   p.qscale = 1.4426950408889634f * scale;
   p.off = row_off; p.key_w = last_key_log2_weight;
+  static const int skew = getenv("GVD_FLASH_SKEW") ? atoi(getenv("GVD_FLASH_SKEW")) : 1;    // A/B knob
+  static const int abl = getenv("GVD_FLASH_ABLATE") ? atoi(getenv("GVD_FLASH_ABLATE")) : 0;  // profiling only: WRONG results
+  p.skew = skew;
   const unsigned nwg = (unsigned)((R + 16 * NW - 1) / (16 * NW)) * n_heads * B;
-  hipLaunchKernelGGL(flash_attn_pad_kernel, dim3(nwg), dim3(NT), 0, gvd_s(stream), p);
+  switch (abl) {
+    case 1: hipLaunchKernelGGL(flash_attn_pad_kernel<1>, dim3(nwg), dim3(NT), 0, gvd_s(stream), p); break;
+    case 2: hipLaunchKernelGGL(flash_attn_pad_kernel<2>, dim3(nwg), dim3(NT), 0, gvd_s(stream), p); break;
+    case 3: hipLaunchKernelGGL(flash_attn_pad_kernel<3>, dim3(nwg), dim3(NT), 0, gvd_s(stream), p); break;
+    default: hipLaunchKernelGGL(flash_attn_pad_kernel<0>, dim3(nwg), dim3(NT), 0, gvd_s(stream), p);
+  }
   GVD_CHECK_LAUNCH();
   return 0;
 }

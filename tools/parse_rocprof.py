@@ -102,8 +102,29 @@ def trace(d, out, title):
     print(open(out).read()[:6000])
 
 
+def timeline(d, out, min_us):
+    """Dispatches of at least `min_us` in issue order with start offsets (ms) and durations: shows how the same kernel's
+    duration depends on what ran before it (clock / power-state ramps after light phases)."""
+    ev = []
+    for f in find(d, '*kernel_trace.csv'):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                g = int(r.get('Grid_Size_X', 0) or 0) * max(1, int(r.get('Grid_Size_Y', 1) or 1))
+                ev.append((float(r['Start_Timestamp']), float(r['End_Timestamp']), _short(r.get('Kernel_Name') or r.get('Name')), g))
+    ev.sort()
+    t0 = ev[0][0]
+    with open(out, 'w') as fh:
+        fh.write('| start ms | dur us | grid threads | kernel |\n|---|---|---|---|\n')
+        for s0, e0, k, g in ev:
+            if (e0 - s0) / 1e3 >= min_us:
+                fh.write('| %.3f | %.1f | %d | `%s` |\n' % ((s0 - t0) / 1e6, (e0 - s0) / 1e3, g, k))
+    print(open(out).read()[-6000:])
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'trace':
+    if sys.argv[1] == 'timeline':
+        timeline(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 300.0)
+    elif sys.argv[1] == 'trace':
         trace(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else 'kernel trace')
     elif sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else 'kernel stats')

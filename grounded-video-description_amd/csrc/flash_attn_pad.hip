@@ -179,6 +179,28 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     if (more && !(ABL & 2)) fetch(key0 + TK);                              // flies under this tile's MFMAs
     const float* sk = smem + buf * (2 * TK * LD);
     const float* sv = sk + TK * LD;
+    // Publishing tile jt+1:
+    //   stage_next   LDS write pass into the buffer that held tile jt-2 (every wave left it before the previous barrier);
+    //   barrier_next the tile's one barrier + the first K fragments of tile jt+1.
+    // (Measured: issuing the write pass 22 MFMAs / one softmax ahead of the barrier is SLOWER, 9.09 vs 8.89 ms per layer -
+    // the wait for the tile's global loads then comes too early.)
+    // PHASE SKEW: waves 4..7 publish right after their softmax (before the PV product), waves 0..3 in the middle of the
+    // PV product, so that per SIMD (waves w and w + 4) one wave's softmax falls into the other's MFMA stretch (8.89 vs
+    // 9.05 ms).  The buffer protocol only depends on the barrier order: every wave passes exactly one barrier per tile,
+    // after its last read of tile jt-1's buffer and before its first read of tile jt+1's.
+    const int nxt = (ABL & 2) ? 0 : (buf == 2 ? 0 : buf + 1);
+    auto stage_next = [&]() {
+      if (ABL & 2) return;
+      if (more) stage(nxt);
+    };
+    auto barrier_next = [&]() {
+      if (ABL & 2) return;
+      __syncthreads();
+      const float* nk = smem + nxt * (2 * TK * LD) + c16 * LD + 4 * g;       // (stale but harmless after the last tile)
+      kpre[0] = *reinterpret_cast<const f32x4*>(nk);
+      kpre[1] = *reinterpret_cast<const f32x4*>(nk + 16 * LD);
+      __builtin_amdgcn_sched_barrier(0);
+    };
 
     // ---- S^T for the two 16-key sub-tiles.  The two accumulator chains alternate (16x16x4: 40-cycle dependent latency
     // against a 32-cycle issue interval); the K fragments of k-block sb+1 are read while block sb multiplies (the
@@ -254,23 +276,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     // ---- O^T += V^T P^T: step = 4 u + s4 contracts key 16 u + 4 g + s4 = score register s4 of sub-tile u; the V
     // fragments of step+1 are read while step multiplies.  Between steps 3 and 4: LDS write pass of the next tile +
     // the tile's only barrier (the reads of step 4 are already in flight; steps 4..7 still read `buf`).
-    const int nxt = (ABL & 2) ? 0 : (buf == 2 ? 0 : buf + 1);
-    auto publish_next = [&]() {
-      if (ABL & 2) return;
-      if (more) stage(nxt);                // held tile jt-2: every wave finished it before arriving at the last barrier
-      __syncthreads();
-      const float* nk = smem + nxt * (2 * TK * LD) + c16 * LD + 4 * g;       // (stale but harmless after the last tile)
-      kpre[0] = *reinterpret_cast<const f32x4*>(nk);
-      kpre[1] = *reinterpret_cast<const f32x4*>(nk + 16 * LD);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    // PHASE SKEW.  The tile's one barrier aligns all eight waves at the program point where they execute it.  If both
-    // waves of a SIMD (w and w + 4) execute it at the same point, they run their softmax phases at the same time and the
-    // matrix pipe idles through both (77 % MFMA-busy).  Waves 4..7 therefore take the barrier BEFORE the PV product and
-    // waves 0..3 in its middle: per SIMD one wave's softmax now falls into the other's 88-MFMA stretch.  The buffer
-    // protocol is unchanged: every wave still passes exactly one barrier per tile, after its last read of tile jt-1's
-    // buffer and before its first read of tile jt+1's.
-    if (skew) publish_next();
+    if (skew) { stage_next(); barrier_next(); }
 #pragma unroll
     for (int step = 0; step < 8; ++step) {
       if (step + 1 < 8) vload(vf[(step + 1) & 1], step + 1);
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
       for (int dt = 0; dt < NSB; ++dt)
         oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[step & 1][dt], sacc[step >> 2][step & 3], oacc[dt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (step == 3 && !skew) publish_next();
+      if (step == 3 && !skew) { stage_next(); barrier_next(); }
     }
     buf = nxt;
   }

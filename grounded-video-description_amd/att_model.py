@@ -356,6 +356,16 @@ class TopDownModel(nn.Module):
         return (self.has_obj_interact and self.flash_obj_interact and os.environ.get('GVD_ENC_FUSED', '1') == '1'
                 and scale == 2.0 ** round(math.log2(scale)) and d % 32 == 0 and -(-d // 6) <= ops.HEAD_PAD)
 
+    def _vis_words_padded(self):
+        """relu(vis_embed.weight) and vis_classifiers_bias zero-padded along the class axis to a multiple of 32 (inference;
+        cached until a source parameter changes)."""
+        w, b = self.vis_embed[0].weight, self.vis_classifiers_bias
+
+        def build(w=w, b=b):
+            pad = (-w.shape[0]) % 32
+            return (F.pad(F.relu(w), (0, 0, 0, pad)).contiguous(), F.pad(b, (0, pad)).contiguous())
+        return self._packed(('vis_words',), (w, b), build)
+
     def _pool_weight_padded(self, K):
         pw = self.pool_embed[0].weight
 
@@ -387,9 +397,12 @@ class TopDownModel(nn.Module):
         pc = ci.gather(ppls)
         loc_in = torch.cat([pc[:, :4] / 720., (pc[:, 4] * 1. / self.num_sampled_frm).unsqueeze(-1)], dim=1)
         loc = F.relu(self.loc_fc[0](loc_in)).contiguous()
-        vis_word = F.relu(self.vis_embed[0].weight).detach()
-        logits = ops.gemm_nt(g_pool, vis_word, self.vis_classifiers_bias.detach(), m_dev=m)              # [cap,D1]
-        pool_in, sim_c = ops.region_feature_rows_compact(g_pool, loc, logits, ci.cmask, m, pad_to=32)
+        # class logits: the D1 = 433 visual words zero-padded to 448 rows so that the output rows are 16-byte aligned (the
+        # GEMM's vectorised LDS epilogue instead of column-strided scalar stores); the row kernel reads D1 of them
+        vis_word, vis_bias = self._vis_words_padded()
+        logits = ops.gemm_nt(g_pool, vis_word, vis_bias, m_dev=m)                                         # [cap,448]
+        pool_in, sim_c = ops.region_feature_rows_compact(g_pool, loc, logits, ci.cmask, m, pad_to=32,
+                                                         n_cls=self.detect_size + 1)
         pool = ops.gemm_nt(pool_in, self._pool_weight_padded(pool_in.shape[-1]), self.pool_embed[0].bias.detach(), 1,
                            m_dev=m)
         pool = self._obj_interact_fused(pool, ci=ci)
@@ -474,9 +487,14 @@ class TopDownModel(nn.Module):
             # inference: class-last similarity logits from ONE plain MFMA GEMM (the visual words are shared by the
             # batch), then mask + class softmax + the three layer norms + concat as one HIP row kernel
             # (model.py:321-340,357-364)
-            logits_t = ops.gemm_nt(g_pool, vis_word.detach(), self.vis_classifiers_bias.detach())     # [B,R,D1]
+            if self.training:      # (train mode under no_grad: the dropout on the visual words is live, model.py:329)
+                cpad = (-D1) % 32
+                vw_pad, vb_pad = F.pad(vis_word, (0, 0, 0, cpad)), F.pad(self.vis_classifiers_bias, (0, cpad))
+            else:
+                vw_pad, vb_pad = self._vis_words_padded()
+            logits_t = ops.gemm_nt(g_pool, vw_pad, vb_pad)                                        # [B,R,448] (D1 = 433 used)
             own = os.environ.get('GVD_POOL_EMBED_OWN', '1') == '1'
-            pool, sim_t = ops.region_feature_rows(g_pool, loc.contiguous(), logits_t, pm, pad_to=32 if own else 1)
+            pool, sim_t = ops.region_feature_rows(g_pool, loc.contiguous(), logits_t, pm, pad_to=32 if own else 1, n_cls=D1)
             sim_mat = sim_t.transpose(1, 2)          # [B,D1,R] view (the reference returns this layout)
             if own:
                 # pool_embed (model.py:384, K = 2781) on the MFMA GEMM: the row kernel wrote the concat zero-padded to

@@ -801,21 +801,22 @@ def enc_attn_core(qkv, R, n_heads, scale, p_drop=0.0):
     return _EncAttnCoreFn.apply(qkv, R, n_heads, scale, float(p_drop), seed)
 
 
-def region_feature_rows(g_pool, loc, sim_logits_t, pnt_mask, ln_eps=1e-5, pad_to=1):
+def region_feature_rows(g_pool, loc, sim_logits_t, pnt_mask, ln_eps=1e-5, pad_to=1, n_cls=None):
     """[LN(g_pool) | LN(loc) | LN(softmax_classes(masked sim logits))] per proposal (model.py:336-364) in one pass.
     g_pool [B,R,2048], loc [B,R,n_loc], sim_logits_t [B,R,D1] (class-last), pnt_mask u8 [B,R+1].
     Returns pool_in [B,R,K] (K = 2048+n_loc+D1 rounded up to a multiple of `pad_to`, pad columns zero) and the class
     distribution sim_t [B,R,D1]."""
     require_cuda_f32(g_pool, loc, sim_logits_t)
     B, R, G = g_pool.shape
-    n_loc, n_cls = loc.shape[-1], sim_logits_t.shape[-1]
+    n_loc, ld = loc.shape[-1], sim_logits_t.shape[-1]
+    n_cls = ld if n_cls is None else n_cls          # logits rows may carry zero-padded classes past n_cls (ignored)
     assert g_pool.is_contiguous() and loc.is_contiguous() and sim_logits_t.is_contiguous()
     assert pnt_mask.dtype == torch.uint8 and pnt_mask.is_contiguous() and pnt_mask.shape == (B, R + 1)
     K = (G + n_loc + n_cls + pad_to - 1) // pad_to * pad_to
     out = torch.empty(B, R, K, device=g_pool.device, dtype=torch.float32)
     sim = torch.empty(B, R, n_cls, device=g_pool.device, dtype=torch.float32)
     mask_ptr = C.c_void_p(pnt_mask.data_ptr() + 1)              # skip the legacy pad column (main.py:227)
-    check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(sim_logits_t), n_cls, n_cls, mask_ptr, R, R + 1,
+    check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(sim_logits_t), n_cls, ld, mask_ptr, R, R + 1,
                                         ptr(out), K, ptr(sim), B * R, None, G, ln_eps, stream_ptr()),
           'gvd_region_feature_rows')
     return out, sim
@@ -871,18 +872,20 @@ def region_feature_rows_train(g_pool, loc, logits_pad, pnt_mask, n_cls, pad_to=3
                                ln_eps)
 
 
-def region_feature_rows_compact(g_pool, loc, sim_logits, row_mask, rows_dev, pad_to=32, ln_eps=1e-5):
-    """`region_feature_rows` over a compacted row set: g_pool [M,2048], loc [M,n_loc], sim_logits [M,D1], row_mask u8 [M]
-    (1 = the row is a masked proposal), live rows = *rows_dev."""
+def region_feature_rows_compact(g_pool, loc, sim_logits, row_mask, rows_dev, pad_to=32, ln_eps=1e-5, n_cls=None):
+    """`region_feature_rows` over a compacted row set: g_pool [M,2048], loc [M,n_loc], sim_logits [M,ld >= n_cls] (columns
+    past n_cls, the zero-padded classes of the similarity GEMM, are ignored), row_mask u8 [M] (1 = the row is a masked
+    proposal), live rows = *rows_dev."""
     require_cuda_f32(g_pool, loc, sim_logits)
     M, G = g_pool.shape
-    n_loc, n_cls = loc.shape[-1], sim_logits.shape[-1]
+    n_loc, ld = loc.shape[-1], sim_logits.shape[-1]
+    n_cls = ld if n_cls is None else n_cls
     assert g_pool.is_contiguous() and loc.is_contiguous() and sim_logits.is_contiguous() and row_mask.dtype == torch.uint8
     K = (G + n_loc + n_cls + pad_to - 1) // pad_to * pad_to
     out = torch.empty(M, K, device=g_pool.device, dtype=torch.float32)
     sim = torch.empty(M, n_cls, device=g_pool.device, dtype=torch.float32)
     # mask addressing row_mask[(row / rows_per_batch) * ld + row % rows_per_batch] with one "batch" of M rows
-    check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(sim_logits), n_cls, n_cls, ptr(row_mask), M, 0,
+    check(lib().gvd_region_feature_rows(ptr(g_pool), ptr(loc), n_loc, ptr(sim_logits), n_cls, ld, ptr(row_mask), M, 0,
                                         ptr(out), K, ptr(sim), M, ptr(rows_dev), G, ln_eps, stream_ptr()),
           'gvd_region_feature_rows(compact)')
     return out, sim

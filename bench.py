@@ -27,6 +27,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL / tensor sharing fail with the legacy mode); the driver's
+# environment exports it already - keep it for any environment this script is launched from
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

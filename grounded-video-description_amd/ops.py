@@ -366,7 +366,7 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, out = ctx.saved_tensors
         if ctx.act:
-            dy = dy * (out > 0).to(dy.dtype)
+            dy = torch.ops.aten.threshold_backward(dy, out, 0)      # ReLU backward in one pass (dy where out > 0)
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         x2 = x.reshape(-1, x.shape[-1])
         dx = dw = None

@@ -256,6 +256,20 @@ class TopDownModel(nn.Module):
         """nn.Linear (+ReLU) on the fp32 MFMA GEMM."""
         return ops.linear(x, lin.weight, lin.bias, act)
 
+    def _lin_k32(self, x, lin, act=0):
+        """nn.Linear (+ReLU) whose input width is not a multiple of the GEMM's 32-deep k tile (fc_embed: K = 3122,
+        loc_fc: K = 5) on the fp32 MFMA GEMM: input and weight zero-padded along K (the padded weight is cached at
+        inference; under autograd the pad is part of the graph)."""
+        pad = (-x.shape[-1]) % 32
+        if pad == 0:
+            return self._lin(x, lin, act)
+        xp = F.pad(x, (0, pad))
+        if torch.is_grad_enabled():
+            w = F.pad(lin.weight, (0, pad))
+        else:
+            w = self._packed(('k32', id(lin)), (lin.weight,), lambda: F.pad(lin.weight, (0, pad)).contiguous())
+        return ops.linear(xp, w, lin.bias, act)
+
     def _drop(self, x, p=None):
         return F.dropout(x, self.drop_prob_lm if p is None else p, self.training)
 
@@ -396,7 +410,7 @@ class TopDownModel(nn.Module):
             g_pool = ops.gemm_nt(ci.gather(ppls_feat), fc7.weight.detach(), fc7.bias.detach(), 1, m_dev=m)
         pc = ci.gather(ppls)
         loc_in = torch.cat([pc[:, :4] / 720., (pc[:, 4] * 1. / self.num_sampled_frm).unsqueeze(-1)], dim=1)
-        loc = F.relu(self.loc_fc[0](loc_in)).contiguous()
+        loc = self._lin_k32(loc_in, self.loc_fc[0], act=1)
         # class logits: the D1 = 433 visual words zero-padded to 448 rows so that the output rows are 16-byte aligned (the
         # GEMM's vectorised LDS epilogue instead of column-strided scalar stores); the row kernel reads D1 of them
         vis_word, vis_bias = self._vis_words_padded()
@@ -481,7 +495,7 @@ class TopDownModel(nn.Module):
         g_pool = self._drop(self._lin(ppls_feat, self.ctx2pool_grd[0], act=1))
         vis_word = self._drop(F.relu(self.vis_embed[0].weight))
         loc_in = torch.cat([ppls[:, :, :4] / 720., (ppls[:, :, 4] * 1. / self.num_sampled_frm).unsqueeze(-1)], dim=2)
-        loc = F.dropout(F.relu(self.loc_fc[0](loc_in)), 0.5, self.training)
+        loc = F.dropout(self._lin_k32(loc_in, self.loc_fc[0], act=1), 0.5, self.training)
         pool_done = False
         if not torch.is_grad_enabled():
             # inference: class-last similarity logits from ONE plain MFMA GEMM (the visual words are shared by the
@@ -538,7 +552,7 @@ class TopDownModel(nn.Module):
     def _preamble_finish(self, segs_feat, sample_idx, fc, pm, pool, p_pool, sim_mat, g_pool):
         """fc embedding + the frame half of the preamble (model.py:393-405)."""
         Ft = segs_feat.shape[1]
-        fc = self._drop(F.relu(self.fc_embed[0](fc)))
+        fc = self._drop(self._lin_k32(fc, self.fc_embed[0], act=1))
         # frame-wise context (model.py:393-405)
         # frame embeddings (model.py:393-395) on the MFMA GEMM, straight from the two column blocks of segs_feat
         c = torch.cat([self._drop(self._lin(segs_feat[:, :, :2048], self.att_embed[0][0], act=1)),

@@ -45,3 +45,12 @@ def test_no_cpu_fallback():
 def test_unsupported_configuration_is_rejected():
     with pytest.raises(NotImplementedError):
         att_model.TopDownModel(gvd_amd.opts.default_opt(vocab_size=50, att_model='transformer'))
+
+
+def test_integration_doc_stub_matches_the_binding():
+    """The ctypes stub INTEGRATION.md shows a maintainer (gvd_attn_side) lists the fields of the real binding, in order."""
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    body = doc[doc.index('class AttnSide(C.Structure)'):]
+    body = body[:body.index('\n\n')]
+    names = re.findall(r"\('([a-z_0-9]+)',", body)
+    assert names == [f[0] for f in hip.AttnSide._fields_], names

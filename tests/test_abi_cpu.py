@@ -52,5 +52,5 @@ def test_integration_doc_stub_matches_the_binding():
     doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
     body = doc[doc.index('class AttnSide(C.Structure)'):]
     body = body[:body.index('\n\n')]
-    names = re.findall(r"\('([a-z_0-9]+)',", body)
+    names = re.findall(r"\('([A-Za-z_0-9]+)',", body)
     assert names == [f[0] for f in hip.AttnSide._fields_], names

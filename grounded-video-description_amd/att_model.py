@@ -278,6 +278,9 @@ class TopDownModel(nn.Module):
         parameter changed (in-place update, load_state_dict, .to(device))."""
         cache = self.__dict__.setdefault('_pack_cache', {})
         sig = tuple((t.data_ptr(), t._version, t.device) for t in params)
+        # nn.DataParallel replicas are shallow copies that share this dict: one entry per device, so that the replicas do
+        # not evict each other's packed weights on every call
+        key = (key, params[0].device)
         hit = cache.get(key)
         if hit is None or hit[0] != sig:
             with torch.no_grad():

@@ -20,6 +20,13 @@
 // Numerics are identical to gemm_f32.hip: the same v_mfma_f32_32x32x2_f32 chain in the same k order per output.
 #include "gemm_common.h"
 
+// Profiling builds only (tools/gemm_ablate.py compiles variants of this file with -DGVD_PIPE_ABL=n; results are WRONG, the
+// MFMA work is unchanged): bit 0 = no per-k-tile barrier, bit 1 = no register->LDS write pass, bit 2 = no global loads after
+// the first tile, bit 3 = no epilogue (nothing stored).  The product build leaves it 0.
+#ifndef GVD_PIPE_ABL
+#define GVD_PIPE_ABL 0
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 4;
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   int buf = 0;
 #pragma unroll 1
   for (int kt = 0; kt + 1 < nkt; ++kt) {
-    fetch();                                   // tile kt+1: in flight under the first three quarters
+    if (!(GVD_PIPE_ABL & 4)) fetch();          // tile kt+1: in flight under the first three quarters
     frags(a1, b1, buf, 1);
     mfma16(a0, b0);
     frags(a0, b0, buf, 2);
@@ -231,10 +238,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       mfma4(a0, b0, t);
-      stage_part(buf ^ 1, t);
+      if (!(GVD_PIPE_ABL & 2)) stage_part(buf ^ 1, t);
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    if (!(GVD_PIPE_ABL & 1)) __syncthreads();
     frags(a0, b0, buf ^ 1, 0);
     mfma16(a1, b1);
     buf ^= 1;
@@ -247,6 +254,17 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   mfma16(a0, b0);
   mfma16(a1, b1);
 
+  if (GVD_PIPE_ABL & 8) {       // keep the accumulators alive without storing a tile
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
+    if (sacc == 12345.678f) p.C[0] = sacc;
+    return;
+  }
   if (!EPI_LDS) {
     // (narrow tiles: the wave's second row block is not part of the tile - push it past M so nothing is stored)
     if (narrow) gemm_epilogue_plain<1, 2>(p, M, reinterpret_cast<const f32x16(&)[1][2]>(acc[0]), bz, m0 + rb, n0 + cb, r, half);

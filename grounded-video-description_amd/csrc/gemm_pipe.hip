@@ -26,6 +26,9 @@
 #ifndef GVD_PIPE_ABL
 #define GVD_PIPE_ABL 0
 #endif
+#ifndef GVD_PIPE_AGPR
+#define GVD_PIPE_AGPR 0
+#endif
 
 namespace {
 
@@ -52,6 +55,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   float* As = smem;
   float* Ws = smem + 2 * BM * LDK;
 
+#if GVD_PIPE_AGPR
+  // An inline-asm AGPR operand makes the function "may need AGPRs": the instruction selector then emits the MFMAs in their
+  // AGPR form (accumulators in the acc register file with its own ports) instead of the VGPR form it prefers when the
+  // whole kernel fits 256 VGPRs - in VGPR form every MFMA's 16-register accumulator traffic shares the VGPR ports with the
+  // operand fetch of the ds_write_b128 pass.
+  { float agpr_hint = 0.f; asm volatile("" : "+a"(agpr_hint)); }
+#endif
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, half = lane >> 5;

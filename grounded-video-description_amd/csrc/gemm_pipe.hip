@@ -29,6 +29,16 @@
 #ifndef GVD_PIPE_AGPR
 #define GVD_PIPE_AGPR 0
 #endif
+// DIRECT-TO-LDS OPERANDS (default on; -DGVD_PIPE_LDSDMA=0 = the register-staged form; tools/gemm_ldsdma_check.py compares the
+// two bit for bit on the device): operand tiles of the plain (not
+// K-strided) products go global -> LDS by direct loads (buffer_load_dwordx4 ... lds, 16 bytes per lane on gfx950), without
+// the register round trip and its ds_write_b128 pass (6 of the kernel's 10 idle points, tools/gemm_ablate.py).  A direct
+// load writes lane l's 16 bytes to LDS at base + 16 l, so the tile is stored UNPADDED (32 floats per row, 8 rows per wave
+// instruction) with an XOR swizzle instead of the 36-float rows: 16-byte slot s of row m holds the k-chunk s ^ (m & 7); the
+// loading lane fetches the k-chunk that belongs at its slot, the fragment reads of 8 consecutive rows hit 8 different slots.
+#ifndef GVD_PIPE_LDSDMA
+#define GVD_PIPE_LDSDMA 1
+#endif
 
 namespace {
 
@@ -52,8 +62,10 @@ struct Seg {
 template <bool EPI_LDS, bool AT = false, bool BT = false, bool EDGE = false>
 __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];     // 73,728 B -> two workgroups per CU
+  constexpr bool DMA = (GVD_PIPE_LDSDMA != 0) && !AT && !BT;
+  constexpr int DLD = BK;                        // DMA layout: unpadded rows
   float* As = smem;
-  float* Ws = smem + 2 * BM * LDK;
+  float* Ws = smem + 2 * BM * (DMA ? DLD : LDK);
 
 #if GVD_PIPE_AGPR
   // An inline-asm AGPR operand makes the function "may need AGPRs": the instruction selector then emits the MFMAs in their
@@ -82,6 +94,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
 
   // staging role: thread covers rows srow + 32 i (i < 4), 16-byte chunk kq of the 128-byte k slice of a row
   const int srow = tid >> 3, kq = tid & 7;
+  // DMA layout: this lane's 16 bytes land in slot kq of tile row srow + 32 i, which holds the k-chunk kq ^ (row & 7)
+  const int kq_sw = kq ^ (srow & 7);
   int arow[NLD], wrow[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
@@ -115,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
     } else {
       sg.ra = gvd_rsrc(p.A[s] + gvd_boff(p, bz, p.abs_[s], p.abs2) + (gathered ? 0 : (int64_t)m0 * p.lda[s]));
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) sg.voa[i] = (unsigned)arow[i] * lda4 + 16u * kq;
+      for (int i = 0; i < NLD; ++i) sg.voa[i] = (unsigned)arow[i] * lda4 + 16u * (DMA ? kq_sw : kq);
     }
     if (BT) {
       pw_t = p.W[s] + gvd_boff(p, bz, p.wbs[s], p.wbs2) + n0;
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
     } else {
       sg.rw = gvd_rsrc(p.W[s] + gvd_boff(p, bz, p.wbs[s], p.wbs2) + (int64_t)n0 * p.ldw[s]);
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) sg.vow[i] = (unsigned)wrow[i] * ldw4 + 16u * kq;
+      for (int i = 0; i < NLD; ++i) sg.vow[i] = (unsigned)wrow[i] * ldw4 + 16u * (DMA ? kq_sw : kq);
     }
   };
   seg_setup(0);
@@ -164,6 +178,27 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
       seg_setup(seg);
     }
   };
+  // direct global -> LDS loads of the tile at kpos into buffer `buf` (DMA layout): wave w's instruction i covers tile rows
+  // 8 w + 32 i .. + 7 (one KiB of LDS, lane l at + 16 l)
+  auto dma = [&](int buf) {
+    const unsigned so = 4u * (unsigned)kpos;
+    const int w8 = __builtin_amdgcn_readfirstlane(wave) * 8;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(sg.ra, (__attribute__((address_space(3))) void*)&As[(buf * BM + w8 + 32 * i) * DLD],
+                                               16, sg.voa[i], so, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(sg.rw, (__attribute__((address_space(3))) void*)&Ws[(buf * BN + w8 + 32 * i) * DLD],
+                                               16, sg.vow[i], so, 0, 0);
+    kpos += BK;
+    if (kpos == kend && seg + 1 < nseg) {
+      ++seg;
+      kpos = 0;
+      kend = seg == 1 ? kseg1 : kseg2;
+      seg_setup(seg);
+    }
+  };
   float* Ast = AT ? &As[tk * LDT + 4 * tc] : &As[srow * LDK + 4 * kq];
   float* Wst = BT ? &Ws[tk * LDT + 4 * tc] : &Ws[srow * LDK + 4 * kq];
   auto stage_part = [&](int buf, int i) {      // one A row and one W row of this thread's share of the tile
@@ -187,7 +222,20 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   static_assert(BK * LDT <= BM * LDK, "a K-strided tile fits the operand buffer");
   const float* Afr = AT ? &As[half * 4 * LDT + rb + r] : &As[(rb + r) * LDK + half * 4];
   const float* Wfr = BT ? &Ws[half * 4 * LDT + cb + r] : &Ws[(cb + r) * LDK + half * 4];
+  // DMA layout: k-chunk 2 q + half of row m sits in slot (2 q + half) ^ (m & 7); rb / cb are multiples of 32, so m & 7 = r & 7
+  const float* Adm = &As[(rb + r) * DLD];
+  const float* Wdm = &Ws[(cb + r) * DLD];
+  const int rsw = r & 7;
   auto frags = [&](f32x4 (&a)[2], f32x4 (&b)[2], int buf, int q) {
+    if (DMA) {
+      const int so4 = ((2 * q + half) ^ rsw) * 4;
+      a[0] = *reinterpret_cast<const f32x4*>(Adm + buf * BM * DLD + so4);
+      a[1] = *reinterpret_cast<const f32x4*>(Adm + buf * BM * DLD + 32 * DLD + so4);
+      b[0] = *reinterpret_cast<const f32x4*>(Wdm + buf * BN * DLD + so4);
+      b[1] = *reinterpret_cast<const f32x4*>(Wdm + buf * BN * DLD + 32 * DLD + so4);
+      __builtin_amdgcn_sched_barrier(0);
+      return;
+    }
     if (AT) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -230,11 +278,30 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   };
 
   f32x4 a0[2], b0[2], a1[2], b1[2];
+  int buf = 0;
+  if (DMA) {
+    dma(0);
+    __syncthreads();                             // (s_waitcnt vmcnt(0) + barrier: every wave's direct loads have landed)
+    frags(a0, b0, 0, 0);
+#pragma unroll 1
+    for (int kt = 0; kt + 1 < nkt; ++kt) {
+      dma(buf ^ 1);                              // tile kt+1 straight into the other buffer: its last reads preceded the
+      frags(a1, b1, buf, 1);                     // previous barrier; three quarters (~3000 cycles) to land
+      mfma16(a0, b0);
+      frags(a0, b0, buf, 2);
+      mfma16(a1, b1);
+      frags(a1, b1, buf, 3);
+      mfma16(a0, b0);
+      __syncthreads();
+      frags(a0, b0, buf ^ 1, 0);
+      mfma16(a1, b1);
+      buf ^= 1;
+    }
+  } else {
   fetch();
   stage(0);
   __syncthreads();
   frags(a0, b0, 0, 0);
-  int buf = 0;
 #pragma unroll 1
   for (int kt = 0; kt + 1 < nkt; ++kt) {
     if (!(GVD_PIPE_ABL & 4)) fetch();          // tile kt+1: in flight under the first three quarters
@@ -255,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
     frags(a0, b0, buf ^ 1, 0);
     mfma16(a1, b1);
     buf ^= 1;
+  }
   }
   frags(a1, b1, buf, 1);
   mfma16(a0, b0);

@@ -1,4 +1,5 @@
-"""Where does the idle tenth of the matrix pipe go in gemm_pipe_kernel?  Builds variants of the GEMM library with parts of
+"""Where does the idle tenth of the matrix pipe go in the REGISTER-STAGED form of gemm_pipe_kernel (-DGVD_PIPE_LDSDMA=0; the
+study that led to the direct-to-LDS default)?  Builds variants of the GEMM library with parts of
 the pipelined kernel removed (-DGVD_PIPE_ABL=n: wrong results, unchanged MFMA work) and times the fc7-shaped product with
 each.  `build` (no GPU needed) writes tools/_bin/libgemm_abl<n>.so; `run` (GPU) loads them through ctypes.
 
@@ -22,7 +23,7 @@ def build():
     for n in MODES:
         out = os.path.join(BIN, 'libgemm_abl%d.so' % n)
         cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-shared',
-               '-Wno-unused-result', '-DGVD_PIPE_ABL=%d' % n] + [os.path.join(SRC, f) for f in (
+               '-Wno-unused-result', '-DGVD_PIPE_LDSDMA=0', '-DGVD_PIPE_ABL=%d' % n] + [os.path.join(SRC, f) for f in (
                    'gemm_f32.hip', 'gemm_pipe.hip', 'gemm_small.hip', 'gemv_f32.hip')] + ['-o', out]
         subprocess.run(cmd, check=True)
         print('built', out, flush=True)

@@ -39,6 +39,15 @@
 #ifndef GVD_PIPE_LDSDMA
 #define GVD_PIPE_LDSDMA 1
 #endif
+// EXPERIMENTAL (default off): the same for the K-STRIDED operands of the backward products.  Verified bitwise equal to the
+// register-staged K-strided path on dX / ragged dX / split dW / ragged dW (tools/gemm_ldsdma_check.py, session AJ), +1 % on
+// dX; not yet run through the training test files, hence not the default.  Such a tile is 32 memory rows (k) of 128 floats; a wave instruction covers
+// two of them (lane l: k row 2 w + 8 i + l / 32, 16-byte slot l % 32), stored unpadded (128 floats per k row) with slot
+// s of k row j holding column chunk s ^ (8 * ((j / 4) & 1)): the two halves of a wave (k rows 4 apart) then read their
+// ds_read_b32 fragments from different banks, as the 132-float rows of the register-staged form arrange.
+#ifndef GVD_PIPE_LDSDMA_T
+#define GVD_PIPE_LDSDMA_T 0
+#endif
 
 namespace {
 
@@ -62,10 +71,13 @@ struct Seg {
 template <bool EPI_LDS, bool AT = false, bool BT = false, bool EDGE = false>
 __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];     // 73,728 B -> two workgroups per CU
-  constexpr bool DMA = (GVD_PIPE_LDSDMA != 0) && !AT && !BT;
-  constexpr int DLD = BK;                        // DMA layout: unpadded rows
+  constexpr bool DMA = (GVD_PIPE_LDSDMA != 0) && ((!AT && !BT) || (GVD_PIPE_LDSDMA_T != 0));
+  constexpr int DLD = BK;                        // DMA layout of a plain operand tile: unpadded rows of 32 floats
+  constexpr int TLD = 128;                       // DMA layout of a K-strided operand tile: unpadded k rows of 128 floats
+  constexpr int A_STRIDE = DMA ? (AT ? BK * TLD : BM * DLD) : BM * LDK;      // floats per LDS buffer of the A / W tile
+  constexpr int W_STRIDE = DMA ? (BT ? BK * TLD : BN * DLD) : BN * LDK;
   float* As = smem;
-  float* Ws = smem + 2 * BM * (DMA ? DLD : LDK);
+  float* Ws = smem + 2 * A_STRIDE;
 
 #if GVD_PIPE_AGPR
   // An inline-asm AGPR operand makes the function "may need AGPRs": the instruction selector then emits the MFMAs in their
@@ -112,7 +124,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   // K-strided operands: thread covers memory rows (k) tk + 8 i, 16-byte column chunk tc (columns = output rows / cols;
   // chunks past the edge are clamped to the last whole chunk - M, N are multiples of 4 there)
   const int tk = tid >> 5, tc = tid & 31;
-  const int acol = min(m0 + 4 * tc, M - 4) - m0, wcol = min(n0 + 4 * tc, p.N - 4) - n0;
+  // (DMA layout: the lane's slot tc of k row tk + 8 i holds column chunk tc ^ 8 ((tk / 4) & 1))
+  const int tcs = DMA ? (tc ^ (((tk >> 2) & 1) * 8)) : tc;
+  const int acol = min(m0 + 4 * tcs, M - 4) - m0, wcol = min(n0 + 4 * tcs, p.N - 4) - n0;
 
   Seg sg;
   int seg = 0, kpos = 0;                                    // position of the NEXT tile to fetch
@@ -182,15 +196,31 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   // 8 w + 32 i .. + 7 (one KiB of LDS, lane l at + 16 l)
   auto dma = [&](int buf) {
     const unsigned so = 4u * (unsigned)kpos;
-    const int w8 = __builtin_amdgcn_readfirstlane(wave) * 8;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    if (AT) {                                   // two k rows of 128 floats per wave instruction
+      const __amdgpu_buffer_rsrc_t ra = gvd_rsrc(pa_t + (int64_t)kpos * lda_t);
 #pragma unroll
-    for (int i = 0; i < NLD; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(sg.ra, (__attribute__((address_space(3))) void*)&As[(buf * BM + w8 + 32 * i) * DLD],
-                                               16, sg.voa[i], so, 0, 0);
+      for (int i = 0; i < NLD; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)&As[buf * A_STRIDE + (2 * wv + 8 * i) * TLD],
+                                                 16, sg.voa[i], 0, 0, 0);
+    } else {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(sg.rw, (__attribute__((address_space(3))) void*)&Ws[(buf * BN + w8 + 32 * i) * DLD],
-                                               16, sg.vow[i], so, 0, 0);
+      for (int i = 0; i < NLD; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(sg.ra, (__attribute__((address_space(3))) void*)&As[buf * A_STRIDE + (8 * wv + 32 * i) * DLD],
+                                                 16, sg.voa[i], so, 0, 0);
+    }
+    if (BT) {
+      const __amdgpu_buffer_rsrc_t rw = gvd_rsrc(pw_t + (int64_t)kpos * ldw_t);
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)&Ws[buf * W_STRIDE + (2 * wv + 8 * i) * TLD],
+                                                 16, sg.vow[i], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(sg.rw, (__attribute__((address_space(3))) void*)&Ws[buf * W_STRIDE + (8 * wv + 32 * i) * DLD],
+                                                 16, sg.vow[i], so, 0, 0);
+    }
     kpos += BK;
     if (kpos == kend && seg + 1 < nseg) {
       ++seg;
@@ -222,17 +252,38 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   static_assert(BK * LDT <= BM * LDK, "a K-strided tile fits the operand buffer");
   const float* Afr = AT ? &As[half * 4 * LDT + rb + r] : &As[(rb + r) * LDK + half * 4];
   const float* Wfr = BT ? &Ws[half * 4 * LDT + cb + r] : &Ws[(cb + r) * LDK + half * 4];
-  // DMA layout: k-chunk 2 q + half of row m sits in slot (2 q + half) ^ (m & 7); rb / cb are multiples of 32, so m & 7 = r & 7
-  const float* Adm = &As[(rb + r) * DLD];
-  const float* Wdm = &Ws[(cb + r) * DLD];
+  // DMA layouts.  Plain tile: k-chunk 2 q + half of row m sits in slot (2 q + half) ^ (m & 7); rb / cb are multiples of
+  // 32, so m & 7 = r & 7.  K-strided tile: value (k row j = 8 q + 4 half + t, column m) sits at j * 128 +
+  // 4 ((m / 4) ^ 8 ((j / 4) & 1)) + m % 4, and (j / 4) & 1 = half.
+  const float* Adm = AT ? &As[half * 4 * TLD + ((((rb + r) >> 2) ^ (half * 8)) << 2) + (r & 3)] : &As[(rb + r) * DLD];
+  const float* Wdm = BT ? &Ws[half * 4 * TLD + ((((cb + r) >> 2) ^ (half * 8)) << 2) + (r & 3)] : &Ws[(cb + r) * DLD];
+  // (second 32-wide block of the wave: +32 columns = +8 chunks, same swizzle bit)
+  const int adm1 = AT ? (((((rb + r) >> 2) + 8) ^ (half * 8)) << 2) - ((((rb + r) >> 2) ^ (half * 8)) << 2) : 32 * DLD;
+  const int wdm1 = BT ? (((((cb + r) >> 2) + 8) ^ (half * 8)) << 2) - ((((cb + r) >> 2) ^ (half * 8)) << 2) : 32 * DLD;
   const int rsw = r & 7;
   auto frags = [&](f32x4 (&a)[2], f32x4 (&b)[2], int buf, int q) {
     if (DMA) {
       const int so4 = ((2 * q + half) ^ rsw) * 4;
-      a[0] = *reinterpret_cast<const f32x4*>(Adm + buf * BM * DLD + so4);
-      a[1] = *reinterpret_cast<const f32x4*>(Adm + buf * BM * DLD + 32 * DLD + so4);
-      b[0] = *reinterpret_cast<const f32x4*>(Wdm + buf * BN * DLD + so4);
-      b[1] = *reinterpret_cast<const f32x4*>(Wdm + buf * BN * DLD + 32 * DLD + so4);
+      if (AT) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          a[0][t] = Adm[buf * A_STRIDE + (q * 8 + t) * TLD];
+          a[1][t] = Adm[buf * A_STRIDE + (q * 8 + t) * TLD + adm1];
+        }
+      } else {
+        a[0] = *reinterpret_cast<const f32x4*>(Adm + buf * A_STRIDE + so4);
+        a[1] = *reinterpret_cast<const f32x4*>(Adm + buf * A_STRIDE + adm1 + so4);
+      }
+      if (BT) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          b[0][t] = Wdm[buf * W_STRIDE + (q * 8 + t) * TLD];
+          b[1][t] = Wdm[buf * W_STRIDE + (q * 8 + t) * TLD + wdm1];
+        }
+      } else {
+        b[0] = *reinterpret_cast<const f32x4*>(Wdm + buf * W_STRIDE + so4);
+        b[1] = *reinterpret_cast<const f32x4*>(Wdm + buf * W_STRIDE + wdm1 + so4);
+      }
       __builtin_amdgcn_sched_barrier(0);
       return;
     }

@@ -304,8 +304,8 @@ class TopDownModel(nn.Module):
         residual LayerNorms are fused row kernels forward and backward.  Pad rows never reach the loss (their gradients
         are exactly zero) and are masked out of every softmax."""
         B, R, d = x.shape
-        nh, HP = 6, ops.TRAIN_HEAD_PAD
         Rp = -(-R // 32) * 32
+        nh, HP = 6, ops.train_head_pad(B, Rp, 6)
         sizes = [t.shape[-1] for t in x.reshape(-1, d)[:1].chunk(nh, -1)]
         starts = [sum(sizes[:i]) for i in range(nh)]
         idx = torch.cat([torch.arange(sizes[h]) + h * HP for h in range(nh)]).to(x.device)

@@ -21,6 +21,7 @@ struct KParams {
   const int* m_dev;      // when set: the row count is read on the device (<= M; tiles past it exit)
   const int* a_rmap;     // when set (pipelined kernel, one segment): output row m reads row a_rmap[m] of A
   int a_t, w_t;          // operand is K-strided: A given as [K, M] (lda >= M), W as [K, N] (ldw >= N)
+  int ktail;             // pipelined kernel, direct-to-LDS plain products, one segment: K % 32 == 16 (see gemm_pipe.hip)
   int binner;            // two-level batch: b = outer * binner + inner (0 / 1 = flat)
   int64_t abs2, wbs2, cbs2;   // inner strides of A / W (every segment) / C
   // LSTM epilogue
@@ -78,6 +79,7 @@ __device__ __forceinline__ void gemm_epilogue_plain(const KParams& p, int M, con
 
 // gemm_pipe.hip
 int gvd_gemm_pipe_launch(KParams& p, int batch, hipStream_t st);
+bool gvd_gemm_pipe_takes_ktail();      // built with the direct-to-LDS plain path (the only one with the K tail of 16)
 // gemm_small.hip: pipelined 64 x 64 kernel for the token-loop products (plain / LSTM-cell epilogue)
 bool gvd_gemm_small_ok(const KParams& p, int batch);
 int gvd_gemm_small_launch(KParams& p, bool lstm, hipStream_t st);

@@ -224,8 +224,14 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
   if (!a || a->nseg < 1 || a->nseg > 3 || !a->C || a->M <= 0 || a->N <= 0 || a->batch <= 0) return GVD_EINVAL;
   KParams p = {};
   p.nseg = a->nseg;
+  // one plain segment with K % 32 == 16 (K >= 48) is taken by the pipelined kernel's shifted tail tile, and only by it
+  const long big_tiles = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
+  const bool ktail = a->nseg == 1 && (a->seg[0].K % BK_MIN) == 16 && a->seg[0].K >= 48 && !a->a_kstrided && !a->w_kstrided &&
+                     a->M > 32 && big_tiles >= 256 && gvd_gemm_pipe_takes_ktail();
   for (int s = 0; s < a->nseg; ++s) {
-    if (!seg_ok(a->seg[s])) return GVD_EINVAL;
+    gvd_gemm_seg sg = a->seg[s];
+    if (ktail) sg.K += 16;                      // (passes the 32-multiple check below; the kernel gets the real K)
+    if (!seg_ok(sg)) return GVD_EINVAL;
     p.A[s] = a->seg[s].A; p.lda[s] = a->seg[s].lda; p.abs_[s] = a->seg[s].a_batch_stride;
     p.W[s] = a->seg[s].W; p.ldw[s] = a->seg[s].ldw; p.wbs[s] = a->seg[s].w_batch_stride;
     p.K[s] = a->seg[s].K;
@@ -237,6 +243,7 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
   p.C = a->C; p.ldc = a->ldc; p.cbs = a->c_batch_stride;
   p.M = a->M; p.N = a->N; p.act = a->act; p.m_dev = a->m_dev;
   p.a_t = a->a_kstrided; p.w_t = a->w_kstrided;
+  p.ktail = ktail ? 1 : 0;                      // (set before any route to the pipelined kernel, incl. the row-gather one)
   if (a->batch_inner > 1) {
     if (a->batch % a->batch_inner || a->mbias || a->rowbias || a->mask || a->a_row_map || (a->a_inner_stride % 4) ||
         (a->w_inner_stride % 4) || (a->c_inner_stride % 4))
@@ -253,6 +260,7 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
     return gvd_gemm_pipe_launch(p, a->batch, st);
   }
   if (p.a_t || p.w_t) return gvd_gemm_pipe_launch(p, a->batch, st);      // backward products: pipelined kernel only
+  if (ktail) return gvd_gemm_pipe_launch(p, a->batch, st);
   if (a->M <= 16 && a->batch == 1 && !a->mbias && !a->mask && !a->m_dev) {   // decode batch: weight-streaming skinny kernel
     GemvParams v = {};
     v.nseg = a->nseg;

@@ -162,6 +162,12 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
 #pragma unroll
   for (int s = 0; s < 3; ++s)
     if (s < p.nseg) nkt += p.K[s] / BK;
+  // K TAIL OF 16 (EXPERIMENTAL, host sets p.ktail only for one-segment plain products on the direct-to-LDS path; used by the
+  // training attention core with 176-column head slots, GVD_TRAIN_HEAD_PAD=176): the last tile is fetched SHIFTED BACK by 16
+  // columns (k = K-32 .. K-1: always inside the operand rows, never past them) and only its last two quarters are
+  // multiplied - the first two repeat columns the previous tile already covered.  Same ascending k order per output.
+  const bool ktail = DMA && p.ktail != 0;
+  if (ktail) ++nkt;
 
   f32x4 ga[NLD], gw[NLD];
   auto fetch = [&]() {
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   // direct global -> LDS loads of the tile at kpos into buffer `buf` (DMA layout): wave w's instruction i covers tile rows
   // 8 w + 32 i .. + 7 (one KiB of LDS, lane l at + 16 l)
   auto dma = [&](int buf) {
-    const unsigned so = 4u * (unsigned)kpos;
+    const unsigned so = 4u * (unsigned)((ktail && kpos + BK > kend) ? kend - BK : kpos);
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     if (AT) {                                   // two k rows of 128 floats per wave instruction
       const __amdgpu_buffer_rsrc_t ra = gvd_rsrc(pa_t + (int64_t)kpos * lda_t);
@@ -344,7 +350,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
       frags(a1, b1, buf, 3);
       mfma16(a0, b0);
       __syncthreads();
-      frags(a0, b0, buf ^ 1, 0);
+      if (ktail && kt + 2 == nkt) frags(a0, b0, buf ^ 1, 2);     // the shifted tail tile starts at its third quarter
+      else frags(a0, b0, buf ^ 1, 0);
       mfma16(a1, b1);
       buf ^= 1;
     }
@@ -375,13 +382,19 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
     buf ^= 1;
   }
   }
-  frags(a1, b1, buf, 1);
-  mfma16(a0, b0);
-  frags(a0, b0, buf, 2);
-  mfma16(a1, b1);
-  frags(a1, b1, buf, 3);
-  mfma16(a0, b0);
-  mfma16(a1, b1);
+  if (ktail) {                      // last tile = columns K-32 .. K-1: quarters 2 and 3 are the 16 new ones
+    frags(a1, b1, buf, 3);
+    mfma16(a0, b0);
+    mfma16(a1, b1);
+  } else {
+    frags(a1, b1, buf, 1);
+    mfma16(a0, b0);
+    frags(a0, b0, buf, 2);
+    mfma16(a1, b1);
+    frags(a1, b1, buf, 3);
+    mfma16(a0, b0);
+    mfma16(a1, b1);
+  }
 
   if (GVD_PIPE_ABL & 8) {       // keep the accumulators alive without storing a tile
     float sacc = 0.f;
@@ -449,6 +462,8 @@ int pipe_launch_t(const KParams& p, dim3 grid, bool lds_epi, hipStream_t st) {
   return 0;
 }
 }  // namespace
+
+bool gvd_gemm_pipe_takes_ktail() { return GVD_PIPE_LDSDMA != 0; }
 
 int gvd_gemm_pipe_launch(KParams& p, int batch, hipStream_t st) {
   p.ntm = (p.M + BM - 1) / BM;

@@ -705,6 +705,15 @@ def add_layernorm(x, y, gamma, beta, eps=1e-6):
 TRAIN_HEAD_PAD = 192      # training attention core: heads zero-padded to a multiple of the GEMM's 32-deep k tile
 
 
+def train_head_pad(B, Rp, n_heads):
+    """Head slot width of the training attention core.  192 (six whole 32-deep k tiles).  EXPERIMENTAL, GVD_TRAIN_HEAD_PAD=176:
+    176-column slots as in inference (8 % fewer flops in the q|k|v / wo projections and the six attention products) for
+    launches the pipelined GEMM's K-tail-of-16 path takes (>= 256 tiles); not yet verified on the device."""
+    if os.environ.get('GVD_TRAIN_HEAD_PAD', '') == '176' and B * n_heads * (-(-Rp // 128)) ** 2 >= 256:
+        return 176
+    return TRAIN_HEAD_PAD
+
+
 def _bgemm(A, a_off, lda, a_bs, W, w_off, ldw, w_bs, K, Cout, c_off, ldc, c_bs, M, N, batch, a_t=0, w_t=0, what='bgemm',
            inner=0, a_is=0, w_is=0, c_is=0):
     """One batched launch of the MFMA GEMM on sub-blocks of larger tensors (element offsets into A / W / Cout).
@@ -747,7 +756,7 @@ class _EncAttnCoreFn(torch.autograd.Function):
         assert qkv.is_contiguous()
         B, Rp, W3 = qkv.shape
         HP = W3 // (3 * nh)
-        assert W3 == 3 * nh * HP and HP % 32 == 0 and Rp % 32 == 0 and R % 4 == 0 and 4 <= R <= Rp
+        assert W3 == 3 * nh * HP and HP % 16 == 0 and Rp % 32 == 0 and R % 4 == 0 and 4 <= R <= Rp
         dev = qkv.device
         Y = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
         ko, vo = nh * HP, 2 * nh * HP

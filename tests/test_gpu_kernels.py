@@ -746,6 +746,34 @@ def test_enc_attn_core_training_matches_autograd(B, R, monkeypatch):
     assert torch.equal(o1, o2) and not torch.equal(o1, O.detach())
 
 
+@pytest.mark.skipif(os.environ.get('GVD_TEST_EXPERIMENTAL') != '1', reason='experimental K-tail path: opt in with GVD_TEST_EXPERIMENTAL=1')
+def test_enc_attn_core_176_column_head_slots():
+    """EXPERIMENTAL: the training attention core over 176-column head slots (K = 176 contractions through the pipelined GEMM's
+    shifted tail tile) equals the 192-slot form up to fp32 rounding - output and gradient."""
+    g = _g(41)
+    B, R, nh, d = 2, 1000, 6, 1024
+    Rp = -(-R // 32) * 32
+    sizes = [t.shape[-1] for t in torch.zeros(1, d).chunk(nh, -1)]
+    vals = [torch.randn(B, Rp, 3, sizes[h], generator=g) for h in range(nh)]
+    dO_h = [torch.randn(B, Rp, sizes[h], generator=g) for h in range(nh)]
+    res = {}
+    for HP in (192, 176):
+        qkv = torch.zeros(B, Rp, 3, nh, HP)
+        dO = torch.zeros(B, Rp, nh, HP)
+        for h in range(nh):
+            qkv[:, :, :, h, :sizes[h]] = vals[h]
+            dO[:, :R, h, :sizes[h]] = dO_h[h][:, :R]
+        qkv = qkv.reshape(B, Rp, 3 * nh * HP).cuda().requires_grad_(True)
+        O = ops.enc_attn_core(qkv, R, nh, 1.0 / 32, 0.0)
+        O.backward(dO.reshape(B, Rp, nh * HP).cuda())
+        res[HP] = (O.detach().view(B, Rp, nh, HP), qkv.grad.view(B, Rp, 3, nh, HP))
+    for h in range(nh):
+        a, b = res[192][0][:, :, h, :sizes[h]], res[176][0][:, :, h, :sizes[h]]
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+        ga, gb = res[192][1][:, :, :, h, :sizes[h]], res[176][1][:, :, :, h, :sizes[h]]
+        assert float((ga - gb).abs().max()) <= 3e-5 * float(ga.abs().max())
+
+
 def test_encoder_training_paths_agree(monkeypatch):
     """The all-MFMA training encoder (padded region axis, packed projection, fused LayerNorm backward) against the
     per-head library formulation in eval mode with gradients on: output and parameter gradients."""

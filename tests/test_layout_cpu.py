@@ -76,3 +76,18 @@ def test_kstrided_tile_loader_and_fragment_reads_agree():
     for rb, q, t in itertools.product((0, 64), range(4), range(4)):
         banks = [(((rb + r) >> 2) ^ (half * 8)) * 4 + ((rb + r) & 3) for half in range(2) for r in range(32)]
         assert len({b % 64 for b in banks}) == 64
+
+
+def test_shifted_tail_tile_covers_every_k_once():
+    """K % 32 == 16 on the direct-to-LDS path (experimental): full tiles cover k < K - 16; the last tile is fetched from
+    K - 32 and only its quarters 2 and 3 (columns 16 .. 31 of the tile) are multiplied: every k exactly once, ascending."""
+    for K in (48, 176, 208, 1040):
+        nfull = K // 32
+        order = []
+        for kt in range(nfull):
+            for q in range(4):
+                order += [kt * 32 + 8 * q + j for j in range(8)]
+        base = K - 32                                  # the tail tile's first column (inside the operand row)
+        for q in (2, 3):
+            order += [base + 8 * q + j for j in range(8)]
+        assert order == list(range(K))

@@ -1,5 +1,7 @@
 """-m gpu: every HIP kernel (called through the C-ABI wrappers) against the CPU oracle on seeded inputs.
 Integer / index / boolean outputs must be bit-exact; fp32 outputs within the stated tolerance."""
+import os
+
 import numpy as np
 import pytest
 import torch

@@ -8,11 +8,13 @@ hot path runs in hand-written HIP kernels (libgvd_hip.so) instead of chains of A
     seq, att2_weights, sim_mat = model(..., 'sample', {'sample_max': 1, 'beam_size': 1})
     cls_pred, att2_ind, grd_ind = model(..., 'GRD')
 
-What runs where (DESIGN.md has the table): the per-token step (two LSTM cells, both additive
-attentions, vocabulary head and token rule), the fc7 / attn_hid / logit / grounder projections and
-the target/loss reductions are HIP kernels; the remaining per-segment preamble (layer norms,
-pool_embed, obj_interact encoder, bi-GRU) currently uses torch-ROCm library ops (rocBLAS/MIOpen) and
-is scheduled as the "next" rows of SURVEY.md §8f.  There is no CPU path: inputs must live on the GPU.
+What runs where (DESIGN.md §2 has the table): the per-token step (two LSTM cells, both additive
+attentions, vocabulary head and token rule), every projection of the per-segment preamble (fc7,
+class similarity, pool_embed, the obj_interact encoder incl. its flash-style attention, ctx2pool /
+ctx2att, frame embeddings), the bi-GRU frame encoder, the row kernels (class softmax, layer norms),
+the target / loss reductions and the whole backward pass are hand-written HIP kernels of
+libgvd_hip.so; torch-ROCm library ops remain only for BatchNorm1d, the dropout masks and the fused
+Adam.  There is no CPU path: inputs must live on the GPU.
 
 Supported configuration = the reference's README recipe (att_model='topdown', att_input_mode='both',
 region_attn_mode='mix', transfer_mode='cls', t_attn_mode='bigru', seq_per_img=1, enable_BUTD=False).
@@ -50,7 +52,10 @@ class _EncLayerNorm(nn.Module):
         return self.gamma * (x - mean) / (std + self.eps) + self.beta
 
 
-def _build_obj_interact(d_model, d_hidden, n_layers):
+def _build_obj_interact(d_model, d_hidden, n_layers, drop_ratio=0.2):
+    """Parameter tree of transformer.Transformer as built at model.py:126-135.  The nn.Dropout modules sit where the
+    reference has them (ResidualBlock.dropout, transformer.py:84; Attention.dropout, transformer.py:95) so that code
+    which walks `model.modules()` to change dropout ratios reaches the same places; they hold no parameters."""
     root = _Holder()
     root.encoder = _Holder()
     layers = []
@@ -60,11 +65,15 @@ def _build_obj_interact(d_model, d_hidden, n_layers):
         lay.selfattn.layer = _Holder()
         for n in ('wq', 'wk', 'wv', 'wo'):
             setattr(lay.selfattn.layer, n, nn.Linear(d_model, d_model, bias=False))
+        lay.selfattn.layer.attention = _Holder()
+        lay.selfattn.layer.attention.dropout = nn.Dropout(drop_ratio)
+        lay.selfattn.dropout = nn.Dropout(drop_ratio)
         lay.selfattn.layernorm = _EncLayerNorm(d_model)
         lay.feedforward = _Holder()
         lay.feedforward.layer = _Holder()
         lay.feedforward.layer.linear1 = nn.Linear(d_model, d_hidden)
         lay.feedforward.layer.linear2 = nn.Linear(d_hidden, d_model)
+        lay.feedforward.dropout = nn.Dropout(drop_ratio)
         lay.feedforward.layernorm = _EncLayerNorm(d_model)
         layers.append(lay)
     root.encoder.layers = nn.ModuleList(layers)
@@ -311,9 +320,9 @@ class TopDownModel(nn.Module):
         idx = torch.cat([torch.arange(sizes[h]) + h * HP for h in range(nh)]).to(x.device)
         idx3 = torch.cat([idx + j * nh * HP for j in range(3)])
         xp = F.pad(x, (0, 0, 0, Rp - R)).reshape(B * Rp, d)
-        p_drop = 0.2 if self.training else 0.0
         for lay in self.obj_interact.encoder.layers:
             sa = lay.selfattn.layer
+            p_drop = sa.attention.dropout.p if self.training else 0.0
             w_qkv = torch.zeros(3 * nh * HP, d, device=x.device, dtype=torch.float32).index_copy(
                 0, idx3, torch.cat([sa.wq.weight, sa.wk.weight, sa.wv.weight], 0))
             w_o = torch.zeros(d, nh * HP, device=x.device, dtype=torch.float32).index_copy(1, idx, sa.wo.weight)
@@ -321,9 +330,9 @@ class TopDownModel(nn.Module):
             o = ops.enc_attn_core(qkv, R, nh, 1.0 / scale, p_drop)
             att = ops.linear(o.view(B * Rp, nh * HP), w_o)
             ff = lay.feedforward.layer
-            xp = self._add_ln(xp, F.dropout(att, 0.2, self.training), lay.selfattn.layernorm)
+            xp = self._add_ln(xp, F.dropout(att, lay.selfattn.dropout.p, self.training), lay.selfattn.layernorm)
             y = self._lin(self._lin(xp, ff.linear1, act=1), ff.linear2)
-            xp = self._add_ln(xp, F.dropout(y, 0.2, self.training), lay.feedforward.layernorm)
+            xp = self._add_ln(xp, F.dropout(y, lay.feedforward.dropout.p, self.training), lay.feedforward.layernorm)
         return xp.view(B, Rp, d)[:, :R]
 
     def _obj_interact_fused(self, x, ci=None):
@@ -457,7 +466,7 @@ class TopDownModel(nn.Module):
                 for qh, kh, vh in zip(q.chunk(6, -1), k.chunk(6, -1), v.chunk(6, -1)):
                     dots = torch.matmul(qh, kh.transpose(1, 2))
                     w = F.softmax(dots if exact else dots / scale, dim=-1)
-                    heads.append(torch.matmul(F.dropout(w, 0.2, self.training), vh))
+                    heads.append(torch.matmul(F.dropout(w, sa.attention.dropout.p, self.training), vh))
             att = self._lin(heads[0] if len(heads) == 1 else torch.cat(heads, -1), sa.wo)
             ff = lay.feedforward.layer
             if fused:   # inference: residual add + custom LayerNorm as one HIP row kernel
@@ -469,9 +478,9 @@ class TopDownModel(nn.Module):
             else:
                 # ResidualBlock (transformer.py:79-88): dropout on the branch, then add + LayerNorm as one fused row
                 # kernel forward and one backward
-                x = self._add_ln(x, F.dropout(att, 0.2, self.training), lay.selfattn.layernorm)
+                x = self._add_ln(x, F.dropout(att, lay.selfattn.dropout.p, self.training), lay.selfattn.layernorm)
                 y = self._lin(self._lin(x, ff.linear1, act=1), ff.linear2)
-                x = self._add_ln(x, F.dropout(y, 0.2, self.training), lay.feedforward.layernorm)
+                x = self._add_ln(x, F.dropout(y, lay.feedforward.dropout.p, self.training), lay.feedforward.layernorm)
         return x
 
     def _preamble(self, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, allow_compact=False):
@@ -498,7 +507,7 @@ class TopDownModel(nn.Module):
         g_pool = self._drop(self._lin(ppls_feat, self.ctx2pool_grd[0], act=1))
         vis_word = self._drop(F.relu(self.vis_embed[0].weight))
         loc_in = torch.cat([ppls[:, :, :4] / 720., (ppls[:, :, 4] * 1. / self.num_sampled_frm).unsqueeze(-1)], dim=2)
-        loc = F.dropout(self._lin_k32(loc_in, self.loc_fc[0], act=1), 0.5, self.training)
+        loc = F.dropout(self._lin_k32(loc_in, self.loc_fc[0], act=1), self.loc_fc[2].p, self.training)
         pool_done = False
         if not torch.is_grad_enabled():
             # inference: class-last similarity logits from ONE plain MFMA GEMM (the visual words are shared by the

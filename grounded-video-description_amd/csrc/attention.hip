@@ -76,10 +76,9 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
 
   // ---- phase 1: scores.  lane owns columns [4*lane, 4*lane+4) and [256+4*lane, ...+4) of A = 512
   const float* qb = S.q + (int64_t)b * S.ldq;
-  const f32x4 q0 = *reinterpret_cast<const f32x4*>(qb + 4 * lane);
-  const f32x4 q1 = *reinterpret_cast<const f32x4*>(qb + 256 + 4 * lane);
-  const f32x4 w0 = *reinterpret_cast<const f32x4*>(S.w + 4 * lane);
-  const f32x4 w1 = *reinterpret_cast<const f32x4*>(S.w + 256 + 4 * lane);
+  const f32x4 q0 = GVD_TWO_LOG2E * *reinterpret_cast<const f32x4*>(qb + 4 * lane);         // pre-scaled: see tanh_fast
+  const f32x4 q1 = GVD_TWO_LOG2E * *reinterpret_cast<const f32x4*>(qb + 256 + 4 * lane);
+  const AttnLaneW W = attn_lane_w(S.w, lane);
   const float ab = *S.alpha_bias;
   const int fbi = S.group > 1 ? b / S.group : b;   // beams of one sample share its features
   // compacted features (masked-proposal compaction, csrc/compact.hip): the side's rows are looked up through row_map in
@@ -122,14 +121,8 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
     f32x4 x01 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane));
     f32x4 x10 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 4 * lane));
     f32x4 x11 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 256 + 4 * lane));
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      s0 = fmaf(w0[k], tanhf(x00[k] + q0[k]), s0);
-      s0 = fmaf(w1[k], tanhf(x01[k] + q1[k]), s0);
-      s1 = fmaf(w0[k], tanhf(x10[k] + q0[k]), s1);
-      s1 = fmaf(w1[k], tanhf(x11[k] + q1[k]), s1);
-    }
+    float s0 = attn_score_lane(x00, x01, q0, q1, W);
+    float s1 = attn_score_lane(x10, x11, q0, q1, W);
     s0 = wave_sum(s0) + ab;
     s1 = wave_sum(s1) + ab;
     if (lane == 0) {
@@ -213,14 +206,13 @@ __global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams
   const int n0 = c * S.chunk;
   const int rows = min(S.chunk, S.N - n0);
 
-  const f32x4 w0 = *reinterpret_cast<const f32x4*>(S.w + 4 * lane);
-  const f32x4 w1 = *reinterpret_cast<const f32x4*>(S.w + 256 + 4 * lane);
-  f32x4 q0[G], q1[G];
+  const AttnLaneW W = attn_lane_w(S.w, lane);
+  f32x4 q0[G], q1[G];                             // pre-scaled queries (tanh_fast, gvd_common.h)
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const float* qb = S.q + (int64_t)(smp * G + g) * S.ldq;
-    q0[g] = *reinterpret_cast<const f32x4*>(qb + 4 * lane);
-    q1[g] = *reinterpret_cast<const f32x4*>(qb + 256 + 4 * lane);
+    q0[g] = GVD_TWO_LOG2E * *reinterpret_cast<const f32x4*>(qb + 4 * lane);
+    q1[g] = GVD_TWO_LOG2E * *reinterpret_cast<const f32x4*>(qb + 256 + 4 * lane);
   }
   const float ab = *S.alpha_bias;
   const float* pf = S.p_feats + ((int64_t)smp * S.N + n0) * ATT_A;
@@ -261,15 +253,7 @@ __global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams
     const f32x4 x1 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane));
     float sc[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float a = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        a = fmaf(w0[k], tanhf(x0[k] + q0[g][k]), a);
-        a = fmaf(w1[k], tanhf(x1[k] + q1[g][k]), a);
-      }
-      sc[g] = wave_sum(a) + ab;
-    }
+    for (int g = 0; g < G; ++g) sc[g] = wave_sum(attn_score_lane(x0, x1, q0[g], q1[g], W)) + ab;
     if (lane < G) {
       float e = 0.f;
 #pragma unroll
@@ -429,6 +413,11 @@ __global__ __launch_bounds__(256 * NG) void attn_combine_kernel(const CombParams
   if (grp == 0 && p.out_sum) *reinterpret_cast<f32x4*>(p.out_sum + (int64_t)b * p.ld_out + 4 * t) = total;
 }
 
+__global__ void tanh_fast_kernel(const float* x, float* y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = tanh_fast(x[i]);
+}
+
 // rows per chunk: 50; halved (not below 13) while fewer than ~512 workgroups would exist (small batches)
 int tune_int(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -462,6 +451,13 @@ void fill_side(SideDev& d, const gvd_attn_side* s, int B) {
 }
 
 }  // namespace
+
+extern "C" int gvd_tanh_fast_f32(const float* x, float* y, int64_t n, gvd_stream_t stream) {
+  if (!x || !y || n <= 0) return GVD_EINVAL;
+  hipLaunchKernelGGL(tanh_fast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, gvd_s(stream), x, y, n);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" size_t gvd_attn_workspace_bytes(int B, int n_region, int n_temporal, int H) {
   long nc = nchunks_of(n_region, B) + (n_temporal > 0 ? nchunks_of(n_temporal, B) : 0);

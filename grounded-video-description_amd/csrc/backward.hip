@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void attn_bwd_step_kernel(const BwdStepParams 
     dab += de;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float t0 = tanhf(x0[k] + q0[k]), t1 = tanhf(x1[k] + q1[k]);
+      const float t0 = tanh_fast(x0[k] + q0[k]), t1 = tanh_fast(x1[k] + q1[k]);
       dq0[k] = fmaf(de * w0[k], 1.f - t0 * t0, dq0[k]);
       dq1[k] = fmaf(de * w1[k], 1.f - t1 * t1, dq1[k]);
       dw0[k] = fmaf(de, t0, dw0[k]);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_bwd_pfeats_kernel(const BwdPfParams 
       const f32x4 q1 = *reinterpret_cast<const f32x4*>(s_q + t * ATT_A + 256 + 4 * lane);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float t0 = tanhf(x0[k] + q0[k]), t1 = tanhf(x1[k] + q1[k]);
+        const float t0 = tanh_fast(x0[k] + q0[k]), t1 = tanh_fast(x1[k] + q1[k]);
         a0[k] = fmaf(de * w0[k], 1.f - t0 * t0, a0[k]);
         a1[k] = fmaf(de * w1[k], 1.f - t1 * t1, a1[k]);
       }

@@ -276,9 +276,10 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
       const float* wv = tmp ? p.a1_w : p.a2_w;
       const float ab = tmp ? *p.a1_b : *p.a2_b;
       const unsigned qoff = (unsigned)(b * 2 * PD_A + (tmp ? 0 : PD_A)) * 4;
-      const f32x4 q0 = ld_agent_x4(rs_q, qoff + 16 * lane), q1 = ld_agent_x4(rs_q, qoff + 1024 + 16 * lane);
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wv + 4 * lane);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(wv + 256 + 4 * lane);
+      // pre-scaled queries / folded weights of tanh_fast (gvd_common.h): same arithmetic as attn_partial_kernel
+      const f32x4 q0 = GVD_TWO_LOG2E * ld_agent_x4(rs_q, qoff + 16 * lane);
+      const f32x4 q1 = GVD_TWO_LOG2E * ld_agent_x4(rs_q, qoff + 1024 + 16 * lane);
+      const AttnLaneW W = attn_lane_w(wv, lane);
       const uint8_t* am = tmp ? nullptr : p.pnt_mask + (int64_t)b * (R + 1) + 1 + n0;
       float* lo = tmp ? nullptr : p.att2_weights + ((int64_t)b * L + t) * R + n0;
       // context phase role: thread = (4 columns of H = 1024, row parity).  Its first 4 feature rows do not depend on
@@ -300,14 +301,8 @@ __global__ __launch_bounds__(PD_NT, 2) void greedy_persistent_kernel(const PdPar
         const f32x4 x01 = *reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane);
         const f32x4 x10 = *reinterpret_cast<const f32x4*>(p1 + 4 * lane);
         const f32x4 x11 = *reinterpret_cast<const f32x4*>(p1 + 256 + 4 * lane);
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          s0 = fmaf(w0[k], tanhf(x00[k] + q0[k]), s0);
-          s0 = fmaf(w1[k], tanhf(x01[k] + q1[k]), s0);
-          s1 = fmaf(w0[k], tanhf(x10[k] + q0[k]), s1);
-          s1 = fmaf(w1[k], tanhf(x11[k] + q1[k]), s1);
-        }
+        float s0 = attn_score_lane(x00, x01, q0, q1, W);
+        float s1 = attn_score_lane(x10, x11, q0, q1, W);
         s0 = wave_sum(s0) + ab;
         s1 = wave_sum(s1) + ab;
         if (lane == 0) {

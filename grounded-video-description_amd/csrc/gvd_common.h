@@ -29,6 +29,55 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// tanh of the additive-attention scores  e[n] = sum_k w_k tanh(p_feats[n,k] + q_k)   (AttModel.py:39-45, 84-90).
+// ocml's tanhf is 29 VALU instructions (two of them quarter-rate); with 512 evaluations per streamed 6 KB row - and G
+// times that in the beam-grouped kernel - the score pass was VALU-bound, not HBM-bound.  Here
+//     tanh(s) = 1 - 2 r,   r = 1 / (1 + 2^(2 log2(e) s))
+// on the hardware v_exp_f32 / v_rcp_f32 (1 ulp each): |error| <= 2.5e-7 absolute over the whole real line (measured
+// on the device by tests/test_gpu_kernels.py::test_tanh_fast_error_bound; 1.9e-7 in an fp32 emulation), saturating
+// exactly to +-1 (2^y -> inf / 0), NaN-propagating.  The score kernels fold the constants into per-lane registers:
+//     sum_k w_k tanh(x_k + q_k) = sum_k w_k + sum_k (-2 w_k) r_k,   r_k = rcp(1 + exp2(fma(x_k, C, C q_k)))
+// = fma + v_exp + add + v_rcp + fma per element (11 issue slots instead of 31).  Every forward score kernel
+// (attn_partial_kernel, attn_partial_group_kernel, the persistent decoder) uses attn_score_fma in the same k order,
+// so they stay bitwise interchangeable.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr float GVD_TWO_LOG2E = 2.8853900817779268f;
+__device__ __forceinline__ float tanh_fast(float s) {
+  const float e = __builtin_amdgcn_exp2f(s * GVD_TWO_LOG2E);
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+}
+// acc + (-2 w) / (1 + exp2(x C + qs)),  qs = C q,  wn = -2 w
+__device__ __forceinline__ float attn_score_fma(float x, float qs, float wn, float acc) {
+  const float e = __builtin_amdgcn_exp2f(fmaf(x, GVD_TWO_LOG2E, qs));
+  return fmaf(wn, __builtin_amdgcn_rcpf(1.0f + e), acc);
+}
+typedef float gvd_score_f32x4 __attribute__((ext_vector_type(4)));
+// per-lane constants of a score pass: the lane owns columns [4 lane, +4) and [256 + 4 lane, +4) of A = 512
+struct AttnLaneW {
+  gvd_score_f32x4 wn0, wn1;   // -2 w
+  float wsum;                 // sum of the lane's 8 w values (the "1" of every 1 - 2 r)
+};
+__device__ __forceinline__ AttnLaneW attn_lane_w(const float* w, int lane) {
+  const gvd_score_f32x4 w0 = *reinterpret_cast<const gvd_score_f32x4*>(w + 4 * lane);
+  const gvd_score_f32x4 w1 = *reinterpret_cast<const gvd_score_f32x4*>(w + 256 + 4 * lane);
+  AttnLaneW o;
+  o.wn0 = -2.0f * w0; o.wn1 = -2.0f * w1;
+  o.wsum = ((w0[0] + w1[0]) + (w0[1] + w1[1])) + ((w0[2] + w1[2]) + (w0[3] + w1[3]));
+  return o;
+}
+// one row's lane-partial score (before the wave reduction): x0 / x1 = the lane's two 16-byte slices of the projection row
+__device__ __forceinline__ float attn_score_lane(gvd_score_f32x4 x0, gvd_score_f32x4 x1, gvd_score_f32x4 qs0,
+                                                 gvd_score_f32x4 qs1, const AttnLaneW& W) {
+  float s = W.wsum;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    s = attn_score_fma(x0[k], qs0[k], W.wn0[k], s);
+    s = attn_score_fma(x1[k], qs1[k], W.wn1[k], s);
+  }
+  return s;
+}
+
 // XCD-aware bijective remap of a linear workgroup id (cdna_hip_programming.md T1): hardware round-robins
 // consecutive ids over the 8 XCDs; after the remap each XCD walks a contiguous chunk of logical ids so
 // neighbouring tiles (which share an operand panel) hit the same private L2.

@@ -96,6 +96,7 @@ _SIG = {
                                     c_f32p, C.c_int64, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'gvd_gemm_nt_f32': (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     'gvd_lstm_cell_fwd': (C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),
+    'gvd_tanh_fast_f32': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     'gvd_attn_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'gvd_attn_fwd': (C.c_int, [C.POINTER(AttnSide), C.POINTER(AttnSide), C.c_int, C.c_int, C.c_int,
                                c_f32p, C.c_int64, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
@@ -158,7 +159,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 6        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 7        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 6
+#define GVD_ABI_VERSION 7
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -149,6 +149,12 @@ typedef struct {
   int group;   /* 0/1: feats/p_feats have one entry per row b.  K>1: rows b share entry b/K (the K beams of a
                   sample attend over ONE copy of its features: feats/p_feats are [B/K,N,*]) */
 } gvd_attn_side;
+
+/* y[i] = the kernels' tanh (csrc/gvd_common.h: tanh_fast = 1 - 2 / (1 + 2^(2 log2(e) x)) on v_exp_f32 / v_rcp_f32,
+ * absolute error <= 2.5e-7) - exported so that the error bound the score kernels rely on is measured on the device
+ * (tests/test_gpu_kernels.py::test_tanh_fast_error_bound).  Replaces torch.tanh inside Attention.forward /
+ * Attention2.forward (AttModel.py:45, 90). */
+int gvd_tanh_fast_f32(const float* x, float* y, int64_t n, gvd_stream_t stream);
 
 /* Both attentions of one decoder step in one pass over HBM.
  * out_sum[b,:] = ctx_region + ctx_temporal (the `att+att2` input of the language LSTM, AttModel.py:148);

@@ -45,8 +45,14 @@ CASES = {
     # norms of the gradient AVERAGED over the shards = what nn.DataParallel's backward (main.py:654-655, loss .sum() /
     # numel()) and a gradient all-reduce(sum)/N produce (mean over replicas of per-replica means)
     'dp8x32_v5000_ft10_trained': dict(mode='dp', B=256, shards=8, V=5000, Ft=10, seed=13, profile='trained_like'),
-    # BASELINE configs[2]: training step batch 64 (losses only)
+    # BASELINE configs[2]: training step batch 64 (losses + gradient projections)
     'mle_b64_v5000_ft10_trained': dict(mode='MLE', B=64, V=5000, Ft=10, seed=5, profile='trained_like'),
+    # TRAIN mode with every dropout ratio 0 (opt.drop_prob_lm = 0; loc_fc / encoder / GRU dropout set to 0 on the built
+    # model): BatchNorm1d of the frame embeddings normalises with BATCH statistics and updates its running statistics
+    # (model.py:114,397) - deterministic on both sides, unlike a run with live dropout
+    'mle_b8_v1000_ft10_bntrain': dict(mode='MLE', B=8, V=1000, Ft=10, seed=14, profile='trained_like', bn_train=True),
+    # reference-default frame count (opts.py:50) at a batch where the two-group GRU kernel and the wide kernels run
+    'greedy_b64_v5000_ft480_trained': dict(mode='sample', B=64, V=5000, Ft=480, seed=15, profile='trained_like'),
 }
 
 # loss weights used for the gradient fixtures (README.md:74-89 recipe + a non-zero w_grd so the
@@ -70,12 +76,57 @@ def build_ingest_case(name, root):
     return opt, ingest_oracle.synthetic_vocab(opt), fr, sr, recs
 
 
+N_PROJ = 8
+
+
+def grad_projections(name, grad, k=N_PROJ):
+    """k seeded random projections <grad, r_j> (float64) of one parameter's gradient.  r_j ~ N(0, I) comes from a CPU
+    torch.Generator seeded by crc32(parameter name), so the build container (reference gradient -> fixture) and the GPU
+    box (HIP gradient) draw identical directions.  A gradient with the right norm but a wrong direction (sign flip,
+    permutation, mis-routed block) moves every projection by ~|grad|; an elementwise relative error eps moves them by
+    ~eps |grad|.  A few hundred bytes per parameter instead of the 275 MB of gradients."""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7fffffff)
+    flat = grad.detach().reshape(-1)
+    out = []
+    for _ in range(k):
+        r = torch.randn(flat.numel(), generator=g)
+        out.append(float(torch.dot(flat.double(), r.to(flat.device).double())))
+    return out
+
+
+def projection_error(name, grad, want_proj, want_norm):
+    """RMS over the k projections of (got - want), relative to the reference gradient norm: an estimate of the relative
+    Frobenius error |g - g_ref| / |g_ref| that also sees direction."""
+    got = torch.tensor(grad_projections(name, grad, len(want_proj)), dtype=torch.float64)
+    want = torch.as_tensor(want_proj, dtype=torch.float64)
+    return float(((got - want) ** 2).mean().sqrt()) / max(float(want_norm), 1e-30)
+
+
+def zero_dropout(model):
+    """Set every dropout ratio of a (reference or HIP) model to 0: nn.Dropout modules (loc_fc's fixed 0.5, the encoder's
+    0.2, transformer.py:84,95) and the GRU's inter-layer dropout (model.py:153).  drop_prob_lm-driven functional dropout
+    (AttModel.py:161) is covered by constructing the model with opt.drop_prob_lm = 0."""
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.GRU):
+            m.dropout = 0.0
+    if hasattr(model, 'drop_prob_lm'):
+        model.drop_prob_lm = 0.0
+    if hasattr(model, 'core') and hasattr(model.core, 'drop_prob_lm'):
+        model.core.drop_prob_lm = 0.0
+    return model
+
+
 def build_case(name):
     """-> (opt, state_dict, inputs dict) regenerated purely from the case's seeds."""
     import importlib
     pkg = importlib.import_module('grounded-video-description_amd')
     spec = CASES[name]
     opt = pkg.opts.default_opt(vocab_size=spec['V'], t_attn_size=spec['Ft'], num_sampled_frm=spec.get('T', 10))
+    if spec.get('bn_train'):
+        opt.drop_prob_lm = 0.0
     sd = pkg.synth.init_state_dict(opt, seed=spec['seed'], profile=spec['profile'])
     if 'end_bias' in spec:
         sd['logit.weight'][0] *= spec['end_gain']

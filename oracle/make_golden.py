@@ -7,8 +7,11 @@ box (no /root/reference) can check both the oracle and the HIP path against refe
 What is stored per case (all produced by the reference model, eval mode, CPU fp32, torch 2.10):
   sample: seq i64[B,L], seqLogprobs f32[B,L], att_idx i16[B,L,T] (main.py:364-365 per-frame argmax),
           att2_weights f32[B,L,R] (only B<=4), sim_sub f32[B,D1,11] (every 97th region of sim_mat)
-  MLE:    losses f32[4] (lm, att2, ground, cls); for B<=8 also grad_norms (per-parameter L2 norm of the
-          gradient of lm + w_att2*att2 + w_grd*ground + w_cls*cls, cases.GRAD_WEIGHTS)
+  MLE:    losses f32[4] (lm, att2, ground, cls); grad_norms (per-parameter L2 norm of the gradient of
+          lm + w_att2*att2 + w_grd*ground + w_cls*cls, cases.GRAD_WEIGHTS) and grad_proj f64[n_params,8]: seeded random
+          projections of every parameter's gradient (cases.grad_projections) - pins the DIRECTION of the gradient, not
+          only its magnitude.  `bn_train` cases run the reference in train mode with every dropout ratio 0 (BatchNorm
+          batch statistics) and also store the updated running statistics
   beam:   seq i64[B,L], seqLogprobs f32[B,L], att2 i32[B,L] (global argmax-over-R region index per step) from the
           reference's own beam_search run under ref_harness.beam_shim (the unshimmed reference raises)
   step:   one main.train optimisation step (loss assembly, clip 0.1, Adam with the fc7/vis_embed lr x0.1 groups): per-parameter
@@ -59,8 +62,10 @@ def run_case(name):
     if spec['mode'] == 'ingest':
         return run_ingest_case(name)
     opt, sd, inp = cases.build_case(name)
-    need_grad = (spec['mode'] == 'MLE' and spec['B'] <= 8) or spec['mode'] in ('step', 'dp')
+    need_grad = spec['mode'] in ('MLE', 'step', 'dp')
     ref = ref_harness.build_reference_model(opt, sd, need_grad=need_grad).eval()
+    if spec.get('bn_train'):
+        cases.zero_dropout(ref).train()
     args = pkg.synth.as_args(inp)
     out = dict(weight_fp=np.int64(cases.weight_fingerprint(sd)),
                input_fp=np.int64(cases.input_fingerprint(inp)),
@@ -95,12 +100,18 @@ def run_case(name):
             loss = lm.sum() + w['w_att2'] * a2.sum() + w['w_grd'] * gl.sum() + w['w_cls'] * cl.sum()
             ref.zero_grad()
             loss.backward()
-            names, norms = [], []
+            names, norms, projs = [], [], []
             for n, p in ref.named_parameters():
                 if p.grad is not None:
                     names.append(n)
                     norms.append(float(p.grad.double().norm()))
-            out.update(grad_names=np.array(names), grad_norms=np.array(norms, dtype=np.float64))
+                    projs.append(cases.grad_projections(n, p.grad))
+            out.update(grad_names=np.array(names), grad_norms=np.array(norms, dtype=np.float64),
+                       grad_proj=np.array(projs, dtype=np.float64))
+            if spec.get('bn_train'):     # the batch-statistics pass also moved the running statistics (momentum 0.1)
+                bn = dict(ref.named_buffers())
+                out.update(bn_running_mean=bn['att_embed_aux.0.running_mean'].numpy().copy(),
+                           bn_running_var=bn['att_embed_aux.0.running_var'].numpy().copy())
         else:
             with torch.no_grad():
                 lm, a2, gl, cl = ref(*args, 'MLE')
@@ -119,13 +130,14 @@ def run_case(name):
             ((lm.sum() + w['w_att2'] * a2.sum() + w['w_grd'] * gl.sum() + w['w_cls'] * cl.sum()) / n).backward()
             shard_losses.append([lm.item(), a2.item(), gl.item(), cl.item()])
             print('   shard %d/%d  %.1fs  losses %s' % (r + 1, n, time.time() - t0, shard_losses[-1]), flush=True)
-        names, norms = [], []
+        names, norms, projs = [], [], []
         for pn, p in ref.named_parameters():
             if p.grad is not None:
                 names.append(pn)
                 norms.append(float(p.grad.double().norm()))
+                projs.append(cases.grad_projections(pn, p.grad))
         out.update(shard_losses=np.array(shard_losses, dtype=np.float32), grad_names=np.array(names),
-                   grad_norms=np.array(norms, dtype=np.float64),
+                   grad_norms=np.array(norms, dtype=np.float64), grad_proj=np.array(projs, dtype=np.float64),
                    losses=np.array(shard_losses, dtype=np.float64).mean(0).astype(np.float32))
     elif spec['mode'] == 'step':
         # main.train (main.py:234-266) with eval-mode arithmetic (dropout off, BN running stats: the only mode in which
@@ -145,14 +157,18 @@ def run_case(name):
         loss.backward()
         total = torch.nn.utils.clip_grad_norm_(ref.parameters(), clip)
         optimizer.step()
-        names, dn, mn = [], [], []
+        names, dn, mn, mp, dp = [], [], [], [], []
         for n, p in ref.named_parameters():
             if p.grad is None:
                 continue
             names.append(n)
             dn.append(float((p.detach() - before[n]).double().norm()))
             mn.append(float(optimizer.state[p]['exp_avg'].double().norm()))
+            # direction pins: the first moment (linear in the clipped gradient) and the parameter update itself
+            mp.append(cases.grad_projections(n, optimizer.state[p]['exp_avg']))
+            dp.append(cases.grad_projections(n, p.detach() - before[n]))
         out.update(step_names=np.array(names), delta_norms=np.array(dn), exp_avg_norms=np.array(mn),
+                   exp_avg_proj=np.array(mp, dtype=np.float64), delta_proj=np.array(dp, dtype=np.float64),
                    total_grad_norm=np.float64(float(total)), loss=np.float64(float(loss)),
                    losses=np.array([lm.item(), a2.item(), gl.item(), cl.item()], dtype=np.float32))
     elif spec['mode'] == 'GRD':

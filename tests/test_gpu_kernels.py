@@ -120,6 +120,27 @@ def test_attention_step(B, R, Ft):
     assert torch.equal(logits.cpu() == O.MIN_VALUE, pm[:, 1:].bool())
 
 
+def test_tanh_fast_error_bound():
+    """The score kernels' tanh (gvd_common.h: tanh_fast, 11 issue slots instead of ocml's 31) stays within 2.5e-7
+    ABSOLUTE of the real tanh over the whole line, saturates exactly and propagates NaN (AttModel.py:45, 90)."""
+    g = _g(77)
+    x = torch.cat([torch.randn(1 << 20, generator=g) * 1.5, torch.randn(1 << 18, generator=g) * 0.05,
+                   torch.linspace(-20, 20, 400001), torch.tensor([0.0, -0.0, 1e-30, -1e-30, 88.0, -88.0, 1e30, -1e30,
+                                                                  float('inf'), -float('inf')])])
+    xd = x.cuda()
+    yd = torch.empty_like(xd)
+    hip.check(hip.lib().gvd_tanh_fast_f32(hip.ptr(xd), hip.ptr(yd), xd.numel(), hip.stream_ptr()), 'tanh_fast')
+    y = yd.cpu().double()
+    err = (y - torch.tanh(x.double())).abs().max().item()
+    assert err <= 2.5e-7, err
+    assert y[-1] == -1.0 and y[-2] == 1.0 and y[-3] == -1.0 and y[-4] == 1.0 and y[-5] == -1.0 and y[-6] == 1.0
+    assert (y.abs() <= 1.0).all()
+    nan = torch.full((4,), float('nan'), device='cuda')
+    out = torch.empty_like(nan)
+    hip.check(hip.lib().gvd_tanh_fast_f32(hip.ptr(nan), hip.ptr(out), 4, hip.stream_ptr()), 'tanh_fast')
+    assert torch.isnan(out).all()
+
+
 def test_top2_unk_rule_and_embed():
     g = _g(9)
     B, V, E, unk = 37, 5000, 512, 4999

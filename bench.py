@@ -35,7 +35,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured copy
-GOLDEN_B256 = os.path.join(ROOT, 'tests', 'golden', 'greedy_b256_v5000_ft10_trained.npz')
+MFMA_F32_PEAK_TFS = 157.3   # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32; MI355X_MICROARCH.md) - no xf32 on gfx950
+GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
+GOLDEN_B256 = os.path.join(GOLDEN_DIR, 'greedy_b256_v5000_ft10_trained.npz')
 
 
 def parse():
@@ -51,6 +53,9 @@ def parse():
     ap.add_argument('--beam', type=int, default=1, help='beam size (1 = greedy; 5 = BASELINE configs[4])')
     ap.add_argument('--frames', type=int, default=10, help='sampled frames T (regions R = 100*T; configs[4] uses 20)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sections', action='store_true',
+                    help='default line only: skip the short configs[2] (train B=64) and configs[4] (beam=5 x 20 frames, '
+                         'B=64) sections and the GEMM roofline pass that the default run appends to its JSON line')
     ap.add_argument('--overlap', action='store_true',
                     help='pipeline the K steps on two HIP streams (preamble of step i+1 || token loop of step i). Off by '
                          'default: co-scheduling stretches the attention kernel, so its live roofline figure would not '
@@ -175,6 +180,8 @@ def _roofline(attn_ms, attn_n, bytes_per_launch, traffic, kernel):
             # the kernel does not fetch rows the attention mask removes (weight exactly 0), so the HBM traffic is below the
             # algorithmic bytes (which count every row): the physical HBM rate is traffic / duration
             'hbm_rate_from_traffic_GBs': None if (not attn_n or not traffic[0]) else round(traffic[0] / avg_s / 1e9, 1),
+            # `frac` follows SURVEY 8(d) (algorithmic bytes); this is the fraction of the HBM peak the kernel MOVES
+            'frac_physical': None if (not attn_n or not traffic[0]) else round(traffic[0] / avg_s / 1e9 / HBM_PEAK_GBS, 4),
             'avg_launch_us': round(avg_s * 1e6, 2), 'launches_timed': attn_n}
 
 
@@ -187,6 +194,108 @@ def _static_traffic(B, Ft, R):
         if tj.get('batch') == B and tj.get('t_attn') == Ft and tj.get('regions', 1000) == R:
             return tj.get('hbm_bytes_per_launch'), 'profiles/attn_traffic.json (static: rocprofv3 --pmc passes of this workload)'
     return None, None
+
+
+
+def _roofline_mfma(hip, run, steps, label):
+    """FLOPs of the pipelined fp32-MFMA GEMM launches (csrc/gemm_pipe.hip) / their HIP-event time, in a dedicated pass of
+    `steps` calls of run() OUTSIDE the timed region (the hook adds a one-thread flop-counter kernel per launch).  Rows come
+    from the device-side row counts, so the compacted preamble is counted with the rows it really multiplies."""
+    prof = hip.GemmProfile(max_pairs=8192)
+    with prof:
+        for _ in range(steps):
+            run()
+        ms, n, flops = prof.read()
+    if not n or ms <= 0:
+        return None
+    ach = flops / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': 'gemm_pipe_kernel (every fp32-MFMA product with >= 256 tiles: %s)' % label,
+            'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TFS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_F32_PEAK_TFS, 4),
+            'traffic': None, 'flops_per_step': flops / steps, 'gemm_ms_per_step': round(ms / steps, 3),
+            'launches_per_step': n // steps, 'steps_measured': steps}
+
+
+def section_train_b64(dev, n_steps=3):
+    """BASELINE configs[2] inside the default line: one optimisation step of 64 segments (train mode: dropout, BN batch
+    statistics), on the weights + inputs of the committed reference case mle_b64_v5000_ft10_trained; `parity` = the
+    eval-mode 'MLE' losses of that case against the reference's own (tests/golden), before any update."""
+    import numpy as np
+    from gvd_amd import att_model, hip, ops, opts, synth, train
+    opt = opts.default_opt(vocab_size=5000, t_attn_size=10)
+    sd = synth.init_state_dict(opt, seed=5, profile='trained_like')
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    a = synth.as_args(synth.trim_to_batch(synth.make_inputs(opt, 64, seed=5, train=True)), dev)
+    out = {'batch': 64}
+    gpath = os.path.join(GOLDEN_DIR, 'mle_b64_v5000_ft10_trained.npz')
+    if os.path.exists(gpath):
+        with torch.no_grad():
+            got = torch.cat([l.reshape(1) for l in model(*a, 'MLE')]).cpu().numpy()
+        want = np.load(gpath)['losses']
+        out['parity'] = {'golden': 'tests/golden/mle_b64_v5000_ft10_trained.npz (reference CPU losses lm/att2/grd/cls)',
+                         'max_abs_loss_diff': float(np.abs(got - want).max()),
+                         'within_1e-4': bool(np.abs(got - want).max() <= 1e-4)}
+    model.train()
+    tr = train.Trainer(model, opt)
+    tr.step(a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        tr.step(a)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_steps
+    out.update(ms_per_step=round(1e3 * dt, 3), segments_per_s=round(64 / dt, 1), steps_timed=n_steps)
+    out['roofline'] = _roofline_mfma(hip, lambda: tr.step(a), 1, 'forward, dX and dW (K-strided) products of the step')
+    del tr, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def section_beam5_t20_b64(dev, n_steps=3):
+    """BASELINE configs[4] inside the default line: beam=5 over 20 frames x 100 regions, 64 segments; `parity` = ids and
+    attended regions of the committed reference case beam5_b8_v5000_ft10_t20 (the reference's own beam_search under the
+    harness shim) decoded by the same model."""
+    import numpy as np
+    from gvd_amd import att_model, hip, ops, opts, synth
+    opt = opts.default_opt(vocab_size=5000, t_attn_size=10, num_sampled_frm=20)
+    sd = synth.init_state_dict(opt, seed=9, profile='trained_like')
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    keys = ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')
+    out = {'batch': 64, 'beam': 5, 'frames': 20}
+    gpath = os.path.join(GOLDEN_DIR, 'beam5_b8_v5000_ft10_t20.npz')
+    with torch.no_grad():
+        if os.path.exists(gpath):
+            g = np.load(gpath)
+            small = synth.make_inputs(opt, 8, seed=9, train=False)
+            seq, lps, att2, _ = model._sample(*[small[k].to(dev) for k in keys], {'beam_size': 5})
+            out['parity'] = {'golden': 'tests/golden/beam5_b8_v5000_ft10_t20.npz (reference beam_search under the shim)',
+                             'token_ids_equal': bool((seq.cpu().numpy() == g['seq']).all()),
+                             'attended_regions_equal': bool((att2.cpu().numpy() == g['att2']).all())}
+        inp = synth.make_inputs(opt, 64, seed=100, train=False)
+        d = [inp[k].to(dev) for k in keys]
+        for _ in range(2):
+            model._sample(*d, {'beam_size': 5})
+        timer = hip.KernelTimer(max_pairs=opt.seq_length * n_steps)
+        ops.set_kernel_timer(timer)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            model._sample(*d, {'beam_size': 5})
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_steps
+        ops.set_kernel_timer(None)
+    model.check_kernel_status()
+    ms, n = timer.read()
+    R = opt.num_sampled_frm * opt.num_prop_per_frm
+    out.update(ms_per_step=round(1e3 * dt, 3), captions_per_s=round(64 / dt, 1), steps_timed=n_steps)
+    out['roofline'] = _roofline(ms, n, 64 * (R + 10) * (opt.att_hid_size + opt.rnn_size) * 4, (None, None),
+                                'attn_partial_group_kernel<5> (one feature stream per sample for its 5 beams)')
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 def bench_train(args, opt, sd, model, B, rank, world, dev):
@@ -232,9 +341,13 @@ def bench_train(args, opt, sd, model, B, rank, world, dev):
                                    'w_grd=%.2f w_cls=%.2f' % (B, args.t_attn, args.vocab, opt.w_att2, opt.w_grd, opt.w_cls),
                        'batch_per_gpu': B, 'parallelism': 'dp%d (RCCL bucketed grad all-reduce)' % world},
             'losses_last': [round(float(x), 5) for x in losses],
+            # the kernel that dominates THIS mode: the pipelined fp32-MFMA GEMM (forward, dX, dW products; ~75 % of the
+            # step), measured in one extra step after the timed region
+            'roofline': (_roofline_mfma(hip, lambda: tr.step(a), 1, 'forward, dX and dW (K-strided) products of the step')
+                         if world == 1 else None),      # (one rank only: an extra step on rank 0 alone would hang the all-reduce)
             # the forward attention streaming kernel of the teacher-forced loop (same kernel, same bytes as in decode)
-            'roofline': _roofline(attn_ms, attn_n, B * (R + Ft) * (A + H) * 4, (None, None),
-                                  'attn_partial_kernel (forward region+temporal attention of the teacher-forced loop)'),
+            'roofline_attention': _roofline(attn_ms, attn_n, B * (R + Ft) * (A + H) * 4, (None, None),
+                                            'attn_partial_kernel (forward region+temporal attention of the teacher-forced loop)'),
             'cpu_baseline': None if (world != 1 or args.no_cpu_baseline) else cpu_baseline_train(opt, sd, args.cpu_seconds)}
         print(json.dumps(out))
     if use_dist:
@@ -372,6 +485,14 @@ def main():
                                   'attn_partial_group_kernel<%d> (one feature stream per sample for its %d beams)'
                                   % (args.beam, args.beam)),
         }
+        if world == 1 and not args.h2d and not args.overlap:
+            # the kernel that takes most of the step's GPU time is not the attention stream but the fp32-MFMA GEMM of the
+            # per-segment preamble: its own roofline block, from two extra steps after the timed region
+            model.kernel_timer = None
+            with torch.no_grad():
+                out['roofline_mfma'] = _roofline_mfma(
+                    hip, lambda: model._sample(*dinp, {'beam_size': args.beam}), 2,
+                    'fc7, class similarity, pool_embed, encoder q|k|v / wo / feed-forward, ctx2pool of the preamble')
         if golden is not None:
             # the timed run decoded the committed reference case: compare with the reference's own output
             from gvd_amd.att_model import attended_region_indices
@@ -400,6 +521,15 @@ def main():
             model.check_kernel_status()
             out['config']['configs1_b4'] = {'batch': 4, 'ms_per_call': round(1e3 * dt, 3),
                                             'captions_per_s': round(4 / dt, 1), 'calls_timed': 20}
+        default_workload = (world == 1 and args.beam == 1 and B == 256 and not args.h2d and not args.overlap
+                            and args.vocab == 5000 and args.t_attn == 10 and args.frames == 10)
+        if default_workload and not args.no_sections:
+            # BASELINE configs[2] and configs[4] as short sections of the default line (their full lines:
+            # `--mode train`, `--beam 5 --frames 20 --batch 64`)
+            del model, dinp
+            torch.cuda.empty_cache()
+            out['config']['configs2_train_b64'] = section_train_b64(dev)
+            out['config']['configs4_beam5_t20_b64'] = section_beam5_t20_b64(dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(opt, sd, args.cpu_seconds, beam=args.beam)
         else:

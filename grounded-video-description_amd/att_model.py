@@ -227,7 +227,19 @@ class TopDownModel(nn.Module):
                                        frm_mask, sample_idx, pnt_mask, True)
         if opt == 'sample':
             seq, lps, att2, sim = self._sample(segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, eval_opt)
-            self.check_kernel_status()      # fail loudly: a timed-out persistent kernel must not yield captions
+            counts = self.kernel_status_counts()
+            if counts is not None:
+                bad, contract = counts.tolist()     # one device->host read per call
+                if contract:
+                    # masked proposals (pnt_mask = 1) with NON-zero features / boxes: inputs the reference accepts
+                    # (model.py:311-391 computes every row) but for which the compacted preamble's premise - all masked rows
+                    # of a segment are the same zero row, dataloader_anet.py:343-344 - does not hold.  Compute, don't
+                    # raise: the batch is decoded again through the dense preamble.
+                    seq, lps, att2, sim = self._sample(segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask,
+                                                       dict(eval_opt, dense_preamble=True))
+                    c2 = self.kernel_status_counts()
+                    bad = 0 if c2 is None else c2.tolist()[0]
+                self.raise_for_status(bad, 0)       # fail loudly: a timed-out persistent kernel must not yield captions
             return seq, att2, sim
         raise ValueError(opt)
 
@@ -238,28 +250,39 @@ class TopDownModel(nn.Module):
             self._kernel_flags = []
         return self._kernel_flags
 
+    def kernel_status_counts(self):
+        """Device int64 vector [persistent-kernel barrier timeouts, loader-contract violations] of all launches since the
+        last call (no host sync; the lists are cleared), or None when nothing was launched."""
+        flags, self._kernel_flags = self._flags(), []
+        contract, self._contract_flags = self.__dict__.get('_contract_flags', []), []
+        if not flags and not contract:
+            return None
+        dev = (flags + contract)[0].device
+        return torch.stack([torch.stack([f.reshape(-1).ne(0).sum() for f in fl]).sum() if fl else
+                            torch.zeros((), dtype=torch.int64, device=dev) for fl in (flags, contract)])
+
+    @staticmethod
+    def raise_for_status(bad, contract):
+        if contract:
+            raise GvdHipError('%d batch(es) had masked proposals (pnt_mask = 1) whose fc6 features / boxes are not zero: the '
+                              "compacted preamble's results are invalid for them.  forward(..., 'sample') recomputes such "
+                              "batches on the dense preamble by itself; direct callers of _sample pass "
+                              "{'dense_preamble': True} or set GVD_COMPACT=0" % contract)
+        if bad:
+            raise GvdHipError('%d persistent-kernel launch(es) hit a grid-barrier timeout (workgroups not co-resident, '
+                              'e.g. a shared GPU): results are invalid.  Re-run, or set GVD_PERSISTENT=0 / '
+                              'GVD_GRU_BARRIER=cg' % bad)
+
     def check_kernel_status(self):
         """The persistent kernels (greedy decoder B <= 4, bi-GRU) bound their grid-barrier spins and latch a flag
         instead of hanging the GPU when workgroups are not co-resident; their outputs are then garbage.  One deferred
         device->host read for all launches since the last call; raises GvdHipError if any flag is set.  Called by
         `forward(..., 'sample')` and `sample_pipelined`; callers of the private `_sample` (bench, tests) call it
         themselves after their timed region."""
-        flags, self._kernel_flags = self._flags(), []
-        contract, self._contract_flags = self.__dict__.get('_contract_flags', []), []
-        if not flags and not contract:
-            return
-        counts = torch.stack([torch.stack([f.reshape(-1).ne(0).sum() for f in fl]).sum() if fl else
-                              torch.zeros((), dtype=torch.int64, device=(flags + contract)[0].device)
-                              for fl in (flags, contract)]).tolist()      # one device->host read
-        bad = counts[0]
-        if counts[1]:
-            raise GvdHipError('%d batch(es) had masked proposals (pnt_mask = 1) whose fc6 features / boxes are not zero. The '
-                              'compacted preamble relies on the loader contract (dataloader_anet.py:343-344 zeroes them); '
-                              'zero them or set GVD_COMPACT=0' % counts[1])
-        if bad:
-            raise GvdHipError('%d persistent-kernel launch(es) hit a grid-barrier timeout (workgroups not co-resident, '
-                              'e.g. a shared GPU): results are invalid.  Re-run, or set GVD_PERSISTENT=0 / '
-                              'GVD_GRU_BARRIER=cg' % bad)
+        counts = self.kernel_status_counts()
+        if counts is not None:
+            bad, contract = counts.tolist()      # one device->host read
+            self.raise_for_status(bad, contract)
 
     def _lin(self, x, lin, act=0):
         """nn.Linear (+ReLU) on the fp32 MFMA GEMM."""
@@ -618,7 +641,8 @@ class TopDownModel(nn.Module):
         sample_max = opt.get('sample_max', 1)
         beam_size = opt.get('beam_size', 1)
         with torch.no_grad():
-            pre = self._preamble(segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, allow_compact=True)
+            pre = self._preamble(segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask,
+                                 allow_compact=not opt.get('dense_preamble', False))
             P = {k: v.detach() for k, v in self._decode_params().items()}
             if not sample_max:
                 from . import sampling
@@ -668,7 +692,16 @@ class TopDownModel(nn.Module):
             for t in o:
                 t.record_stream(cur)
         self._pipeline_keepalive = keep              # released on the next call, after the streams were joined
-        self.check_kernel_status()
+        counts = self.kernel_status_counts()
+        if counts is not None:
+            bad, contract = counts.tolist()
+            if contract and isinstance(batches, (list, tuple)):
+                # some batch broke the zero-row loader contract: recompute them on the dense preamble (a lazy producer that
+                # recycles its staging buffers cannot be replayed: that case raises below)
+                outs = [self._sample(b[0], b[1], b[2], b[3], b[4], b[5], dict(eval_opt, dense_preamble=True)) for b in batches]
+                c2 = self.kernel_status_counts()
+                bad, contract = (0 if c2 is None else c2.tolist()[0]), 0
+            self.raise_for_status(bad, contract)
         return outs
 
     # ------------------------------------------------------------------ 'MLE' / 'GRD' (model.py:283-489)

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams
     *reinterpret_cast<f32x4*>(p.part_ctx + ((int64_t)(smp * G + g) * p.nctot + cglob) * ATT_H + 4 * tid) = acc[g];
 }
 
+
 struct CombParams {
   const float* part_ctx; const float* part_ml;
   int nc[2]; int nside; int nctot;

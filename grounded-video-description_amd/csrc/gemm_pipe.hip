@@ -465,6 +465,26 @@ int pipe_launch_t(const KParams& p, dim3 grid, bool lds_epi, hipStream_t st) {
 
 bool gvd_gemm_pipe_takes_ktail() { return GVD_PIPE_LDSDMA != 0; }
 
+// ---- measurement hook (bench.py `roofline_mfma`): while armed, every pipelined-GEMM launch is bracketed by an event pair on
+// its stream and a one-thread kernel adds the launch's flops - 2 x rows x N x K x batch with the DEVICE-side row count where
+// the launch has one - to a device counter.  Process-global and not thread-safe: armed by bench.py for a dedicated
+// measurement pass (outside its timed region), never by the product path.
+namespace {
+gvd_prof* g_gemm_prof = nullptr;
+double* g_gemm_flops = nullptr;
+
+__global__ void gemm_flops_kernel(double* acc, const int* m_dev, int M, double per_row) {
+  const int m = m_dev ? min(*m_dev, M) : M;
+  *acc += per_row * (double)m;
+}
+}  // namespace
+
+extern "C" int gvd_gemm_prof_set(gvd_prof* prof, double* dev_flops) {
+  g_gemm_prof = prof;
+  g_gemm_flops = prof ? dev_flops : nullptr;
+  return 0;
+}
+
 int gvd_gemm_pipe_launch(KParams& p, int batch, hipStream_t st) {
   p.ntm = (p.M + BM - 1) / BM;
   p.ntn = (p.N + BN - 1) / BN;
@@ -480,5 +500,16 @@ int gvd_gemm_pipe_launch(KParams& p, int batch, hipStream_t st) {
   // a last tile at most half full in N (few N tiles) or in M (few M tiles) is worth the sub-tile skip
   const int remn = p.N - (p.ntn - 1) * BN, remm = p.M - (p.ntm - 1) * BM;
   const bool edge = (remn <= BN / 2 && p.ntn <= 4) || (!p.m_dev && remm <= BM / 2 && p.ntm <= 4);
-  return edge ? pipe_launch_t<true>(p, grid, lds_epi, st) : pipe_launch_t<false>(p, grid, lds_epi, st);
+  gvd_prof* prof = g_gemm_prof;
+  if (prof) {
+    double ktot = 0.0;
+    for (int s = 0; s < p.nseg; ++s) ktot += (double)p.K[s];
+    if (g_gemm_flops)
+      hipLaunchKernelGGL(gemm_flops_kernel, dim3(1), dim3(1), 0, st, g_gemm_flops, p.m_dev, p.M,
+                         2.0 * (double)p.N * ktot * (double)batch);
+    gvd_prof_begin(prof, st);
+  }
+  const int rc = edge ? pipe_launch_t<true>(p, grid, lds_epi, st) : pipe_launch_t<false>(p, grid, lds_epi, st);
+  if (prof) gvd_prof_end(prof, st);
+  return rc;
 }

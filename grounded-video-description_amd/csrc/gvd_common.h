@@ -39,7 +39,7 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 // exactly to +-1 (2^y -> inf / 0), NaN-propagating.  The score kernels fold the constants into per-lane registers:
 //     sum_k w_k tanh(x_k + q_k) = sum_k w_k + sum_k (-2 w_k) r_k,   r_k = rcp(1 + exp2(fma(x_k, C, C q_k)))
 // = fma + v_exp + add + v_rcp + fma per element (11 issue slots instead of 31).  Every forward score kernel
-// (attn_partial_kernel, attn_partial_group_kernel, the persistent decoder) uses attn_score_fma in the same k order,
+// (attn_partial_kernel, attn_partial_group_kernel, the persistent decoder) uses attn_score_lane in the same k order,
 // so they stay bitwise interchangeable.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr float GVD_TWO_LOG2E = 2.8853900817779268f;

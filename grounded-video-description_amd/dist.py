@@ -59,6 +59,13 @@ class GradAllReducer:
     above zero (which used to push the bucket with the earliest gradients into `finish()`), and their
     `.grad` stays None exactly as in a single-process run, so the optimizer treats them the same on 1 and
     N ranks.  A parameter that has a gradient on some rank but not on this one contributes zeros.
+
+    The bucket layout is COLLECTIVE state: it only ever changes at a point every rank reaches together.  If an
+    excluded parameter receives a gradient later on ANY rank (a rank-asymmetric use), that rank only raises a
+    local flag; `finish()` MAX-reduces a small status word on every rank in every step (flag + optional caller
+    status, e.g. the kernel-status count of train.Trainer), and when the reduced flag is set ALL ranks - after the
+    current buckets were drained, never with collectives in flight - re-run the discovery together, average the
+    gradients of the newly used parameters in the same step, and rebuild the buckets for the next one.
     """
 
     def __init__(self, module, bucket_mb=64, process_group=None):
@@ -68,7 +75,11 @@ class GradAllReducer:
         self.all_params = [p for p in module.parameters() if p.requires_grad]
         self.params = list(self.all_params)
         self._discovered = False
+        self._late = False          # an excluded parameter got a gradient on THIS rank since the last finish()
+        self._word = None
+        self.rediscoveries = 0
         self._hooks = []
+        self._handles = []
         # GVD_DP_FORCE=1: run the hook/bucket/all-reduce machinery even on a 1-rank group (single-GPU test of the path)
         self.active = self.world > 1 or (os.environ.get('GVD_DP_FORCE') == '1' and dist.is_initialized())
         self._build_buckets()
@@ -77,6 +88,8 @@ class GradAllReducer:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _build_buckets(self):
+        if self._handles:
+            raise RuntimeError('GradAllReducer: bucket layout changed with %d all-reduce(s) in flight' % len(self._handles))
         self.buckets = []          # list of dict(params, offsets, numel, flat)
         cap = int(self.bucket_mb * 1024 * 1024 / 4)
         cur, cur_n = [], 0
@@ -104,6 +117,9 @@ class GradAllReducer:
                                  flat=torch.zeros(n, dtype=p0.dtype, device=p0.device)))
 
     def reset(self):
+        """Start of a step (before backward).  Never drops collectives that are still in flight: they are waited for."""
+        for _, h in self._handles:
+            h.wait()
         self._pending = [len(b['params']) for b in self.buckets]
         self._next = 0             # buckets [0, _next) have been launched
         self._handles = []
@@ -125,31 +141,30 @@ class GradAllReducer:
 
     def _on_grad(self, p):
         bi = self.where.get(id(p))
-        if bi is None:                  # excluded (never-used) parameter suddenly got a gradient: rediscover next step
-            self._discovered = False
+        if bi is None:
+            # excluded (never-used) parameter got a gradient on this rank.  LOCAL flag only: the layout is collective
+            # state and is rebuilt by all ranks together in finish() / resolve()
+            self._late = True
             return
         self._pending[bi] -= 1
         if self._discovered:            # step 0 reduces everything in finish(), after the discovery exchange
             self._launch_ready()
 
-    def _discover(self):
-        """Union over ranks of the parameters that got a gradient in this (first) step; rebuild the buckets from them."""
+    def _used_union(self):
         used = torch.tensor([0 if p.grad is None else 1 for p in self.all_params], dtype=torch.int32,
                             device=self.all_params[0].device)
         dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group)
-        used = used.tolist()
+        return used.tolist()
+
+    def _discover(self):
+        """Union over ranks of the parameters that got a gradient in this (first) step; rebuild the buckets from them."""
+        used = self._used_union()
         self.params = [p for p, u in zip(self.all_params, used) if u]
         self.unused = [p for p, u in zip(self.all_params, used) if not u]
         self._build_buckets()
         self._discovered = True
 
-    def finish(self):
-        """Call after loss.backward(): completes every bucket and writes the averaged gradients back."""
-        if not self.active:
-            return
-        if not self._discovered:
-            self._discover()
-        self._launch_ready(force=True)
+    def _drain(self):
         for bi, h in self._handles:
             h.wait()
             b = self.buckets[bi]
@@ -160,7 +175,52 @@ class GradAllReducer:
                     p.grad = g.clone()
                 else:
                     p.grad.copy_(g)
+        self._handles = []
+
+    def finish(self, status=None, defer=False):
+        """Call after loss.backward(): completes every bucket and writes the averaged gradients back.
+
+        status: optional int32 device vector of the caller; returned MAX-reduced over the ranks (so that e.g. a kernel
+        error raised from it is raised on every rank in the same step).  defer=False: the rediscovery flag is read here
+        (one device->host read) and acted upon; defer=True: the caller reads the returned word itself - element 0 is the
+        flag, the rest is `status` - and MUST call `resolve(word[0])` on every rank before it uses the gradients."""
+        if not self.active:
+            return None if status is None else torch.cat([status.new_zeros(1), status])
+        if not self._discovered:
+            self._discover()
+        dev = self.all_params[0].device
+        word = torch.zeros(1 + (0 if status is None else status.numel()), dtype=torch.int32, device=dev)
+        if self._late:
+            word[0] = 1
+        if status is not None:
+            word[1:] = status.to(device=dev, dtype=torch.int32).reshape(-1)
+        wh = dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        self._launch_ready(force=True)
+        self._drain()
+        wh.wait()
+        self._late = False
         self.reset()
+        if not defer:
+            self.resolve(int(word[0].item()))
+        return word
+
+    def resolve(self, flag):
+        """Act on the MAX-reduced rediscovery flag of this step (same value on every rank): average the gradients of the
+        parameters that were excluded so far but used by some rank in this step, and rebuild the bucket layout."""
+        if not self.active or not flag:
+            return
+        used = self._used_union()
+        known = set(id(p) for p in self.params)
+        fresh = [p for p, u in zip(self.all_params, used) if u and id(p) not in known]
+        for p in fresh:                       # same list, same order on every rank
+            g = torch.zeros_like(p) if p.grad is None else p.grad
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            g.div_(self.world)
+            p.grad = g
+        self.params = [p for p in self.all_params if id(p) in known or any(p is q for q in fresh)]
+        self.unused = [p for p in self.all_params if not (id(p) in known or any(p is q for q in fresh))]
+        self._build_buckets()
+        self.rediscoveries += 1
 
     def remove(self):
         for h in self._hooks:

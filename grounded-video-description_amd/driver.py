@@ -122,7 +122,8 @@ def load_checkpoint(model, start_from, run_id, load_best_score=0, map_location='
 
 def train_epoch(trainer, batches, opt, log=None):
     """main.py:197-311: one pass over `batches` (iterables of the 11 positional model inputs); returns the running
-    means main.py prints (train loss, lm, att2, ground, cls)."""
+    means main.py prints (train loss, lm, att2, ground, cls).  The number of optimisation steps of the pass is left in
+    `trainer.steps_last_epoch` (run_epochs advances infos['iter'] by it)."""
     trainer.model.train()
     sums = torch.zeros(5)
     n = 0
@@ -134,6 +135,7 @@ def train_epoch(trainer, batches, opt, log=None):
         n += 1
         if log is not None and step % max(getattr(opt, 'disp_interval', 100), 1) == 0:
             log('step %d: train_loss %.4f (lm %.4f att2 %.4f grd %.4f cls %.4f)' % ((step,) + tuple((sums / n).tolist())))
+    trainer.steps_last_epoch = n
     return (sums / max(n, 1)).tolist()
 
 
@@ -264,11 +266,16 @@ def run_epochs(trainer, opt, train_batches, validate, checkpoint_path=None, info
       * every val_every_epoch epochs `validate(epoch)` returns the language stats dict; its 'CIDEr' is the model
         selection score: model.pth + infos/histories are written every validation, model-best.pth when it improves
         (main.py:700-743).
+    Conscious deviation: the reference never increments its `iteration` (main.py:309-311,646), so its
+    infos['iter'] is always the resumed value; here infos['iter'] counts the optimisation steps run so far, so that a
+    resumed run knows its position.  lr / loss histories stay keyed by epoch (the reference's iteration-keyed entries all
+    collapse onto the single key `iteration`).
     Returns (infos, histories) exactly as they are pickled."""
     infos = dict(infos or {})
     histories = dict(histories or {})
     best = infos.get('best_val_score', None)
     start_epoch = infos.get('epoch', 0)
+    iteration = infos.get('iter', 0)
     val_hist = histories.setdefault('val_result_history', {})
     histories.setdefault('loss_history', {})
     lr_hist = histories.setdefault('lr_history', {})
@@ -281,6 +288,7 @@ def run_epochs(trainer, opt, train_batches, validate, checkpoint_path=None, info
         lr_hist[epoch] = opt.learning_rate
         if not getattr(opt, 'inference_only', False):
             means = train_epoch(trainer, train_batches(epoch), opt, log=log)
+            iteration += getattr(trainer, 'steps_last_epoch', 0)
             histories['loss_history'][epoch] = means[0]
         if epoch % opt.val_every_epoch == 0:
             with torch.no_grad():
@@ -292,7 +300,7 @@ def run_epochs(trainer, opt, train_batches, validate, checkpoint_path=None, info
             best_flag = best is None or score > best
             if best_flag:
                 best = score
-            infos.update(iter=infos.get('iter', 0), epoch=epoch, best_val_score=best)
+            infos.update(iter=iteration, epoch=epoch, best_val_score=best)
             if checkpoint_path is not None:
                 save_checkpoint(trainer.model, opt, checkpoint_path, infos=infos, histories=histories, best=best_flag,
                                 itow=itow)

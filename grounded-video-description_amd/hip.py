@@ -95,6 +95,7 @@ _SIG = {
     'gvd_attn_fwd_prof': (C.c_int, [C.POINTER(AttnSide), C.POINTER(AttnSide), C.c_int, C.c_int, C.c_int,
                                     c_f32p, C.c_int64, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'gvd_gemm_nt_f32': (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    'gvd_gemm_prof_set': (C.c_int, [C.c_void_p, C.c_void_p]),
     'gvd_lstm_cell_fwd': (C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),
     'gvd_tanh_fast_f32': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     'gvd_attn_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -159,7 +160,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 7        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 8        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 
@@ -226,6 +227,30 @@ def require_cuda_f32(*tensors):
             raise GvdHipError('HIP hot path called with a non-GPU tensor; there is no CPU fallback')
         if t.dtype != torch.float32:
             raise GvdHipError('expected float32, got %s' % t.dtype)
+
+
+class GemmProfile:
+    """Arms gvd_gemm_prof_set for a `with` block: event pairs around every pipelined-GEMM launch + a device flop counter.
+    .read() -> (total_ms, launches, flops).  Measurement only (bench.py roofline_mfma); process-global."""
+
+    def __init__(self, max_pairs=8192):
+        self.timer = KernelTimer(max_pairs)
+        self.flops = torch.zeros(1, dtype=torch.float64, device='cuda')
+
+    def __enter__(self):
+        self.timer.reset()
+        self.flops.zero_()
+        check(lib().gvd_gemm_prof_set(self.timer.h, ptr(self.flops)), 'gvd_gemm_prof_set')
+        return self
+
+    def __exit__(self, *exc):
+        lib().gvd_gemm_prof_set(None, None)
+        return False
+
+    def read(self):
+        torch.cuda.synchronize()
+        ms, n = self.timer.read()
+        return ms, n, float(self.flops.item())
 
 
 class KernelTimer:

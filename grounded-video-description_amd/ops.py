@@ -706,10 +706,14 @@ TRAIN_HEAD_PAD = 192      # training attention core: heads zero-padded to a mult
 
 
 def train_head_pad(B, Rp, n_heads):
-    """Head slot width of the training attention core.  192 (six whole 32-deep k tiles).  EXPERIMENTAL, GVD_TRAIN_HEAD_PAD=176:
-    176-column slots as in inference (8 % fewer flops in the q|k|v / wo projections and the six attention products) for
-    launches the pipelined GEMM's K-tail-of-16 path takes (>= 256 tiles); not yet verified on the device."""
-    if os.environ.get('GVD_TRAIN_HEAD_PAD', '') == '176' and B * n_heads * (-(-Rp // 128)) ** 2 >= 256:
+    """Head slot width of the training attention core: 176 columns as in inference (8 % fewer flops in the q|k|v / wo
+    projections and the six attention products than 192-column slots) whenever every product of the launch runs on the
+    pipelined GEMM, whose K-tail-of-16 path (csrc/gemm_pipe.hip: the last k tile is fetched shifted back by 16 columns and
+    only its last two quarters are multiplied) takes the K = 176 contractions; 192 (six whole 32-deep k tiles) for small
+    launches that run on the general kernel.  Verified on the device against the 192-slot form
+    (tests/test_gpu_kernels.py::test_enc_attn_core_176_column_head_slots) and by the reference gradient goldens.
+    GVD_TRAIN_HEAD_PAD=192 forces the wide slots."""
+    if os.environ.get('GVD_TRAIN_HEAD_PAD', '176') == '176' and B * n_heads * (-(-Rp // 128)) ** 2 >= 256:
         return 176
     return TRAIN_HEAD_PAD
 

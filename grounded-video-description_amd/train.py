@@ -50,19 +50,36 @@ class Trainer:
         self.model, self.opt = model, opt
         self.optimizer = build_optimizer(model, opt)
         self.reducer = gdist.GradAllReducer(model, bucket_mb=bucket_mb)
+        self._grad_norm = None
+
+    @property
+    def last_grad_norm(self):
+        """Pre-clip total gradient norm of the last step (main.py:265).  Kept on the device; read on demand."""
+        return None if self._grad_norm is None else float(self._grad_norm)
 
     def step(self, args):
-        """args: the 11 positional tensors of AttModel.forward.  Returns the 4 detached losses [4]."""
+        """args: the 11 positional tensors of AttModel.forward.  Returns the 4 detached losses [4].
+
+        ONE device->host read per step: the kernel-status counts of the persistent kernels (the bi-GRU runs as one in
+        training too: a grid-barrier timeout must not reach the optimizer silently) - MAX-reduced over the ranks together
+        with the reducer's rediscovery flag, so that under data parallelism every rank raises (or rebuilds its buckets)
+        in the same step instead of leaving its peers blocked in the next collective.  The gradient norm stays a device
+        tensor (clip_grad_norm_ scales on the device)."""
         self.model.zero_grad(set_to_none=True)
         self.reducer.reset()
         losses = self.model(*args, 'MLE')
         loss = combine_losses(losses, self.opt)
         loss.backward()
-        self.reducer.finish()
-        self.last_grad_norm = float(nn.utils.clip_grad_norm_(self.model.parameters(), self.opt.grad_clip))
-        if hasattr(self.model, 'check_kernel_status'):
-            # the GRU of the frame encoder runs as a persistent cooperative kernel in training too: a grid-barrier timeout
-            # (workgroups not co-resident) must not reach the optimizer silently
-            self.model.check_kernel_status()
+        counts = self.model.kernel_status_counts() if hasattr(self.model, 'kernel_status_counts') else None
+        if self.reducer.active:
+            st = torch.zeros(2, dtype=torch.int32, device=loss.device) if counts is None else counts.to(torch.int32)
+            word = self.reducer.finish(status=st, defer=True).tolist()          # the step's one host read
+            self.reducer.resolve(word[0])
+            bad, contract = word[1], word[2]
+        else:
+            bad, contract = (0, 0) if counts is None else counts.tolist()       # the step's one host read
+        if bad or contract:
+            self.model.raise_for_status(bad, contract)
+        self._grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), self.opt.grad_clip)
         self.optimizer.step()
         return torch.cat([l.detach() for l in losses])

@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 7
+#define GVD_ABI_VERSION 8
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -102,6 +102,12 @@ typedef struct {
 } gvd_gemm_args;
 
 int gvd_gemm_nt_f32(const gvd_gemm_args* args, gvd_stream_t stream);
+
+/* Measurement hook (bench.py `roofline_mfma`): while `prof` is non-NULL every launch of the pipelined fp32-MFMA GEMM kernel
+ * (csrc/gemm_pipe.hip) is bracketed by an event pair of `prof` on its stream, and 2 x rows x N x K x batch flops - rows read
+ * from the launch's device-side row count where it has one - are added to the device double *dev_flops (may be NULL).
+ * Process-global, not thread-safe, off by default; pass NULL to disarm.  No reference counterpart (instrumentation). */
+int gvd_gemm_prof_set(gvd_prof* prof, double* dev_flops);
 
 /* nn.LSTMCell forward (AttModel.py:121,123,139,160): gates = sum_s X_s W_s^T + b_ih + b_hh (+ rowbias),
  * gate order i,f,g,o; c' = sig(f) c + sig(i) tanh(g); h' = sig(o) tanh(c').  The gate GEMM and the

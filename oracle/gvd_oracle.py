@@ -192,7 +192,7 @@ def roi_labels_for_step(mask_boxes_t, overlaps):
     """
     B = overlaps.shape[0]
     ov = overlaps.masked_fill(mask_boxes_t.reshape(B, 1, -1).bool().expand_as(overlaps), 0)
-    return (ov.max(dim=2)[0] > 0.5).float()
+    return (ov.max(dim=2)[0] > 0.5).to(ov.dtype)          # (.float() in the reference; dtype-generic for the fp64 truth runs of the tests)
 
 
 def frame_mask_for_step(mask_boxes_t, frm_mask, pnt_mask):
@@ -207,14 +207,14 @@ def frame_mask_for_step(mask_boxes_t, frm_mask, pnt_mask):
 # --------------------------------------------------------------------------------------------------
 # per-segment preamble  (model.py:302-409 / 504-568 / 634-698 — identical in the three drivers)
 # --------------------------------------------------------------------------------------------------
-def preamble(W, opt, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, fast_gru=True):
+def preamble(W, opt, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, fast_gru=True, bn_train=False):
     B, Ft = segs_feat.shape[0], segs_feat.shape[1]
     T = opt.num_sampled_frm
     D1 = opt.detect_size + 1
     out = {}
     # fc feature: temporal mean ‖ segment-position embedding, each layer-normed (model.py:306-308)
     fc = segs_feat.mean(dim=1)
-    seg_info = F.relu(linear(num[:, 3:7].float(), W, 'seg_info_embed.0'))
+    seg_info = F.relu(linear(num[:, 3:7].to(W['seg_info_embed.0.weight'].dtype), W, 'seg_info_embed.0'))
     fc = torch.cat([F.layer_norm(fc, [fc.shape[-1]]), F.layer_norm(seg_info, [seg_info.shape[-1]])], dim=-1)
     # fc7 on the raw fc6 region features (model.py:311-313)
     g_pool = F.relu(linear(ppls_feat, W, 'ctx2pool_grd.0'))
@@ -240,9 +240,15 @@ def preamble(W, opt, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, fast
     # frame-wise context (model.py:393-405)
     c = torch.cat([F.relu(linear(segs_feat[:, :, :2048], W, 'att_embed.0.0')),
                    F.relu(linear(segs_feat[:, :, 2048:], W, 'att_embed.1.0'))], dim=2)
-    c = F.batch_norm(c.permute(0, 2, 1).contiguous(), W['att_embed_aux.0.running_mean'],
-                     W['att_embed_aux.0.running_var'], W['att_embed_aux.0.weight'],
-                     W['att_embed_aux.0.bias'], False, 0.1, 1e-5)
+    # nn.BatchNorm1d(H) over [B,H,Ft] (model.py:114,397).  eval: running statistics; train (`bn_train`, the dropout-free
+    # train-mode parity case): batch statistics over (B, Ft) and the momentum-0.1 update of CLONES of the running buffers
+    # (returned as out['bn_running'])
+    rm, rv = W['att_embed_aux.0.running_mean'], W['att_embed_aux.0.running_var']
+    if bn_train:
+        rm, rv = rm.clone(), rv.clone()
+        out['bn_running'] = (rm, rv)
+    c = F.batch_norm(c.permute(0, 2, 1).contiguous(), rm, rv, W['att_embed_aux.0.weight'],
+                     W['att_embed_aux.0.bias'], bool(bn_train), 0.1, 1e-5)
     c = F.relu(c).permute(0, 2, 1).contiguous()
     c = gru_bidir_2layer(c, W) if fast_gru else gru_bidir_2layer_loop(c, W)
     idx_mask = torch.ones(B, Ft, 1, dtype=torch.bool)
@@ -348,7 +354,7 @@ def lm_criterion(logp, att2_weights, ground_weights, target, att2_target):
 
 
 def forward_train(W, opt, segs_feat, input_seq, gt_seq, num, ppls, gt_boxes, mask_boxes, ppls_feat,
-                  frm_mask, sample_idx, pnt_mask, eval_obj_ground=False, pre=None):
+                  frm_mask, sample_idx, pnt_mask, eval_obj_ground=False, pre=None, bn_train=False):
     """AttModel._forward (model.py:283-489), seq_per_img = 1.
 
     'MLE' (eval_obj_ground=False) -> (lm_loss, att2_loss, ground_loss, cls_loss) scalars (+ aux dict);
@@ -361,7 +367,7 @@ def forward_train(W, opt, segs_feat, input_seq, gt_seq, num, ppls, gt_boxes, mas
     seq = torch.cat([torch.zeros(B, 1, dtype=seq.dtype), seq], 1)                     # model.py:285-286
     input_seq = input_seq.view(-1, input_seq.shape[2], input_seq.shape[3])            # [B,L+1,4]
     if pre is None:
-        pre = preamble(W, opt, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask)
+        pre = preamble(W, opt, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, bn_train=bn_train)
     pm = pnt_mask.to(torch.uint8)
     fm = frm_mask.to(torch.uint8)
     overlaps = bbox_overlaps(ppls, gt_boxes, fm | pm[:, 1:].unsqueeze(-1))            # model.py:317-318
@@ -406,7 +412,7 @@ def forward_train(W, opt, segs_feat, input_seq, gt_seq, num, ppls, gt_boxes, mas
         roi = torch.stack(labels, 1)
         lm, a2l, gl = lm_criterion(logp, att2_weights, ground, seq[:, 1:Lc + 1], roi)
         aux = dict(att2_weights=att2_weights, ground_weights=ground, roi_labels=roi, frm_masks=fmask_all,
-                   overlaps=overlaps, sim_target=sim_target, logp=logp, seq_cnt=Lc)
+                   overlaps=overlaps, sim_target=sim_target, logp=logp, seq_cnt=Lc, bn_running=pre.get('bn_running'))
         return lm, a2l, gl, cls_loss, aux
     ground = grounder_dot(xt_all, pre['g_pool'], pm[:, 1:], bias + att2_weights)
     T, P = opt.num_sampled_frm, opt.num_prop_per_frm

@@ -68,6 +68,37 @@ def _worker(rank, world, port, outdir):
     red.finish()
     ok &= launched_in_backward == len(red.buckets)     # every bucket was complete before finish()
     ok &= all((a is None and p.grad is None) or torch.allclose(a, p.grad, atol=1e-7) for a, p in zip(avg, m.parameters()))
+    # third step, RANK-ASYMMETRIC: only rank 1 runs the so-far excluded m[3].  The rediscovery is a collective decision
+    # (MAX-reduced flag in finish()): both ranks rebuild the same layout, m[3]'s gradient is averaged in the SAME step
+    # (zeros from rank 0), nothing hangs, and the next step runs on the new layout
+    for p in m.parameters():
+        p.grad = None
+    red.reset()
+    h = m[2](torch.relu(m[0](x)))
+    (m[3](h) if rank == 1 else h).pow(2).mean().backward()
+    local3 = [None if p.grad is None else p.grad.clone() for p in m.parameters()]
+    red.finish()
+    ok &= red.rediscoveries == 1
+    g3 = [None] * world
+    dist.all_gather_object(g3, local3)
+    for i, p in enumerate(m.parameters()):
+        want = sum((g[i] if g[i] is not None else torch.zeros_like(p)) for g in g3) / world
+        ok &= p.grad is not None and torch.allclose(p.grad, want, atol=1e-7)
+    for p in m.parameters():
+        p.grad = None
+    red.reset()
+    m[3](m[2](torch.relu(m[0](x)))).pow(2).mean().backward()
+    ok &= red._next == len(red.buckets)                # the new layout (incl. m[3]) launches from the hooks
+    red.finish()
+    ok &= red.rediscoveries == 1 and all(p.grad is not None for p in m.parameters())
+    # caller status word: MAX over ranks comes back on every rank
+    for p in m.parameters():
+        p.grad = None
+    red.reset()
+    m[3](m[2](torch.relu(m[0](x)))).pow(2).mean().backward()
+    word = red.finish(status=torch.tensor([rank * 7, 0], dtype=torch.int32), defer=True).tolist()
+    red.resolve(word[0])
+    ok &= word == [0, 7 * (world - 1), 0]
     # (2) the real loss on this rank's shard of a batch (oracle), averaged grads == mean of shard grads
     opt = gvd_amd.opts.default_opt(vocab_size=120, t_attn_size=6)
     sd = synth.init_state_dict(opt, seed=4)

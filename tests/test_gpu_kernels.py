@@ -85,8 +85,10 @@ def test_lstm_cell(B):
     assert torch.isfinite(gates).all() and float(gates[:, :H].min()) >= 0.0      # i gate is a sigmoid
 
 
-@pytest.mark.parametrize('B,R,Ft', [(4, 1000, 10), (3, 1000, 480), (40, 1000, 10), (2, 37, 5)])
+@pytest.mark.parametrize('B,R,Ft', [(4, 1000, 10), (3, 1000, 480), (40, 1000, 10), (2, 37, 5), (300, 130, 3)])
 def test_attention_step(B, R, Ft):
+    """The streaming attention kernel against the oracle; (300, 130, 3) launches more than 192 MB -> the nontemporal
+    instantiation."""
     g = _g(B * R + Ft)
     H, A = 1024, 512
     opt = gvd_amd.opts.default_opt(vocab_size=10)
@@ -769,9 +771,8 @@ def test_enc_attn_core_training_matches_autograd(B, R, monkeypatch):
     assert torch.equal(o1, o2) and not torch.equal(o1, O.detach())
 
 
-@pytest.mark.skipif(os.environ.get('GVD_TEST_EXPERIMENTAL') != '1', reason='experimental K-tail path: opt in with GVD_TEST_EXPERIMENTAL=1')
 def test_enc_attn_core_176_column_head_slots():
-    """EXPERIMENTAL: the training attention core over 176-column head slots (K = 176 contractions through the pipelined GEMM's
+    """The training attention core over 176-column head slots (the default for launches on the pipelined GEMM) (K = 176 contractions through the pipelined GEMM's
     shifted tail tile) equals the 192-slot form up to fp32 rounding - output and gradient."""
     g = _g(41)
     B, R, nh, d = 2, 1000, 6, 1024

@@ -72,23 +72,64 @@ def test_attn_bwd_kernels(B, N, masked):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
 
 
-GRAD_CASES = [n for n, s in cases.CASES.items() if s['mode'] == 'MLE' and s['B'] <= 8]
+GRAD_CASES = [n for n, s in cases.CASES.items() if s['mode'] == 'MLE']
+
+# Direction-aware gradient tolerances.  `projection_error` estimates |g - g_ref| / |g_ref| from 8 seeded random
+# projections (cases.grad_projections); parameters whose true gradient is zero (the alpha_net biases: a softmax is shift
+# invariant) hold only rounding noise on both sides and are exempt below NOISE x the largest gradient norm.
+# Why 1e-3-level and not 1e-5: the forward activations of the two fp32 implementations differ by ~1e-6 relative
+# (tools/fwd_diag.py: 1.5e-6 after pool_embed), so about one in a million ReLU pre-activations falls on the other side
+# of zero; ONE such flip in the encoder's feed-forward (1.5 M pre-activations at B = 3) moves the gradient of that unit's
+# bias by ~1 / sqrt(rows) and the Frobenius error of linear1.{weight,bias} to ~1e-3 - measured identically with every
+# fused kernel switched to its library form (tools/grad_diag.py, profiles/r03/grad_diag_c.log), while the CPU oracle
+# in fp32 stays within 1e-5 of its own fp64 run when no flip happens.  A sign-flipped / permuted / mis-routed gradient
+# is off by O(1).
+PROJ_TOL = 5e-3
+ELEM_TOL = 3e-3
+NOISE = 1e-6
+
+
+def _check_projections(named_grads, names, norms, projs, what='grad'):
+    gmax = float(max(norms))
+    worst = (0.0, None)
+    for n, want_norm, want_proj in zip(names, norms, projs):
+        g = named_grads[n]
+        assert g is not None, n
+        if want_norm <= NOISE * gmax:
+            continue
+        err = cases.projection_error(n, g, want_proj, want_norm)
+        worst = max(worst, (err, n))
+        assert err < PROJ_TOL, '%s: %s projections off by %.3g x |reference| (direction / routing error?)' % (n, what, err)
+    print('worst %s projection error %.3g (%s)' % (what, worst[0], worst[1]))
 
 
 @pytest.mark.parametrize('name', GRAD_CASES)
 def test_mle_gradients_match_reference(name, golden_dir):
-    """Eval-mode (dropout off, BN running stats) gradients of lm + w_att2*att2 + w_grd*grd + w_cls*cls: every
-    parameter's gradient L2 norm vs the reference's (oracle/make_golden.py), plus the 4 losses."""
+    """Gradients of lm + w_att2*att2 + w_grd*grd + w_cls*cls against the REFERENCE's own backward (oracle/make_golden.py)
+    at B = 4 ... 64: the 4 losses, every parameter's gradient L2 norm AND its direction (seeded random projections of the
+    reference gradient, so a sign-flipped / permuted / mis-routed gradient of the right magnitude fails).  Eval-mode
+    arithmetic, except the `bn_train` case: train mode with every dropout ratio 0, i.e. BatchNorm batch statistics + the
+    running-statistics update (model.py:114,397)."""
     g = np.load(os.path.join(golden_dir, name + '.npz'))
+    spec = cases.CASES[name]
     opt, sd, inp = cases.build_case(name)
+    assert cases.weight_fingerprint(sd) == int(g['weight_fp']) and cases.input_fingerprint(inp) == int(g['input_fp'])
     model = att_model.TopDownModel(opt)
     model.load_state_dict(sd)
     model = model.cuda().eval()
+    if spec.get('bn_train'):
+        cases.zero_dropout(model).train()
     lm, a2, gl, cl = model(*synth.as_args(inp, 'cuda'), 'MLE')
     np.testing.assert_allclose(np.array([float(lm), float(a2), float(gl), float(cl)]), g['losses'], atol=1e-4)
+    if spec.get('bn_train'):
+        bn = model.att_embed_aux[0]
+        np.testing.assert_allclose(bn.running_mean.cpu().numpy(), g['bn_running_mean'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), g['bn_running_var'], rtol=1e-4, atol=1e-5)
     w = cases.GRAD_WEIGHTS
     (lm.sum() + w['w_att2'] * a2.sum() + w['w_grd'] * gl.sum() + w['w_cls'] * cl.sum()).backward()
-    ref = dict(zip([str(n) for n in g['grad_names']], g['grad_norms']))
+    model.check_kernel_status()
+    names = [str(n) for n in g['grad_names']]
+    ref = dict(zip(names, g['grad_norms']))
     params = dict(model.named_parameters())
     worst = 0.0
     for n, want in ref.items():
@@ -100,6 +141,7 @@ def test_mle_gradients_match_reference(name, golden_dir):
         rel = abs(got - want) / max(want, 1e-3)
         worst = max(worst, rel)
         assert rel < 2e-3, '%s: |grad| %.6g vs reference %.6g' % (n, got, want)
+    _check_projections({n: params[n].grad for n in names}, names, g['grad_norms'], g['grad_proj'])
     for n in ('core.i2h_2.weight', 'core.h2h_2.weight'):
         assert params[n].grad is None or float(params[n].grad.abs().sum()) == 0.0
     print('worst relative grad-norm error', worst)
@@ -109,7 +151,8 @@ def test_mle_gradients_match_reference(name, golden_dir):
 def test_mle_edge_shapes_match_oracle(name):
     """Training edge shapes (oracle/edge_cases.py: one segment, sizes no tile divides, an annotated frame with every
     proposal masked): 4 losses within 1e-4 of the oracle (itself pinned to the reference on these cases by
-    tests/test_oracle_vs_reference.py), every parameter's gradient norm vs the oracle's autograd."""
+    tests/test_oracle_vs_reference.py) and EVERY parameter gradient elementwise against the oracle's autograd:
+    relative Frobenius error <= ELEM_TOL and cosine >= 1 - ELEM_TOL^2 / 2 (zero-true-gradient parameters exempt)."""
     opt, sd, inp = edge_cases.TRAIN_EDGE_CASES[name]()
     W = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v)
          for k, v in sd.items()}
@@ -123,10 +166,22 @@ def test_mle_edge_shapes_match_oracle(name):
     np.testing.assert_allclose(np.array([float(lm), float(a2), float(gl), float(cl)]),
                                np.array([olm.item(), oa2.item(), ogl.item(), ocl.item()]), atol=1e-4)
     (lm.sum() + w['w_att2'] * a2.sum() + w['w_grd'] * gl.sum() + w['w_cls'] * cl.sum()).backward()
+    gmax = max(float(v.grad.double().norm()) for v in W.values() if torch.is_tensor(v) and v.grad is not None)
+    worst = (0.0, None)
     for n, p in model.named_parameters():
-        want = 0.0 if W[n].grad is None else float(W[n].grad.double().norm())
-        got = 0.0 if p.grad is None else float(p.grad.double().norm())
-        assert abs(got - want) / max(want, 1e-3) < 2e-3, '%s: |grad| %.6g vs oracle %.6g' % (n, got, want)
+        want = None if W[n].grad is None else W[n].grad.double()
+        got = None if p.grad is None else p.grad.double().cpu()
+        wn = 0.0 if want is None else float(want.norm())
+        gn = 0.0 if got is None else float(got.norm())
+        assert abs(gn - wn) / max(wn, 1e-3) < 2e-3, '%s: |grad| %.6g vs oracle %.6g' % (n, gn, wn)
+        if wn <= NOISE * gmax:        # unused (i2h_2 / h2h_2) or zero-true-gradient parameters: nothing to compare
+            continue
+        rel = float((got - want).norm()) / wn
+        cos = float((got * want).sum()) / (wn * gn)
+        worst = max(worst, (rel, n))
+        assert rel <= ELEM_TOL and cos >= 1.0 - 0.5 * ELEM_TOL ** 2, \
+            '%s: gradient differs elementwise: rel %.3g, cos %.9f' % (n, rel, cos)
+    print('worst elementwise relative gradient error %.3g (%s)' % worst)
 
 
 STEP_CASES = [n for n, s in cases.CASES.items() if s['mode'] == 'step']
@@ -162,6 +217,16 @@ def test_one_optimisation_step_matches_reference(name, golden_dir):
         # of a softmax-attention alpha_net) can take either sign, so the update norm gets a looser, lr-scaled bound
         if mn > 1e-6:      # (the softmax-shift-invariant alpha_net biases have an exactly-zero true gradient)
             assert abs(got_d - dn) <= 0.02 * dn + 1e-9, '%s: |delta| %.6g vs reference %.6g' % (n, got_d, dn)
+    # direction of the first moments (linear in the clipped gradient) and of the parameter updates themselves
+    names = [str(x) for x in g['step_names']]
+    _check_projections({n: tr.optimizer.state[params[n]]['exp_avg'] for n in names}, names, g['exp_avg_norms'],
+                       g['exp_avg_proj'], what='exp_avg')
+    big = [i for i, mn in enumerate(g['exp_avg_norms']) if mn > 1e-6]
+    for i in big:
+        n = names[i]
+        err = cases.projection_error(n, params[n].detach() - before[n], g['delta_proj'][i], g['delta_norms'][i])
+        # (elements whose gradient is rounding noise move by +-lr either way: looser than the first-moment bound)
+        assert err < 0.05, '%s: update direction off by %.3g x |reference update|' % (n, err)
     for n in ('core.i2h_2.weight', 'core.h2h_2.weight'):
         assert torch.equal(params[n].detach(), before[n])
 
@@ -344,3 +409,5 @@ def test_batch_dp_8x32_matches_reference_shard_by_shard(golden_dir):
     for pn, want in ref.items():
         got = float(params[pn].grad.double().norm())
         assert abs(got - want) / max(want, 1e-3) < 2e-3, '%s: |grad| %.6g vs reference %.6g' % (pn, got, want)
+    names = [str(x) for x in g['grad_names']]
+    _check_projections({pn: params[pn].grad for pn in names}, names, g['grad_norms'], g['grad_proj'], what='dp-mean grad')

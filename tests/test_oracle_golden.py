@@ -48,26 +48,35 @@ def test_greedy_matches_reference(name, golden_dir):
 def test_mle_losses_match_reference(name, golden_dir):
     g = _load(golden_dir, name)
     opt, sd, inp = _build(name, g)
-    want_grad = 'grad_norms' in g
+    spec = cases.CASES[name]
+    want_grad = 'grad_norms' in g and spec['B'] <= 8      # (the B = 32 / 64 backward takes minutes on CPU: GPU tests only)
+    bn_train = bool(spec.get('bn_train'))
     W = sd
     if want_grad:
         W = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v)
              for k, v in sd.items()}
     ctx = torch.enable_grad() if want_grad else torch.no_grad()
     with ctx:
-        lm, a2, gl, cl, aux = O.forward_train(W, opt, *[inp[k] for k in gvd_amd.synth.FORWARD_ORDER])
+        lm, a2, gl, cl, aux = O.forward_train(W, opt, *[inp[k] for k in gvd_amd.synth.FORWARD_ORDER], bn_train=bn_train)
     got = np.array([lm.item(), a2.item(), gl.item(), cl.item()], dtype=np.float32)
     np.testing.assert_allclose(got, g['losses'], rtol=0, atol=1e-4)    # BASELINE tolerance
+    if bn_train:      # train-mode BatchNorm also moved its running statistics (model.py:114,397)
+        np.testing.assert_allclose(aux['bn_running'][0].numpy(), g['bn_running_mean'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(aux['bn_running'][1].numpy(), g['bn_running_var'], rtol=1e-5, atol=1e-6)
     if cases.CASES[name].get('max_cap_len'):
         assert aux['seq_cnt'] < opt.seq_length                         # early `break` exercised (model.py:425)
     if want_grad:
         w = cases.GRAD_WEIGHTS
         (lm + w['w_att2'] * a2 + w['w_grd'] * gl + w['w_cls'] * cl).backward()
         ref = dict(zip([str(n) for n in g['grad_names']], g['grad_norms']))
+        proj = dict(zip([str(n) for n in g['grad_names']], g['grad_proj']))
         for n, v in W.items():
             if n in ref:
                 assert v.grad is not None, n
                 np.testing.assert_allclose(float(v.grad.double().norm()), ref[n], rtol=1e-4, atol=1e-7)
+                # direction: seeded random projections of the gradient (cases.grad_projections)
+                if ref[n] > 1e-6:
+                    assert cases.projection_error(n, v.grad, proj[n], ref[n]) < 1e-4, n
             elif v.is_floating_point() and v.requires_grad:
                 assert v.grad is None or float(v.grad.abs().sum()) == 0.0, n   # i2h_2/h2h_2: unused
 
@@ -130,10 +139,12 @@ def test_one_optimisation_step_matches_reference(name, golden_dir):
     before = {k: v.detach().clone() for k, v in W.items() if torch.is_tensor(v) and v.requires_grad}
     optim.step()
     assert abs(total - float(g['total_grad_norm'])) / float(g['total_grad_norm']) < 1e-4
-    for n, dn, mn in zip([str(x) for x in g['step_names']], g['delta_norms'], g['exp_avg_norms']):
+    for k, (n, dn, mn) in enumerate(zip([str(x) for x in g['step_names']], g['delta_norms'], g['exp_avg_norms'])):
         assert abs(float(optim.state[W[n]]['exp_avg'].double().norm()) - mn) / max(mn, 1e-7) < 1e-3, n
         if mn > 1e-6:
             assert abs(float((W[n].detach() - before[n]).double().norm()) - dn) <= 0.02 * dn + 1e-9, n
+            # direction of the first moment (linear in the clipped gradient)
+            assert cases.projection_error(n, optim.state[W[n]]['exp_avg'], g['exp_avg_proj'][k], mn) < 1e-3, n
 
 
 def test_gru_loop_matches_fused():

@@ -53,6 +53,10 @@ def parse():
     ap.add_argument('--beam', type=int, default=1, help='beam size (1 = greedy; 5 = BASELINE configs[4])')
     ap.add_argument('--frames', type=int, default=10, help='sampled frames T (regions R = 100*T; configs[4] uses 20)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="torch.distributed backend: 'nccl' (= RCCL over xGMI, the product path) or 'gloo' - the only way to run "
+                         'N > 1 ranks on a box with ONE GPU (ranks share cuda:0; RCCL refuses two ranks on one device): used to '
+                         'exercise the N-rank code path end to end where no multi-GPU node is available, never for numbers')
     ap.add_argument('--no-sections', action='store_true',
                     help='default line only: skip the short configs[2] (train B=64) and configs[4] (beam=5 x 20 frames, '
                          'B=64) sections and the GEMM roofline pass that the default run appends to its JSON line')
@@ -197,6 +201,17 @@ def _static_traffic(B, Ft, R):
 
 
 
+def _max_and_per_rank(elapsed, dev, use_dist, gloo):
+    """MAX over ranks of the timed region (the contract's clock) + every rank's own time (so a straggler is visible)."""
+    if not use_dist:
+        return elapsed, [round(elapsed, 6)]
+    t = torch.tensor([elapsed], device='cpu' if gloo else dev, dtype=torch.float64)
+    allt = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(allt, t)
+    per = [round(float(x), 6) for x in allt]
+    return max(per), per
+
+
 def _roofline_mfma(hip, run, steps, label):
     """FLOPs of the pipelined fp32-MFMA GEMM launches (csrc/gemm_pipe.hip) / their HIP-event time, in a dedicated pass of
     `steps` calls of run() OUTSIDE the timed region (the hook adds a one-thread flop-counter kernel per launch).  Rows come
@@ -324,11 +339,17 @@ def bench_train(args, opt, sd, model, B, rank, world, dev):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ops.set_kernel_timer(None)
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    elapsed, per_rank = _max_and_per_rank(elapsed, dev, use_dist, args.dist_backend == 'gloo')
     attn_ms, attn_n = timer.read()
+    dp_timeline = None
+    if tr.reducer.active:
+        # one extra step (all ranks, outside the timed region) with the reducer's launch trace on: at which point of the
+        # backward pass each gradient bucket's all-reduce was issued = the window the collective can hide in
+        tr.reducer.trace = True
+        tr.step(a)
+        torch.cuda.synchronize()
+        dp_timeline = tr.reducer.launch_timeline()
+        tr.reducer.trace = False
     if rank == 0:
         R = opt.num_sampled_frm * opt.num_prop_per_frm
         A, H, Ft = opt.att_hid_size, opt.rnn_size, args.t_attn
@@ -341,6 +362,8 @@ def bench_train(args, opt, sd, model, B, rank, world, dev):
                                    'w_grd=%.2f w_cls=%.2f' % (B, args.t_attn, args.vocab, opt.w_att2, opt.w_grd, opt.w_cls),
                        'batch_per_gpu': B, 'parallelism': 'dp%d (RCCL bucketed grad all-reduce)' % world},
             'losses_last': [round(float(x), 5) for x in losses],
+            'per_rank_seconds': per_rank,
+            'dp_bucket_launches': dp_timeline,
             # the kernel that dominates THIS mode: the pipelined fp32-MFMA GEMM (forward, dX, dW products; ~75 % of the
             # step), measured in one extra step after the timed region
             'roofline': (_roofline_mfma(hip, lambda: tr.step(a), 1, 'forward, dX and dW (K-strided) products of the step')
@@ -361,12 +384,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.dist_backend == 'gloo':
+        local = local % max(torch.cuda.device_count(), 1)      # (ranks may share a device: code-path runs on a 1-GPU box)
     torch.cuda.set_device(local)
     use_dist = 'RANK' in os.environ        # launched by torch.distributed.run (also for a single rank)
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        if args.dist_backend == 'gloo':
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
     if world != args.gpus:
         sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     dev = torch.device('cuda', local)
@@ -452,10 +480,7 @@ def main():
         elapsed = time.perf_counter() - t0
     ops.set_kernel_timer(None)
     model.check_kernel_status()          # outside the timed region: no persistent-kernel barrier timed out
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    elapsed, per_rank = _max_and_per_rank(elapsed, dev, use_dist, args.dist_backend == 'gloo')
     attn_ms, attn_n = timer.read()
 
     if rank == 0:
@@ -472,7 +497,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32', 'data': 'synthetic', 'per_rank_seconds': per_rank,
             'config': {'workload': "%s 'sample' (preamble + 20-token loop), %d segments/GPU/step, L=20, "
                                    "T x P = %d x 100 regions [B,%d,2048] fc6 + [B,%d,3072] frame feats, V=%d, "
                                    "obj_interact on; random-init weights (trained_like profile)"

@@ -5,6 +5,9 @@
 // every row whose mask byte is set (proposal below prop_thresh / beyond num_pps, frame beyond num_frm) is zero-filled.
 // One 64-lane wave per row, 16-byte stores when the row allows it; rows that are kept are not touched at all.
 #include "gvd_common.h"
+#include <errno.h>
+#include <sys/uio.h>
+#include <unistd.h>
 
 namespace {
 
@@ -35,4 +38,39 @@ extern "C" int gvd_zero_masked_rows(float* x, int64_t rows, int D, const uint8_t
                      mask, rows_per_batch, mask_ld, mask_off);
   GVD_CHECK_LAUNCH();
   return 0;
+}
+
+// Host side of the ingest (no GPU work): read `rows` rows of `row_bytes` bytes that lie back to back in a file (a .npy
+// payload) into destination rows that are `dst_stride` bytes apart - the frame-feature files are column blocks of the wider
+// segs_feat rows (dataloader_anet.py:198-206).  One pread when the destination is contiguous, otherwise scatter reads
+// (preadv, up to 1024 rows per call) straight from the page cache into the pinned staging rows: no contiguous scratch copy,
+// no Python object per row, and - called through ctypes - no GIL while it runs, so the reader threads scale.
+extern "C" int64_t gvd_pread_rows(int fd, int64_t file_off, void* dst, int64_t rows, int64_t row_bytes, int64_t dst_stride) {
+  if (fd < 0 || file_off < 0 || !dst || rows < 0 || row_bytes <= 0 || dst_stride < row_bytes) return -EINVAL;
+  char* d = static_cast<char*>(dst);
+  int64_t done = 0;
+  if (dst_stride == row_bytes) {
+    const int64_t want = rows * row_bytes;
+    while (done < want) {
+      const ssize_t n = pread(fd, d + done, (size_t)(want - done), (off_t)(file_off + done));
+      if (n < 0) { if (errno == EINTR) continue; return -errno; }
+      if (n == 0) break;
+      done += n;
+    }
+    return done;
+  }
+  constexpr int IOV = 1024;
+  struct iovec iov[IOV];
+  int64_t r = 0;
+  while (r < rows) {
+    const int n = (int)(rows - r < IOV ? rows - r : IOV);
+    for (int i = 0; i < n; ++i) { iov[i].iov_base = d + (r + i) * dst_stride; iov[i].iov_len = (size_t)row_bytes; }
+    const int64_t want = (int64_t)n * row_bytes;
+    const ssize_t got = preadv(fd, iov, n, (off_t)(file_off + done));
+    if (got < 0) { if (errno == EINTR) continue; return -errno; }
+    done += got;
+    if (got != want) break;          // short read (end of file): the caller compares with rows * row_bytes
+    r += n;
+  }
+  return done;
 }

@@ -77,6 +77,8 @@ class GradAllReducer:
         self._discovered = False
         self._late = False          # an excluded parameter got a gradient on THIS rank since the last finish()
         self._word = None
+        self.trace = False          # record a stream event at reset(), at every bucket launch and at finish() (bench.py)
+        self._tev = None
         self.rediscoveries = 0
         self._hooks = []
         self._handles = []
@@ -123,10 +125,31 @@ class GradAllReducer:
         self._pending = [len(b['params']) for b in self.buckets]
         self._next = 0             # buckets [0, _next) have been launched
         self._handles = []
+        if self.trace and self.all_params and self.all_params[0].is_cuda:
+            self._tev = {'t0': self._event(), 'launch': [], 'finish': None}
+
+    @staticmethod
+    def _event():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def launch_timeline(self):
+        """After a traced step (trace = True) and a device sync: when, on the compute stream's clock, each bucket's
+        all-reduce was issued relative to the step's start and to the end of backward -> the window the collective has to
+        hide in.  [{'bucket', 'mbytes', 'launched_ms', 'backward_end_ms'}]"""
+        t = self._tev_done if hasattr(self, '_tev_done') else None
+        if not t or t['finish'] is None:
+            return []
+        end = t['t0'].elapsed_time(t['finish'])
+        return [{'bucket': bi, 'mbytes': round(self.buckets[bi]['numel'] * 4 / 1e6, 1) if bi < len(self.buckets) else None,
+                 'launched_ms': round(t['t0'].elapsed_time(e), 3), 'backward_end_ms': round(end, 3)} for bi, e in t['launch']]
 
     def _launch(self, bi):
         b = self.buckets[bi]
         flat = b['flat']
+        if self._tev is not None:
+            self._tev['launch'].append((bi, self._event()))
         for p, o in zip(b['params'], b['offsets']):
             if p.grad is None:
                 flat[o:o + p.numel()].zero_()
@@ -188,6 +211,8 @@ class GradAllReducer:
             return None if status is None else torch.cat([status.new_zeros(1), status])
         if not self._discovered:
             self._discover()
+        if self._tev is not None:
+            self._tev['finish'] = self._event()            # = end of backward on the compute stream
         dev = self.all_params[0].device
         word = torch.zeros(1 + (0 if status is None else status.numel()), dtype=torch.int32, device=dev)
         if self._late:
@@ -199,6 +224,8 @@ class GradAllReducer:
         self._drain()
         wh.wait()
         self._late = False
+        if self._tev is not None:
+            self._tev_done, self._tev = self._tev, None
         self.reset()
         if not defer:
             self.resolve(int(word[0].item()))

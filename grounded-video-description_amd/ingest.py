@@ -24,7 +24,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import torch
 
-from . import ops
+from . import hip, ops
 
 
 def _npy_open(path):
@@ -41,18 +41,20 @@ def _npy_open(path):
 
 
 def _read_rows_into(path, dst, max_rows):
-    """read() the first min(rows, max_rows) rows of a [..., D] float32 .npy straight into `dst` (a C-contiguous
-    [>= rows, D] float32 view of the pinned staging buffer): one kernel copy from the page cache, no mmap page faults,
-    no intermediate array, GIL released.  Returns (rows_read, rows_in_file)."""
+    """Read the first min(rows, max_rows) rows of a [..., D] float32 .npy straight into `dst`, a float32 [>= rows, D] view
+    of the pinned staging buffer whose rows may be a COLUMN BLOCK of wider rows (the frame features `<vid>_resnet.npy
+    [F,2048]` / `_bn.npy [F,1024]` are the two column blocks of segs_feat's 3072-wide rows, dataloader_anet.py:198-206).
+    One native call (gvd_pread_rows: pread, or scatter preadv for strided rows) from the page cache into the pinned rows -
+    no mmap page faults, no intermediate array, no Python object per row, GIL released.  Returns (rows_read, rows_in_file)."""
     f, shape = _npy_open(path)
     try:
         D = shape[-1]
         rows_file = int(np.prod(shape[:-1]))
         rows = min(rows_file, max_rows)
-        assert dst.shape[1] == D and dst.flags['C_CONTIGUOUS']
+        assert dst.shape[1] == D and dst.strides[1] == 4 and dst.dtype == np.float32
         if rows:
             want = rows * D * 4
-            got = f.readinto(memoryview(dst[:rows]).cast('B'))
+            got = hip.lib().gvd_pread_rows(f.fileno(), f.tell(), dst.ctypes.data, rows, D * 4, dst.strides[0])
             if got != want:
                 raise IOError('%s: short read (%d of %d bytes)' % (path, got, want))
         return rows, rows_file
@@ -84,7 +86,12 @@ class InferenceIngest:
     """records: dicts with seg_id '<vid>_segment_<k>', n_seg_in_vid, timestamps (t0, t1), duration, proposals [n,7]."""
 
     def __init__(self, opt, feature_root, seg_feature_root, device=None, max_batch=256, exclude_bgd_det=False,
-                 workers=8, depth=2):
+                 workers=None, depth=2):
+        if workers is None:
+            # one segment is three page-cache -> pinned-memory copies (8 + 4 + 2 MB at Ft = 480): a host thread moves
+            # ~3 GB/s, so the reader pool is sized to the host, not to a fixed 8 (measured on the 256-thread GPU box:
+            # tools/ingest_bench.py)
+            workers = max(8, min(48, (os.cpu_count() or 8) // 4))
         self.opt = opt
         self.feature_root, self.seg_feature_root = feature_root, seg_feature_root
         self.device = device
@@ -116,16 +123,11 @@ class InferenceIngest:
         m[0] = 0                                                          # legacy pad column, main.py:345
         m[1:1 + n_pps] = masked[:n_pps]
         m[1 + n_pps:] = 1
-        # frame features: the two files are column blocks of one row, so they go through small contiguous scratch
-        if not hasattr(self._tls, 'rgb'):           # per-thread scratch
-            self._tls.rgb = np.empty((self.Ft, 2048), dtype=np.float32)
-            self._tls.motion = np.empty((self.Ft, opt.fc_feat_size - 2048), dtype=np.float32)
-        d_rgb, d_mot = self._tls.rgb, self._tls.motion
-        n_frm, num_frm = _read_rows_into(os.path.join(self.seg_feature_root, vid[2:] + '_resnet.npy'), d_rgb, self.Ft)
-        _read_rows_into(os.path.join(self.seg_feature_root, vid[2:] + '_bn.npy'), d_mot, self.Ft)
+        # frame features: the two files are the two column blocks of one 3072-wide row -> scatter reads straight into the
+        # pinned rows
         seg = slot.segs[b].numpy()
-        np.copyto(seg[:n_frm, :d_rgb.shape[1]], d_rgb[:n_frm])
-        np.copyto(seg[:n_frm, d_rgb.shape[1]:], d_mot[:n_frm])
+        n_frm, num_frm = _read_rows_into(os.path.join(self.seg_feature_root, vid[2:] + '_resnet.npy'), seg[:, :2048], self.Ft)
+        _read_rows_into(os.path.join(self.seg_feature_root, vid[2:] + '_bn.npy'), seg[:, 2048:], self.Ft)
         fm = slot.fmask[b].numpy()
         fm[:n_frm] = 0
         fm[n_frm:] = 1

@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 8
+#define GVD_ABI_VERSION 9
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -405,6 +405,12 @@ int gvd_greedy_decode(const gvd_greedy_args* args, gvd_stream_t stream);
  * column is passed with mask_ld = R+1, mask_off = 1).  Rows that are kept are not touched. */
 int gvd_zero_masked_rows(float* x, int64_t rows, int D, const uint8_t* mask, int64_t rows_per_batch, int64_t mask_ld,
                          int64_t mask_off, gvd_stream_t stream);
+
+/* Host helper of the ingest (no GPU work): pread `rows` back-to-back file rows of `row_bytes` bytes at `file_off` into
+ * destination rows `dst_stride` bytes apart (pinned staging; a column block of wider rows when dst_stride > row_bytes:
+ * the <vid>_resnet.npy / _bn.npy blocks of segs_feat, dataloader_anet.py:198-206).  Returns the bytes read (the caller
+ * checks == rows * row_bytes) or -errno.  Called through ctypes it runs without the GIL. */
+int64_t gvd_pread_rows(int fd, int64_t file_off, void* dst, int64_t rows, int64_t row_bytes, int64_t dst_stride);
 
 /* ---------------------------------------------------------------------------------------------
  * Training targets and losses

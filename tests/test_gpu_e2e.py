@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import gvd_amd
-from gvd_amd import att_model, synth
+from gvd_amd import att_model, hip, synth
 from oracle import cases, edge_cases, gvd_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -131,6 +131,8 @@ def test_forward_api_sample(golden_dir):
 def test_mle_losses_match_reference(name, golden_dir):
     g, opt, sd, inp = _case(name, golden_dir)
     model = _model(opt, sd)
+    if cases.CASES[name].get('bn_train'):       # train mode, every dropout ratio 0: BatchNorm batch statistics (no_grad
+        cases.zero_dropout(model).train()       # inference-kernel path of the preamble with train-mode modules)
     with torch.no_grad():
         out = model(*synth.as_args(inp, 'cuda'), 'MLE')
     assert len(out) == 4 and all(tuple(o.shape) == (1,) for o in out)     # model.py:483
@@ -335,3 +337,66 @@ def test_eval_grounding_files(golden_dir, tmp_path):
     assert got_g['results'] == json.loads(json.dumps(want_g))
     want_cls, _ = driver.class_accuracy(torch.from_numpy(g['cls_pred']), vocab)
     assert abs(cls - want_cls) < 1e-12 and attn == 0.0 and grd == 0.0
+
+
+def test_forward_sample_computes_inputs_that_break_the_zero_row_loader_contract():
+    """Masked proposals (pnt_mask = 1) with NON-zero fc6 features / boxes are inputs the reference accepts (model.py:311-391
+    computes every row; they still take part in the encoder's self-attention as keys).  The compacted preamble's premise
+    does not hold for them: forward(..., 'sample') notices (device flag, read with the call's one status read) and decodes
+    the batch again through the dense preamble - ids / attended regions equal the oracle's on the same inputs."""
+    opt, sd, inp = edge_cases.EDGE_CASES['masked_frames']()
+    g = torch.Generator().manual_seed(3)
+    pm = inp['pnt_mask'][:, 1:].bool()
+    inp = {k: v.clone() for k, v in inp.items()}
+    inp['ppls_feat'][pm] = torch.relu(torch.randn(int(pm.sum()), inp['ppls_feat'].shape[-1], generator=g))
+    inp['ppls'][pm] = torch.rand(int(pm.sum()), inp['ppls'].shape[-1], generator=g) * 100
+    oseq, olps, oatt2, _ = edge_cases.oracle_greedy(opt, sd, inp)
+    model = _model(opt, sd)
+    with torch.no_grad():
+        seq, att2, sim = model(*synth.as_args(inp, 'cuda'), 'sample', {'sample_max': 1, 'beam_size': 1})
+    assert torch.equal(seq.cpu(), oseq)
+    assert torch.equal(O.attended_region_indices(att2.cpu(), opt), O.attended_region_indices(oatt2, opt))
+    np.testing.assert_allclose(att2.cpu().numpy(), oatt2.numpy(), rtol=1e-4, atol=2e-4)
+    # the private driver tells its direct callers instead of silently returning the compacted result
+    with torch.no_grad():
+        model._sample(*[inp[k].cuda() for k in ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')])
+    with pytest.raises(hip.GvdHipError):
+        model.check_kernel_status()
+
+
+def test_two_threads_two_streams_call_the_model_concurrently():
+    """nn.DataParallel (main.py:655) calls the replicas from one Python thread each.  On this 1-GPU box: two threads, each
+    on its own HIP stream, decode different batches through ONE model object at the same time (shared weight-pack cache,
+    shared status-flag lists, per-call workspaces) - the results equal the serial ones."""
+    import threading
+    opt = gvd_amd.opts.default_opt(vocab_size=1200, t_attn_size=10)
+    sd = synth.init_state_dict(opt, seed=31, profile='trained_like')
+    model = _model(opt, sd)
+    keys = ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')
+    batches = [[synth.make_inputs(opt, B, seed=40 + i, train=False)[k].cuda() for k in keys] for i, B in enumerate((8, 12))]
+    with torch.no_grad():
+        serial = [model._sample(*b) for b in batches]
+    model.check_kernel_status()
+    torch.cuda.synchronize()
+    out, err = [None, None], []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s), torch.no_grad():
+                for _ in range(3):
+                    seq, att2, sim = model(batches[i][0], None, None, batches[i][2], batches[i][1], None, None, batches[i][3],
+                                           None, batches[i][4], batches[i][5], 'sample', {'sample_max': 1, 'beam_size': 1})
+                s.synchronize()
+            out[i] = (seq, att2)
+        except Exception as e:          # noqa: BLE001 (reported by the assertion below)
+            err.append(repr(e))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for i in range(2):
+        assert torch.equal(out[i][0], serial[i][0])
+        assert torch.equal(out[i][1], serial[i][2])

@@ -267,6 +267,24 @@ def test_bench_under_torchrun_single_rank(mode):
     assert j['n_gpus'] == 1 and j['value'] > 0 and j['steps'] == 2
 
 
+@pytest.mark.parametrize('mode', ['sample', 'train'])
+def test_bench_two_ranks_share_the_one_gpu(mode):
+    """The N = 2 path of bench.py end to end on a 1-GPU box: torch.distributed.run with two ranks that share cuda:0 over
+    gloo (--dist-backend gloo; RCCL refuses two ranks on one device) - per-rank shards, barrier, the bucketed gradient
+    all-reduce from the autograd hooks (train), MAX + per-rank times.  A code-path run, not a measurement."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', '29631', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2',
+           '--warmup', '1', '--batch', '8', '--vocab', '1000', '--no-cpu-baseline', '--mode', mode, '--dist-backend', 'gloo']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert j['n_gpus'] == 2 and j['value'] > 0 and len(j['per_rank_seconds']) == 2
+    assert abs(j['ms_per_step'] * 2 / 1e3 - max(j['per_rank_seconds'])) < 1e-3
+
+
 @pytest.mark.parametrize('B,R', [(2, 40), (3, 100)])
 def test_region_feature_rows_train_forward_and_backward(B, R):
     """ops.region_feature_rows_train (fused row kernel forward + fused backward) against autograd through the ATen form

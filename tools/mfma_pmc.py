@@ -1,21 +1,71 @@
-"""Workload for MFMA-utilisation PMC passes: the hot-path GEMM shapes on the pipelined kernel (fc7, fused QKV), the
-decode-step shapes north_star names (attn_hid = both h2att queries, logit) and the padded-head flash attention kernel."""
-import os, sys
+"""Workloads for MFMA-utilisation PMC passes, one section per invocation so that a pass's counters can be grouped by kernel
+name alone:   python tools/mfma_pmc.py <section>
+  fc7 | qkv            plain products of the preamble on the pipelined kernel (gemm_pipe_kernel, direct-to-LDS operands)
+  dx | dw              K-strided backward products of nn.Linear (dX = dY W, dW = dY^T X), training shapes at B = 64
+  attn_core            the six products of the training attention core over 176-column head slots (K-tail / EDGE tiles)
+  logit | attn_hid | lstm   the token-loop products north_star names, B = 256 (gemm_small_kernel)
+  flash                padded-head flash attention (inference encoder), B = 256"""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-import gvd_amd
-from gvd_amd import ops
-def gemm(M, N, K, n=3):
-    A = torch.randn(M, K, device='cuda'); W = torch.randn(N, K, device='cuda') / K ** 0.5; b = torch.randn(N, device='cuda')
-    out = torch.empty(M, N, device='cuda')
+import torch  # noqa: E402
+import gvd_amd  # noqa: E402,F401
+from gvd_amd import ops  # noqa: E402
+
+sec = sys.argv[1]
+dev = 'cuda'
+
+
+def gemm(M, N, K, n=4):
+    A = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev)
+    out = torch.empty(M, N, device=dev)
     for _ in range(n):
         ops.gemm_nt(A, W, b, 0, out=out)
-gemm(256000, 2048, 2048)        # fc7                      -> gemm_pipe_kernel<true>, grid 32000
-gemm(256000, 3168, 1024)        # fused q|k|v              -> grid 50000
-gemm(256, 5000, 1024, 6)        # logit   (decode step)    -> gemm_nt_kernel<64,64>
-gemm(256, 1024, 1024, 6)        # attn_hid (both h2att queries stacked)
-qkv = torch.randn(256, 1000, 18 * ops.HEAD_PAD, device='cuda') * 0.5
-qkv.view(256, 1000, 18, ops.HEAD_PAD)[..., 171:] = 0
-for _ in range(3):
-    ops.flash_attn_padded(qkv, 6, 1.0 / 32.0)
+
+
+if sec == 'fc7':
+    gemm(256000, 2048, 2048)
+elif sec == 'qkv':
+    gemm(256000, 3168, 1024)
+elif sec == 'dx':
+    dY = torch.randn(64 * 1024, 3168, device=dev)
+    W = torch.randn(3168, 1024, device=dev)
+    for _ in range(4):
+        assert ops.gemm_dx(dY, W) is not None
+elif sec == 'dw':
+    dY = torch.randn(64 * 1024, 1024, device=dev)
+    X = torch.randn(64 * 1024, 2784, device=dev)
+    for _ in range(4):
+        assert ops.gemm_dw(dY, X) is not None
+elif sec == 'attn_core':
+    B, R, nh, HP = 64, 1000, 6, 176
+    Rp = 1024
+    qkv = torch.zeros(B, Rp, 3, nh, HP, device=dev)
+    qkv[..., :171] = torch.randn(B, Rp, 3, nh, 171, device=dev) * 0.5
+    qkv = qkv.reshape(B, Rp, 3 * nh * HP).requires_grad_(True)
+    for _ in range(2):
+        o = ops.enc_attn_core(qkv, R, nh, 1.0 / 32, 0.0)
+        o.backward(torch.randn_like(o))
+        qkv.grad = None
+elif sec == 'logit':
+    gemm(256, 5000, 1024, 8)
+elif sec == 'attn_hid':
+    gemm(256, 1024, 1024, 8)
+elif sec == 'lstm':
+    B, H = 256, 1024
+    x, h, c = torch.randn(B, 1536, device=dev), torch.randn(B, H, device=dev), torch.randn(B, H, device=dev)
+    w_ih, w_hh = torch.randn(4 * H, 1536, device=dev) * 0.02, torch.randn(4 * H, H, device=dev) * 0.02
+    b = torch.zeros(4 * H, device=dev)
+    for _ in range(8):
+        ops.lstm_cell([x], [w_ih], h, w_hh, b, b, c)
+elif sec == 'flash':
+    qkv = torch.randn(256, 1000, 18 * ops.HEAD_PAD, device=dev) * 0.5
+    qkv.view(256, 1000, 18, ops.HEAD_PAD)[..., 171:] = 0
+    for _ in range(3):
+        ops.flash_attn_padded(qkv, 6, 1.0 / 32.0)
+else:
+    raise SystemExit('unknown section ' + sec)
 torch.cuda.synchronize()

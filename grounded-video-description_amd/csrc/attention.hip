@@ -58,7 +58,7 @@ __device__ __forceinline__ T ld_stream(const T* ptr) {
 }
 
 template <bool NT>
-__global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
+__global__ __launch_bounds__(256, 8) void attn_partial_kernel(const FwdParams p) {   // 8 waves / SIMD (<= 64 VGPRs, no spill)
   __shared__ float s_score[MAX_CHUNK];
   __shared__ float s_red[8];
   __shared__ int s_live[MAX_CHUNK];
@@ -191,11 +191,14 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const FwdParams p) {
 // ("shared across beams in a batched redesign").  Partials are written per beam row in the layout
 // attn_combine_kernel expects.  grid = (chunks, samples).
 template <int G, bool NT>
-__global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams p) {
+__global__ __launch_bounds__(256, 6) void attn_partial_group_kernel(const FwdParams p) {   // >= 6 waves / SIMD: <= 80 VGPRs
   __shared__ float s_score[G][MAX_CHUNK];
   __shared__ float s_m[G];
   __shared__ int s_live[MAX_CHUNK];
   __shared__ int s_n[2];
+  // the G pre-scaled queries live in LDS, not in 8 G registers per lane: with them in registers the kernel needed 105
+  // VGPRs at G = 5 (4 waves per SIMD; PMC: 2.9 resident on average, 70 % of the wave cycles parked on memory)
+  __shared__ __attribute__((aligned(16))) float s_q[G][ATT_A];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int smp = blockIdx.y;                    // sample; its beam rows are smp*G + g
   int c = blockIdx.x;
@@ -207,12 +210,10 @@ __global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams
   const int rows = min(S.chunk, S.N - n0);
 
   const AttnLaneW W = attn_lane_w(S.w, lane);
-  f32x4 q0[G], q1[G];                             // pre-scaled queries (tanh_fast, gvd_common.h)
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const float* qb = S.q + (int64_t)(smp * G + g) * S.ldq;
-    q0[g] = GVD_TWO_LOG2E * *reinterpret_cast<const f32x4*>(qb + 4 * lane);
-    q1[g] = GVD_TWO_LOG2E * *reinterpret_cast<const f32x4*>(qb + 256 + 4 * lane);
+  for (int i = tid; i < G * (ATT_A / 4); i += 256) {      // pre-scaled queries (tanh_fast, gvd_common.h)
+    const int g = i / (ATT_A / 4), a4 = i % (ATT_A / 4);
+    *reinterpret_cast<f32x4*>(&s_q[g][4 * a4]) =
+        GVD_TWO_LOG2E * *reinterpret_cast<const f32x4*>(S.q + (int64_t)(smp * G + g) * S.ldq + 4 * a4);
   }
   const float ab = *S.alpha_bias;
   const float* pf = S.p_feats + ((int64_t)smp * S.N + n0) * ATT_A;
@@ -245,27 +246,43 @@ __global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams
   }
   __syncthreads();
   const int nlive = s_n[0];
-  // ---- phase 1: one projection row per wave per pass, G scores from it
-  for (int i = wave; i < nlive; i += 4) {
-    const int r = s_live[i];
+  // ---- phase 1: two projection rows per wave per pass (4 x 16 B per lane in flight), G scores from each
+  for (int i = wave * 2; i < nlive; i += 8) {
+    const bool two = (i + 1) < nlive;
+    const int r = s_live[i], r2 = two ? s_live[i + 1] : r;
     const float* p0 = pf + (int64_t)r * ATT_A;
-    const f32x4 x0 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 4 * lane));
-    const f32x4 x1 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane));
-    float sc[G];
+    const float* p1 = pf + (int64_t)r2 * ATT_A;
+    const f32x4 x00 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 4 * lane));
+    const f32x4 x01 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane));
+    const f32x4 x10 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 4 * lane));
+    const f32x4 x11 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 256 + 4 * lane));
+    float sc0[G], sc1[G];
+    int lz = 0;
+    asm volatile("" : "+v"(lz));       // opaque 0: keeps the query reads inside the row loop (loop-invariant code motion
+                                       // would put all 8 G of them back into registers)
 #pragma unroll
-    for (int g = 0; g < G; ++g) sc[g] = wave_sum(attn_score_lane(x0, x1, q0[g], q1[g], W)) + ab;
-    if (lane < G) {
-      float e = 0.f;
+    for (int g = 0; g < G; ++g) {
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(&s_q[g][4 * lane + lz]);
+      const f32x4 q1 = *reinterpret_cast<const f32x4*>(&s_q[g][256 + 4 * lane + lz]);
+      sc0[g] = wave_sum(attn_score_lane(x00, x01, q0, q1, W)) + ab;
+      sc1[g] = wave_sum(attn_score_lane(x10, x11, q0, q1, W)) + ab;
+    }
+    if (lane < 2 * G) {
+      const int g = lane % G, second = lane / G;
+      if (!second || two) {
+        float e = 0.f;
 #pragma unroll
-      for (int g = 0; g < G; ++g) if (lane == g) e = sc[g];
-      const int64_t row = (int64_t)smp * G + lane;
-      const bool am = S.att_mask && S.att_mask[row * S.ld_att_mask + n0 + r];
-      if (am) e = GVD_MIN_VALUE;
-      s_score[lane][r] = e;
-      if (S.scores_out) S.scores_out[row * S.ld_scores + n0 + r] = e;
-      if (S.logits_out) {
-        const bool pm = S.pnt_mask && S.pnt_mask[row * S.ld_pnt_mask + n0 + r];
-        S.logits_out[row * S.ld_logits + n0 + r] = pm ? GVD_MIN_VALUE : e;
+        for (int gg = 0; gg < G; ++gg) if (g == gg) e = second ? sc1[gg] : sc0[gg];
+        const int rr = second ? r2 : r;
+        const int64_t row = (int64_t)smp * G + g;
+        const bool am = S.att_mask && S.att_mask[row * S.ld_att_mask + n0 + rr];
+        if (am) e = GVD_MIN_VALUE;
+        s_score[g][rr] = e;
+        if (S.scores_out) S.scores_out[row * S.ld_scores + n0 + rr] = e;
+        if (S.logits_out) {
+          const bool pm = S.pnt_mask && S.pnt_mask[row * S.ld_pnt_mask + n0 + rr];
+          S.logits_out[row * S.ld_logits + n0 + rr] = pm ? GVD_MIN_VALUE : e;
+        }
       }
     }
   }
@@ -293,15 +310,15 @@ __global__ __launch_bounds__(256) void attn_partial_group_kernel(const FwdParams
   const bool skip = s_n[1] != 0;                 // every beam has a live row: rows masked for all beams weigh exactly 0
   const int nctx = skip ? nlive : rows;
   int i = 0;
-  for (; i + 4 <= nctx; i += 4) {
-    f32x4 v[4];
-    int rr[4];
+  for (; i + 8 <= nctx; i += 8) {                // 8 feature rows (8 x 16 B per lane) in flight
+    f32x4 v[8];
+    int rr[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) rr[u] = skip ? s_live[i + u] : i + u;
+    for (int u = 0; u < 8; ++u) rr[u] = skip ? s_live[i + u] : i + u;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)rr[u] * ATT_H));
+    for (int u = 0; u < 8; ++u) v[u] = ld_stream<NT>(reinterpret_cast<const f32x4*>(fb + (int64_t)rr[u] * ATT_H));
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 8; ++u)
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const float pw = s_score[g][rr[u]];

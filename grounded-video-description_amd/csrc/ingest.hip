@@ -6,6 +6,9 @@
 // One 64-lane wave per row, 16-byte stores when the row allows it; rows that are kept are not touched at all.
 #include "gvd_common.h"
 #include <errno.h>
+#include <fcntl.h>
+#include <stdlib.h>
+#include <string.h>
 #include <sys/uio.h>
 #include <unistd.h>
 
@@ -73,4 +76,71 @@ extern "C" int64_t gvd_pread_rows(int fd, int64_t file_off, void* dst, int64_t r
     r += n;
   }
   return done;
+}
+
+// Open a float32 C-ordered .npy file, parse its header (format 1.0 / 2.0 / 3.0: magic, version, header length, the Python
+// dict literal with 'descr', 'fortran_order', 'shape'), and read its first min(rows, max_rows) rows - rows = product of all
+// but the last dimension, which must equal D - into destination rows `dst_stride` bytes apart (gvd_pread_rows).  The whole
+// per-file work of the ingest as ONE native call: no Python header parsing (ast.literal_eval), no file object, no GIL.
+// Returns the rows in the file (>= 0; *rows_read = rows copied) or a negative code: -errno, or -1000 - k for a malformed /
+// unsupported header (k: 1 magic, 2 header length, 3 dtype, 4 order, 5 shape, 6 last dimension, 7 short read).
+extern "C" int64_t gvd_npy_read_rows_f32(const char* path, void* dst, int64_t max_rows, int64_t D, int64_t dst_stride,
+                                         int64_t* rows_read) {
+  if (!path || !dst || max_rows < 0 || D <= 0 || dst_stride < D * 4 || !rows_read) return -EINVAL;
+  *rows_read = 0;
+  const int fd = open(path, O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return -errno;
+  char buf[4096];
+  const ssize_t got = pread(fd, buf, sizeof(buf) - 1, 0);
+  int64_t rc = 0, hlen = 0, hoff = 0;
+  if (got < 10 || memcmp(buf, "\x93NUMPY", 6) != 0) rc = -1001;
+  if (!rc) {
+    const unsigned char* u = reinterpret_cast<const unsigned char*>(buf);
+    if (u[6] == 1) { hlen = u[8] | (u[9] << 8); hoff = 10; }
+    else if (u[6] == 2 || u[6] == 3) { hlen = (int64_t)u[8] | ((int64_t)u[9] << 8) | ((int64_t)u[10] << 16) | ((int64_t)u[11] << 24); hoff = 12; }
+    else rc = -1001;
+    if (!rc && (hlen <= 0 || hoff + hlen > got)) rc = -1002;
+  }
+  int64_t rows_file = 1, last = -1;
+  if (!rc) {
+    buf[hoff + hlen] = 0;
+    const char* h = buf + hoff;
+    const char* d = strstr(h, "'descr'");
+    if (!d || !(strstr(d, "'<f4'") || strstr(d, "'=f4'") || strstr(d, "'|f4'"))) rc = -1003;
+    const char* f = strstr(h, "'fortran_order'");
+    if (!rc && (!f || !strstr(f, "False") || (strstr(f, "True") && strstr(f, "True") < strstr(f, "False")))) rc = -1004;
+    const char* sh = strstr(h, "'shape'");
+    const char* q = sh ? strchr(sh, '(') : nullptr;
+    if (!rc && !q) rc = -1005;
+    if (!rc) {
+      ++q;
+      int nd = 0;
+      int64_t prod = 1;
+      while (*q && *q != ')') {
+        while (*q == ' ' || *q == ',') ++q;
+        if (*q == ')' || !*q) break;
+        char* e = nullptr;
+        const long long v = strtoll(q, &e, 10);
+        if (e == q || v < 0) { rc = -1005; break; }
+        if (last >= 0) prod *= last;
+        last = v;
+        ++nd;
+        q = e;
+      }
+      if (!rc && nd == 0) rc = -1005;
+      rows_file = prod;
+      if (!rc && last != D) rc = -1006;
+    }
+  }
+  if (!rc) {
+    const int64_t rows = rows_file < max_rows ? rows_file : max_rows;
+    if (rows > 0) {
+      const int64_t n = gvd_pread_rows(fd, hoff + hlen, dst, rows, D * 4, dst_stride);
+      if (n < 0) rc = n;
+      else if (n != rows * D * 4) rc = -1007;
+    }
+    if (!rc) { *rows_read = rows; rc = rows_file; }
+  }
+  close(fd);
+  return rc;
 }

@@ -149,6 +149,7 @@ _SIG = {
     'gvd_greedy_workspace_bytes': (C.c_size_t, [C.c_int] * 7),
     'gvd_greedy_decode': (C.c_int, [C.POINTER(GreedyArgs), C.c_void_p]),
     'gvd_pread_rows': (C.c_int64, [C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
+    'gvd_npy_read_rows_f32': (C.c_int64, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
     'gvd_zero_masked_rows': (C.c_int, [c_f32p, C.c_int64, C.c_int, c_u8p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     'gvd_iou_targets': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_u8p, c_u8p, C.c_int, C.c_int, C.c_int,
                                   c_f32p, c_i64p, C.c_void_p]),
@@ -161,7 +162,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 9        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 10        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

@@ -17,6 +17,7 @@ zeroing â€” three full passes over 8 MB per sample on the CPU in the reference â
 (`gvd_zero_masked_rows`, touches only the rows it clears).  Staging is double-buffered so batch i+1 is read and copied
 while batch i is being decoded.  All compute is in the HIP library: there is no CPU fallback for the device half.
 """
+import ctypes as C
 import os
 import threading
 from concurrent.futures import ThreadPoolExecutor
@@ -27,39 +28,49 @@ import torch
 from . import hip, ops
 
 
-def _npy_open(path):
-    """Open a .npy file and parse its header: (file positioned at the data, shape).  float32, C order only â€” the
-    layout the reference's feature extractors write."""
-    f = open(path, 'rb', buffering=0)
-    version = np.lib.format.read_magic(f)
-    shape, fortran, dtype = (np.lib.format.read_array_header_1_0(f) if version == (1, 0)
-                             else np.lib.format.read_array_header_2_0(f))
-    if fortran or dtype != np.float32:
-        f.close()
-        raise ValueError('%s: expected a C-ordered float32 array, got %s%s' % (path, dtype, ' (F order)' if fortran else ''))
-    return f, shape
-
-
 def _read_rows_into(path, dst, max_rows):
     """Read the first min(rows, max_rows) rows of a [..., D] float32 .npy straight into `dst`, a float32 [>= rows, D] view
     of the pinned staging buffer whose rows may be a COLUMN BLOCK of wider rows (the frame features `<vid>_resnet.npy
     [F,2048]` / `_bn.npy [F,1024]` are the two column blocks of segs_feat's 3072-wide rows, dataloader_anet.py:198-206).
-    One native call (gvd_pread_rows: pread, or scatter preadv for strided rows) from the page cache into the pinned rows -
-    no mmap page faults, no intermediate array, no Python object per row, GIL released.  Returns (rows_read, rows_in_file)."""
-    f, shape = _npy_open(path)
+    ONE native call per file (gvd_npy_read_rows_f32: open, header parse, pread - scatter preadv for strided rows - from the
+    page cache into the pinned rows): no mmap page faults, no intermediate array, no Python header parsing or file object,
+    GIL released.  Returns (rows_read, rows_in_file)."""
+    assert dst.strides[1] == 4 and dst.dtype == np.float32
+    n = C.c_int64(0)
+    rc = hip.lib().gvd_npy_read_rows_f32(os.fsencode(path), dst.ctypes.data, min(max_rows, dst.shape[0]), dst.shape[1],
+                                         dst.strides[0], C.byref(n))
+    if rc < 0:
+        if rc <= -1000:
+            raise ValueError('%s: not a C-ordered float32 .npy with last dimension %d (reader code %d)' % (path, dst.shape[1], rc))
+        raise OSError(-rc, os.strerror(-rc), path)
+    return n.value, rc
+
+
+def _local_node_cpus():
+    """CPUs of the NUMA node the calling thread runs on (intersected with the process's affinity mask), or None when the
+    topology cannot be read.  The pinned staging buffers and - for page-cache-resident files written by this process - the
+    file pages are first-touched from the constructing thread, so readers on the same node copy node-locally; readers
+    spread over both sockets of the 256-thread GPU host were measured SLOWER the more of them there were."""
     try:
-        D = shape[-1]
-        rows_file = int(np.prod(shape[:-1]))
-        rows = min(rows_file, max_rows)
-        assert dst.shape[1] == D and dst.strides[1] == 4 and dst.dtype == np.float32
-        if rows:
-            want = rows * D * 4
-            got = hip.lib().gvd_pread_rows(f.fileno(), f.tell(), dst.ctypes.data, rows, D * 4, dst.strides[0])
-            if got != want:
-                raise IOError('%s: short read (%d of %d bytes)' % (path, got, want))
-        return rows, rows_file
-    finally:
-        f.close()
+        cpu = os.sched_getcpu()
+        allowed = os.sched_getaffinity(0)
+        base = '/sys/devices/system/node'
+        for d in os.listdir(base):
+            if not d.startswith('node') or not d[4:].isdigit():
+                continue
+            cpus = set()
+            with open(os.path.join(base, d, 'cpulist')) as f:
+                for part in f.read().strip().split(','):
+                    if not part:
+                        continue
+                    a, _, b = part.partition('-')
+                    cpus.update(range(int(a), int(b or a) + 1))
+            if cpu in cpus:
+                cpus &= allowed
+                return cpus or None
+    except (OSError, ValueError, AttributeError):
+        pass
+    return None
 
 
 class _Slot:
@@ -76,6 +87,10 @@ class _Slot:
         self.fmask = buf(max_batch, Ft, dtype=torch.uint8)
         self.num = buf(max_batch, 7, dtype=torch.int64)
         self.sidx = buf(max_batch, 2, dtype=torch.int64)
+        # numpy views of the same memory for the host half (no per-segment tensor -> array conversions)
+        self.feat_np, self.segs_np, self.ppls_np = self.feat.numpy(), self.segs.numpy(), self.ppls.numpy()
+        self.mask_np, self.fmask_np = self.mask.numpy(), self.fmask.numpy()
+        self.num_np, self.sidx_np = self.num.numpy(), self.sidx.numpy()
         self.n_pps = [0] * max_batch
         self.n_frm = [0] * max_batch
         self.B = 0
@@ -86,12 +101,14 @@ class InferenceIngest:
     """records: dicts with seg_id '<vid>_segment_<k>', n_seg_in_vid, timestamps (t0, t1), duration, proposals [n,7]."""
 
     def __init__(self, opt, feature_root, seg_feature_root, device=None, max_batch=256, exclude_bgd_det=False,
-                 workers=None, depth=2):
+                 workers=None, depth=2, numa_local=None):
+        if numa_local is None:
+            numa_local = os.environ.get('GVD_INGEST_NUMA', '1') == '1'
         if workers is None:
             # one segment is three page-cache -> pinned-memory copies (8 + 4 + 2 MB at Ft = 480): a host thread moves
             # ~3 GB/s, so the reader pool is sized to the host, not to a fixed 8 (measured on the 256-thread GPU box:
             # tools/ingest_bench.py)
-            workers = max(8, min(48, (os.cpu_count() or 8) // 4))
+            workers = max(8, min(32, (os.cpu_count() or 8) // 4))
         self.opt = opt
         self.feature_root, self.seg_feature_root = feature_root, seg_feature_root
         self.device = device
@@ -101,7 +118,15 @@ class InferenceIngest:
         pin = device is not None
         self.slots = [_Slot(max_batch, self.R, self.Ft, opt.att_feat_size, opt.fc_feat_size, pin) for _ in range(depth)]
         self.max_batch = max_batch
-        self.pool = ThreadPoolExecutor(max_workers=workers)
+        cpus = _local_node_cpus() if numa_local else None
+
+        def pin_worker(cpus=cpus):
+            if cpus:
+                try:
+                    os.sched_setaffinity(0, cpus)         # (0 = the calling THREAD on Linux)
+                except OSError:
+                    pass
+        self.pool = ThreadPoolExecutor(max_workers=workers, initializer=pin_worker)
         self.copy_stream = torch.cuda.Stream(device=device) if device is not None else None
         self._next = 0
         self._tls = threading.local()
@@ -113,31 +138,31 @@ class InferenceIngest:
         vid, seg_idx = seg_id.split('_segment_')
         props = np.asarray(rec['proposals'], dtype=np.float64)
         n = props.shape[0]
-        n_pps, rows_file = _read_rows_into(os.path.join(self.feature_root, seg_id + '.npy'), slot.feat[b].numpy(), self.R)
+        n_pps, rows_file = _read_rows_into(os.path.join(self.feature_root, seg_id + '.npy'), slot.feat_np[b], self.R)
         assert n == rows_file, 'proposal count does not match the region feature file'          # l.191
         masked = props[:, 6] <= opt.prop_thresh                                                   # l.194-196
         if self.exclude_bgd_det:
             masked |= props[:, 5] == 0
-        slot.ppls[b, :n_pps] = torch.from_numpy(props[:n_pps]).float()
-        m = slot.mask[b].numpy()
+        slot.ppls_np[b, :n_pps] = props[:n_pps]                           # (float64 -> float32 rounding, as .float())
+        m = slot.mask_np[b]
         m[0] = 0                                                          # legacy pad column, main.py:345
         m[1:1 + n_pps] = masked[:n_pps]
         m[1 + n_pps:] = 1
         # frame features: the two files are the two column blocks of one 3072-wide row -> scatter reads straight into the
         # pinned rows
-        seg = slot.segs[b].numpy()
+        seg = slot.segs_np[b]
         n_frm, num_frm = _read_rows_into(os.path.join(self.seg_feature_root, vid[2:] + '_resnet.npy'), seg[:, :2048], self.Ft)
         _read_rows_into(os.path.join(self.seg_feature_root, vid[2:] + '_bn.npy'), seg[:, 2048:], self.Ft)
-        fm = slot.fmask[b].numpy()
+        fm = slot.fmask_np[b]
         fm[:n_frm] = 0
         fm[n_frm:] = 1
         t0, t1 = rec['timestamps']
         dur = rec['duration']
         sidx = np.array([np.round(num_frm * t0 * 1. / dur), np.round(num_frm * t1 * 1. / dur)])   # l.207-208
-        slot.sidx[b] = torch.from_numpy(np.clip(np.round(sidx), 0, self.Ft).astype(np.int64))
-        # main.py copies the FloatTensor `num` into a LongTensor: the two time stamps truncate
-        numf = torch.FloatTensor([1, n_pps, 0, int(seg_idx), rec['n_seg_in_vid'], t0 * 1. / dur, t1 * 1. / dur])
-        slot.num[b] = numf.long()
+        slot.sidx_np[b] = np.clip(np.round(sidx), 0, self.Ft).astype(np.int64)
+        # main.py copies the FloatTensor `num` into a LongTensor: float32 rounding, then the two time stamps truncate
+        slot.num_np[b] = np.array([1, n_pps, 0, int(seg_idx), rec['n_seg_in_vid'], t0 * 1. / dur, t1 * 1. / dur],
+                                  dtype=np.float32).astype(np.int64)
         slot.n_pps[b], slot.n_frm[b] = n_pps, n_frm
 
     def stage(self, records):
@@ -175,13 +200,35 @@ class InferenceIngest:
             fmask.copy_(slot.fmask[:B], non_blocking=True)
             num.copy_(slot.num[:B], non_blocking=True)
             sidx.copy_(slot.sidx[:B], non_blocking=True)
-            for b in range(B):                     # valid rows only: contiguous chunks of the pinned buffers
-                n, f = slot.n_pps[b], slot.n_frm[b]
+            # valid rows only, as few copies as the layout allows: a run of segments whose rows are all valid is ONE
+            # contiguous chunk of the pinned buffer and of the device tensor (the ANet-Entities files hold T x 100 proposals
+            # for every segment, so normally the whole batch is one copy per tensor); ragged segments go one by one
+            def runs(counts, full):
+                b = 0
+                while b < B:
+                    e = b
+                    while e < B and counts[e] == full:
+                        e += 1
+                    if e > b:
+                        yield b, e, full
+                        b = e
+                    else:
+                        yield b, b + 1, counts[b]
+                        b += 1
+            for b0, b1, n in runs(slot.n_pps, self.R if Rb == self.R else -1):
                 if n:
-                    feat[b, :n].copy_(slot.feat[b, :n], non_blocking=True)
-                    ppls[b, :n].copy_(slot.ppls[b, :n], non_blocking=True)
+                    if b1 - b0 > 1 or n == self.R == Rb:
+                        feat[b0:b1].copy_(slot.feat[b0:b1], non_blocking=True)
+                        ppls[b0:b1].copy_(slot.ppls[b0:b1], non_blocking=True)
+                    else:
+                        feat[b0, :n].copy_(slot.feat[b0, :n], non_blocking=True)
+                        ppls[b0, :n].copy_(slot.ppls[b0, :n], non_blocking=True)
+            for b0, b1, f in runs(slot.n_frm, self.Ft):
                 if f:
-                    segs[b, :f].copy_(slot.segs[b, :f], non_blocking=True)
+                    if f == self.Ft:
+                        segs[b0:b1].copy_(slot.segs[b0:b1], non_blocking=True)
+                    else:
+                        segs[b0, :f].copy_(slot.segs[b0, :f], non_blocking=True)
             extra = self._device_extras(slot, ppls, Rb, dev)      # needs the proposals BEFORE masked rows are zeroed
             ops.zero_masked_rows(feat, mask, mask_off=1)
             ops.zero_masked_rows(ppls, mask, mask_off=1)

@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 9
+#define GVD_ABI_VERSION 10
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -411,6 +411,13 @@ int gvd_zero_masked_rows(float* x, int64_t rows, int D, const uint8_t* mask, int
  * the <vid>_resnet.npy / _bn.npy blocks of segs_feat, dataloader_anet.py:198-206).  Returns the bytes read (the caller
  * checks == rows * row_bytes) or -errno.  Called through ctypes it runs without the GIL. */
 int64_t gvd_pread_rows(int fd, int64_t file_off, void* dst, int64_t rows, int64_t row_bytes, int64_t dst_stride);
+
+/* One file of the feature layout in one native call: open `path` (.npy, float32, C order, last dimension D), parse the header,
+ * read the first min(rows_in_file, max_rows) rows into destination rows `dst_stride` bytes apart.  Returns rows_in_file
+ * (*rows_read = rows copied) or < 0: -errno, or -1000 - k for a malformed / unsupported header.  Replaces np.load of
+ * dataloader_anet.py:189,198-199 for the pinned-staging pipeline (no Python object per file, GIL released). */
+int64_t gvd_npy_read_rows_f32(const char* path, void* dst, int64_t max_rows, int64_t D, int64_t dst_stride,
+                              int64_t* rows_read);
 
 /* ---------------------------------------------------------------------------------------------
  * Training targets and losses

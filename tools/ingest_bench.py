@@ -13,7 +13,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 BS = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 WS = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else '16').split(',')]
 W = WS[0]
-opt = gvd_amd.opts.default_opt(t_attn_size=480)
+FT = int(os.environ.get('FT', '480'))
+opt = gvd_amd.opts.default_opt(t_attn_size=FT)
 root = tempfile.mkdtemp(dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
 fr, sr, recs = IO.write_synthetic_dataset(root, opt, n_videos=(N + 3) // 4, segs_per_video=(4,), seed=1, num_frm=(300, 480, 600),
                                            short_props=False)
@@ -32,8 +33,8 @@ torch.cuda.synchronize()
 ta = time.perf_counter() - t0
 print('(a) reference-style CPU padding/masking + H2D : %.1f segments/s' % (n / ta))
 # (b) pipeline, for every worker count asked for
-for W in WS:
-    ing = ingest.InferenceIngest(opt, fr, sr, device=dev, max_batch=BS, workers=W)
+for W, numa in [(w, n) for n in (True, False) for w in WS]:
+    ing = ingest.InferenceIngest(opt, fr, sr, device=dev, max_batch=BS, workers=W, numa_local=numa)
     for _ in ing.batches(recs[:BS], BS):
         pass
     torch.cuda.synchronize()
@@ -44,7 +45,8 @@ for W in WS:
             n += len(chunk)
     torch.cuda.synchronize()
     tb = time.perf_counter() - t0
-    print('(b) pinned staging (%d threads) + async H2D + GPU zero fill: %.1f segments/s (%.2f GB/s of features)'
-          % (W, n / tb, n / tb * (1000 * 2048 * 4 + 480 * 3072 * 4) / 1e9), flush=True)
+    print('(b) pinned staging (%d threads, %s) + async H2D + GPU zero fill, Ft=%d: %.1f segments/s (%.2f GB/s of features)'
+          % (W, 'node-local' if numa else 'unpinned', FT, n / tb, n / tb * (1000 * 2048 * 4 + min(FT, 480) * 3072 * 4) / 1e9),
+          flush=True)
     del ing
 import shutil; shutil.rmtree(root, ignore_errors=True)

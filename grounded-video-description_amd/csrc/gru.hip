@@ -19,6 +19,7 @@
 // state accesses, 2.1 us vs 10.6 us for a release/acquire-fence counter) publishes h_t for the next step.
 #include "gvd_common.h"
 #include <hip/hip_cooperative_groups.h>
+#include <stdlib.h>
 
 namespace cg = cooperative_groups;
 
@@ -28,8 +29,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int GRU_HH = 512;     // hidden size per direction
-constexpr int GRU_HU = 8;       // hidden units per workgroup
-constexpr int GRU_NW = GRU_HH / GRU_HU;   // workgroups per direction
+constexpr int GRU_HU = 8;       // hidden units per workgroup (batches of at most 64 rows; 16 above: see gru_layer_kernel)
+constexpr int GRU_NW = GRU_HH / GRU_HU;   // workgroups per direction at HU = 8
 constexpr int MAX_TILES = 8;    // batch tiles of 32 rows per launch (B <= 256 per launch)
 constexpr int LDA = GRU_HH + 4; // padded LDS row of an h tile: conflict-free ds_read_b128 over 32 rows
 
@@ -42,17 +43,25 @@ struct GruParams {
   int B, T;
 };
 
-template <bool CG_SYNC>
+// HU = hidden units per workgroup.  HU = 8: 2 x 64 workgroups per group (24 of the 32 MFMA columns used), up to two groups
+// sharing the batch tiles.  HU = 16 (batches of more than 64 rows): 2 x 32 workgroups per group, 48 columns = two MFMA column
+// tiles per batch tile, up to FOUR groups - every workgroup then stages (and waits at a barrier pair for) half as many 64 KB
+// h_{t-1} tiles per time step, which is what the step cost at B = 256 was made of (19.6 us: 4 tiles x (staging from L2 +
+// two barriers) per workgroup against 6.8 us of MFMAs).  Same k order per output -> bitwise equal results for both HU.
+template <bool CG_SYNC, int HU>
 __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
+  constexpr int NWG = GRU_HH / HU;                 // workgroups per direction and group
+  constexpr int NCT = (3 * HU + 31) / 32;          // MFMA column tiles (1 or 2)
+  constexpr int NU = HU / 8;                       // hidden units per thread in the gate phase
+  constexpr int LDP = 3 * HU + 1;                  // s_part row stride (odd: conflict-free column reads)
   __shared__ __attribute__((aligned(16))) float s_a[2][32 * LDA];   // double-buffered h_{t-1} batch tiles
-  __shared__ float s_part[4][32][33];
+  __shared__ float s_part[4][32][LDP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, half = lane >> 5;
-  // grid = nparts x (2 directions x 64 unit slices): with more than one 32-row batch tile the batch tiles are dealt
-  // to nparts = 2 groups of 128 workgroups, so all 256 CUs work and the per-step tile loop is half as long
-  const int lid = blockIdx.x % (2 * GRU_NW), part = blockIdx.x / (2 * GRU_NW), nparts = gridDim.x / (2 * GRU_NW);
-  const int dir = lid / GRU_NW;
-  const int j0 = (lid % GRU_NW) * GRU_HU;
+  // grid = nparts x (2 directions x NWG unit slices): the batch tiles are dealt to the nparts groups
+  const int lid = blockIdx.x % (2 * NWG), part = blockIdx.x / (2 * NWG), nparts = gridDim.x / (2 * NWG);
+  const int dir = lid / NWG;
+  const int j0 = (lid % NWG) * HU;
   const int B = p.B, T = p.T;
   const int nt_all = (B + 31) / 32;
   const int nt_per = (nt_all + nparts - 1) / nparts;
@@ -64,25 +73,31 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
   // h_t is exchanged between workgroups inside this launch: all accesses of `out` are agent-coherent (sc1)
   const __amdgpu_buffer_rsrc_t out_rs = gvd_rsrc(p.out);
 
-  // ---- this lane's slice of W_hh: column `col` of the tile = gate col/HU, unit j0 + col%HU (cols >= 24 unused);
-  //      register-resident for the whole sequence
-  f32x4 wreg[16];
-  {
-    const bool used = col < 3 * GRU_HU;
-    const int wrow = used ? (col / GRU_HU) * GRU_HH + j0 + (col % GRU_HU) : 0;
+  // ---- this lane's slice of W_hh: column c = 32 ct + col of the workgroup's 3 HU columns = gate c / HU, unit
+  //      j0 + c % HU (columns >= 3 HU unused); register-resident for the whole sequence
+  f32x4 wreg[NCT][16];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int c = 32 * ct + col;
+    const bool used = c < 3 * HU;
+    const int wrow = used ? (c / HU) * GRU_HH + j0 + (c % HU) : 0;
     const float* wp = p.w_hh[dir] + (int64_t)wrow * GRU_HH + wave * 128 + half * 4;
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (used) v = *reinterpret_cast<const f32x4*>(wp + kb * 8);
-      wreg[kb] = v;
+      wreg[ct][kb] = v;
     }
   }
-  // gate-phase role: thread = (row r = tid/8 of the batch tile, unit jj = tid%8)
+  // gate-phase role: thread = (row r = tid/8 of the batch tile, units jj = tid%8 + 8 u, u < NU)
   const int g_row = tid >> 3, g_jj = tid & 7;
-  const float bh_r = p.b_hh[dir][j0 + g_jj];
-  const float bh_z = p.b_hh[dir][GRU_HH + j0 + g_jj];
-  const float bh_n = p.b_hh[dir][2 * GRU_HH + j0 + g_jj];
+  float bh_r[NU], bh_z[NU], bh_n[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    bh_r[u] = p.b_hh[dir][j0 + g_jj + 8 * u];
+    bh_z[u] = p.b_hh[dir][GRU_HH + j0 + g_jj + 8 * u];
+    bh_n[u] = p.b_hh[dir][2 * GRU_HH + j0 + g_jj + 8 * u];
+  }
   // staging role: 16 x 16-byte pieces per thread per tile; piece i -> tile row (tid + 256 i) / 128, float4 column % 128
   // (a wave-load covers 1 KiB contiguous of one sample's h_{t-1}: fully coalesced)
 
@@ -113,16 +128,21 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
     };
     // gate-phase inputs (gi_r, gi_z, gi_n, own h_{t-1}) are fetched one batch tile ahead so their latency hides
     // behind the MFMA phase of the current tile
-    float cur_r = 0.f, cur_z = 0.f, cur_n = 0.f, cur_h = 0.f, nxt_r = 0.f, nxt_z = 0.f, nxt_n = 0.f, nxt_h = 0.f;
-    auto load_gate_inputs = [&](int mt, float& r_, float& z_, float& n_, float& h_) {
+    float cur_r[NU], cur_z[NU], cur_n[NU], cur_h[NU], nxt_r[NU], nxt_z[NU], nxt_n[NU], nxt_h[NU];
+    auto load_gate_inputs = [&](int mt, float* r_, float* z_, float* n_, float* h_) {
       const int b = (tile0 + mt) * 32 + g_row;
-      r_ = z_ = n_ = h_ = 0.f;
-      if (b < B) {
-        const float* gip = p.gi + (int64_t)b * ld_gi + (int64_t)t * 6 * GRU_HH + dir * 3 * GRU_HH + j0 + g_jj;
-        r_ = gip[0]; z_ = gip[GRU_HH]; n_ = gip[2 * GRU_HH];
-        if (step > 0) h_ = ld_agent_f32(out_rs, (unsigned)(((int64_t)b * ld_out + off_tp + j0 + g_jj) * 4));
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        r_[u] = z_[u] = n_[u] = h_[u] = 0.f;
+        if (b < B) {
+          const float* gip = p.gi + (int64_t)b * ld_gi + (int64_t)t * 6 * GRU_HH + dir * 3 * GRU_HH + j0 + g_jj + 8 * u;
+          r_[u] = gip[0]; z_[u] = gip[GRU_HH]; n_[u] = gip[2 * GRU_HH];
+          if (step > 0) h_[u] = ld_agent_f32(out_rs, (unsigned)(((int64_t)b * ld_out + off_tp + j0 + g_jj + 8 * u) * 4));
+        }
       }
     };
+#pragma unroll
+    for (int u = 0; u < NU; ++u) cur_r[u] = cur_z[u] = cur_n[u] = cur_h[u] = nxt_r[u] = nxt_z[u] = nxt_n[u] = nxt_h[u] = 0.f;
     if (ntiles > 0) {
       load_gate_inputs(0, cur_r, cur_z, cur_n, cur_h);
       if (step > 0) load_tile(0);
@@ -137,40 +157,55 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
         store_tile(abuf);
         __syncthreads();
         if (mt + 1 < ntiles) load_tile(mt + 1);            // next tile's loads fly during this tile's MFMAs
-        f32x16 acc;
+        f32x16 acc[NCT];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
         const float* ap = abuf + col * LDA + wave * 128 + half * 4;
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) {
           const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kb * 8);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wreg[kb][s], acc, 0, 0, 0);
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+              acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wreg[ct][kb][s], acc[ct], 0, 0, 0);
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-          s_part[wave][row][col] = acc[e];
+        for (int ct = 0; ct < NCT; ++ct) {
+          if (32 * ct + col < 3 * HU) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+              s_part[wave][row][32 * ct + col] = acc[ct][e];
+            }
+          }
         }
       }
       if (mt + 1 < ntiles) load_gate_inputs(mt + 1, nxt_r, nxt_z, nxt_n, nxt_h);
       __syncthreads();
       const int b = (tile0 + mt) * 32 + g_row;
       if (b < B) {
-        float gr = bh_r, gz = bh_z, gn = bh_n;
-        if (step > 0) {
-          gr += s_part[0][g_row][g_jj] + s_part[1][g_row][g_jj] + s_part[2][g_row][g_jj] + s_part[3][g_row][g_jj];
-          gz += s_part[0][g_row][GRU_HU + g_jj] + s_part[1][g_row][GRU_HU + g_jj] + s_part[2][g_row][GRU_HU + g_jj] +
-                s_part[3][g_row][GRU_HU + g_jj];
-          gn += s_part[0][g_row][2 * GRU_HU + g_jj] + s_part[1][g_row][2 * GRU_HU + g_jj] +
-                s_part[2][g_row][2 * GRU_HU + g_jj] + s_part[3][g_row][2 * GRU_HU + g_jj];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const int jj = g_jj + 8 * u;
+          float gr = bh_r[u], gz = bh_z[u], gn = bh_n[u];
+          if (step > 0) {
+            gr += s_part[0][g_row][jj] + s_part[1][g_row][jj] + s_part[2][g_row][jj] + s_part[3][g_row][jj];
+            gz += s_part[0][g_row][HU + jj] + s_part[1][g_row][HU + jj] + s_part[2][g_row][HU + jj] +
+                  s_part[3][g_row][HU + jj];
+            gn += s_part[0][g_row][2 * HU + jj] + s_part[1][g_row][2 * HU + jj] +
+                  s_part[2][g_row][2 * HU + jj] + s_part[3][g_row][2 * HU + jj];
+          }
+          const float r = sigmoid_f(cur_r[u] + gr);
+          const float z = sigmoid_f(cur_z[u] + gz);
+          const float n = tanhf(cur_n[u] + r * gn);
+          st_agent_f32(out_rs, (unsigned)(((int64_t)b * ld_out + off_t + j0 + jj) * 4), (1.f - z) * n + z * cur_h[u]);
         }
-        const float r = sigmoid_f(cur_r + gr);
-        const float z = sigmoid_f(cur_z + gz);
-        const float n = tanhf(cur_n + r * gn);
-        st_agent_f32(out_rs, (unsigned)(((int64_t)b * ld_out + off_t + j0 + g_jj) * 4), (1.f - z) * n + z * cur_h);
       }
-      cur_r = nxt_r; cur_z = nxt_z; cur_n = nxt_n; cur_h = nxt_h;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { cur_r[u] = nxt_r[u]; cur_z[u] = nxt_z[u]; cur_n[u] = nxt_n[u]; cur_h[u] = nxt_h[u]; }
       // s_part is rewritten only after the next tile's staging barrier (or the grid barrier); s_a[mt&1] is rewritten
       // two tiles later, i.e. after two more barriers: no extra barrier needed here.  For step == 0 (no staging
       // barrier) s_part is not used at all.
@@ -268,14 +303,36 @@ extern "C" int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const 
     p.sync = sync_ws ? reinterpret_cast<unsigned*>(sync_ws) + (size_t)GVD_SYNC_WORDS * si : nullptr;
     if ((int64_t)nb * T * 2 * GRU_HH * 4 >= (int64_t)0x7fffffff) return GVD_EINVAL;   // 32-bit buffer offsets
     void* args[] = {&p};
-    // cooperative launch in both modes: it validates that all 128 workgroups are co-resident
-    const void* fn = sync_ws ? reinterpret_cast<const void*>(gru_layer_kernel<false>)
-                             : reinterpret_cast<const void*>(gru_layer_kernel<true>);
-    const int nparts = (nb > 32 && gru_cus() >= 4 * GRU_NW) ? 2 : 1;
-    hipError_t e = hipLaunchCooperativeKernel(fn, dim3(nparts * 2 * GRU_NW), dim3(256), args, 0, st);
-    if (e != hipSuccess && nparts == 2) {   // 256 workgroups not co-resident here: one group of 128
-      (void)hipGetLastError();
-      e = hipLaunchCooperativeKernel(fn, dim3(2 * GRU_NW), dim3(256), args, 0, st);
+    // cooperative launch in both modes: it validates that all workgroups are co-resident.
+    // More than 64 rows (3+ batch tiles): 16 hidden units per workgroup, the tiles dealt to up to 4 groups of 64
+    // workgroups; otherwise 8 units per workgroup and up to 2 groups of 128 (GVD_GRU_HU=8 / 16 forces one form).
+    static const int hu_env = getenv("GVD_GRU_HU") ? atoi(getenv("GVD_GRU_HU")) : 0;
+    const bool wide = hu_env ? hu_env == 16 : nb > 64;
+    const int ntiles = (nb + 31) / 32;
+    hipError_t e;
+    if (wide) {
+      const void* fn = sync_ws ? reinterpret_cast<const void*>(gru_layer_kernel<false, 16>)
+                               : reinterpret_cast<const void*>(gru_layer_kernel<true, 16>);
+      const int per = 2 * (GRU_HH / 16);
+      int nparts = gru_cus() / per;
+      if (nparts > ntiles) nparts = ntiles;
+      if (nparts > 4) nparts = 4;
+      if (nparts < 1) nparts = 1;
+      e = hipLaunchCooperativeKernel(fn, dim3(nparts * per), dim3(256), args, 0, st);
+      while (e != hipSuccess && nparts > 1) {   // not co-resident here: fewer groups
+        (void)hipGetLastError();
+        nparts /= 2;
+        e = hipLaunchCooperativeKernel(fn, dim3(nparts * per), dim3(256), args, 0, st);
+      }
+    } else {
+      const void* fn = sync_ws ? reinterpret_cast<const void*>(gru_layer_kernel<false, 8>)
+                               : reinterpret_cast<const void*>(gru_layer_kernel<true, 8>);
+      const int nparts = (nb > 32 && gru_cus() >= 4 * GRU_NW) ? 2 : 1;
+      e = hipLaunchCooperativeKernel(fn, dim3(nparts * 2 * GRU_NW), dim3(256), args, 0, st);
+      if (e != hipSuccess && nparts == 2) {   // 256 workgroups not co-resident here: one group of 128
+        (void)hipGetLastError();
+        e = hipLaunchCooperativeKernel(fn, dim3(2 * GRU_NW), dim3(256), args, 0, st);
+      }
     }
     if (e != hipSuccess) return (int)e;
   }

@@ -162,8 +162,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
 #pragma unroll
   for (int s = 0; s < 3; ++s)
     if (s < p.nseg) nkt += p.K[s] / BK;
-  // K TAIL OF 16 (EXPERIMENTAL, host sets p.ktail only for one-segment plain products on the direct-to-LDS path; used by the
-  // training attention core with 176-column head slots, GVD_TRAIN_HEAD_PAD=176): the last tile is fetched SHIFTED BACK by 16
+  // K TAIL OF 16 (host sets p.ktail only for one-segment plain products on the direct-to-LDS path; used by the training attention
+  // core with its 176-column head slots - verified on the device against the 192-slot form and by the reference gradient goldens,
+  // tests/test_gpu_kernels.py::test_enc_attn_core_176_column_head_slots): the last tile is fetched SHIFTED BACK by 16
   // columns (k = K-32 .. K-1: always inside the operand rows, never past them) and only its last two quarters are
   // multiplied - the first two repeat columns the previous tile already covered.  Same ascending k order per output.
   const bool ktail = DMA && p.ktail != 0;

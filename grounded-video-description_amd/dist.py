@@ -46,9 +46,12 @@ def broadcast_parameters(module, src=0):
 class GradAllReducer:
     """Bucketed, backward-overlapped gradient averaging for a replica.
 
-    Parameters are packed into flat buckets in REVERSE registration order (gradients of late layers are
-    produced first).  A post-accumulate-grad hook marks a parameter ready; a bucket whose gradients are all
-    there is copied into its flat buffer and all-reduced asynchronously.  Collectives are issued STRICTLY IN
+    Parameters are packed into flat buckets in the order in which their gradients became ready in the first step
+    (rank 0's hook order, broadcast: the same layout on every rank) - NOT in reverse registration order, which puts the
+    Detectron-transferred fc7 layer (registered last but one, its gradient the very LAST of backward) at the head of
+    the second bucket and so holds every later bucket back until backward ends.  A post-accumulate-grad hook marks a
+    parameter ready; a bucket whose gradients are all there is copied into its flat buffer and all-reduced
+    asynchronously.  Collectives are issued STRICTLY IN
     BUCKET ORDER (a ready bucket waits for its predecessors), so every rank launches the same sequence
     whatever the local hook timing.  `finish()` launches what is left, waits, divides by the world size and
     writes the averages back into `.grad`.
@@ -75,6 +78,7 @@ class GradAllReducer:
         self.all_params = [p for p in module.parameters() if p.requires_grad]
         self.params = list(self.all_params)
         self._discovered = False
+        self._fired = []            # step 0: parameters in the order their gradient hooks fired
         self._late = False          # an excluded parameter got a gradient on THIS rank since the last finish()
         self._word = None
         self.trace = False          # record a stream event at reset(), at every bucket launch and at finish() (bench.py)
@@ -95,7 +99,7 @@ class GradAllReducer:
         self.buckets = []          # list of dict(params, offsets, numel, flat)
         cap = int(self.bucket_mb * 1024 * 1024 / 4)
         cur, cur_n = [], 0
-        for p in reversed(self.params):
+        for p in (self.params if self._discovered else reversed(self.params)):
             if cur and cur_n + p.numel() > cap:
                 self._close(cur)
                 cur, cur_n = [], 0
@@ -172,6 +176,8 @@ class GradAllReducer:
         self._pending[bi] -= 1
         if self._discovered:            # step 0 reduces everything in finish(), after the discovery exchange
             self._launch_ready()
+        else:
+            self._fired.append(p)
 
     def _used_union(self):
         used = torch.tensor([0 if p.grad is None else 1 for p in self.all_params], dtype=torch.int32,
@@ -182,10 +188,20 @@ class GradAllReducer:
     def _discover(self):
         """Union over ranks of the parameters that got a gradient in this (first) step; rebuild the buckets from them."""
         used = self._used_union()
-        self.params = [p for p, u in zip(self.all_params, used) if u]
+        # gradient-ready order of rank 0 (position of every parameter in its hook sequence; parameters whose hook did not
+        # fire there - used on other ranks only - go last, in registration order)
+        pos = {id(p): i for i, p in enumerate(self._fired)}
+        n = len(self.all_params)
+        order = torch.tensor([pos.get(id(p), n + i) for i, p in enumerate(self.all_params)], dtype=torch.int32,
+                             device=self.all_params[0].device)
+        dist.broadcast(order, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        order = order.tolist()
+        ranked = sorted(range(n), key=lambda i: (order[i], i))
+        self.params = [self.all_params[i] for i in ranked if used[i]]
         self.unused = [p for p, u in zip(self.all_params, used) if not u]
-        self._build_buckets()
+        self._fired = []
         self._discovered = True
+        self._build_buckets()
 
     def _drain(self):
         for bi, h in self._handles:
@@ -244,7 +260,7 @@ class GradAllReducer:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
             g.div_(self.world)
             p.grad = g
-        self.params = [p for p in self.all_params if id(p) in known or any(p is q for q in fresh)]
+        self.params = self.params + fresh            # keeps the gradient-ready order; late joiners go last
         self.unused = [p for p in self.all_params if not (id(p) in known or any(p is q for q in fresh))]
         self._build_buckets()
         self.rediscoveries += 1

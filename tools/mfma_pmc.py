@@ -3,7 +3,10 @@ name alone:   python tools/mfma_pmc.py <section>
   fc7 | qkv            plain products of the preamble on the pipelined kernel (gemm_pipe_kernel, direct-to-LDS operands)
   dx | dw              K-strided backward products of nn.Linear (dX = dY W, dW = dY^T X), training shapes at B = 64
   attn_core            the six products of the training attention core over 176-column head slots (K-tail / EDGE tiles)
-  logit | attn_hid | lstm   the token-loop products north_star names, B = 256 (gemm_small_kernel)
+  ctx2pool             the fc7 -> attn_hid projection of the preamble (model.py:391: pool [B R, 1024] -> p_pool [B R, 512]), B = 256
+  logit_train          the hidden -> |V| projection over the teacher-forced rows (B Lc = 1280 x 5000 x 1024), training
+  logit | attn_hid | lstm   the per-token products, B = 256 rows (gemm_small_kernel): logit = hidden -> |V|, attn_hid = the two
+                       stacked h2att queries (AttModel.py:39,77), lstm = one LSTM cell
   flash                padded-head flash attention (inference encoder), B = 256"""
 import os
 import sys
@@ -30,6 +33,10 @@ if sec == 'fc7':
     gemm(256000, 2048, 2048)
 elif sec == 'qkv':
     gemm(256000, 3168, 1024)
+elif sec == 'ctx2pool':
+    gemm(256000, 512, 1024)
+elif sec == 'logit_train':
+    gemm(1280, 5000, 1024, 8)
 elif sec == 'dx':
     dY = torch.randn(64 * 1024, 3168, device=dev)
     W = torch.randn(3168, 1024, device=dev)

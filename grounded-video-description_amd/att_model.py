@@ -590,9 +590,28 @@ class TopDownModel(nn.Module):
         fc = self._drop(self._lin_k32(fc, self.fc_embed[0], act=1))
         # frame-wise context (model.py:393-405)
         # frame embeddings (model.py:393-395) on the MFMA GEMM, straight from the two column blocks of segs_feat
-        c = torch.cat([self._drop(self._lin(segs_feat[:, :, :2048], self.att_embed[0][0], act=1)),
-                       self._drop(self._lin(segs_feat[:, :, 2048:], self.att_embed[1][0], act=1))], dim=2)
-        c = self.att_embed_aux(c.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+        if not self.training and not torch.is_grad_enabled():
+            # inference: the two projections write their column blocks of `c` in place (no concat pass), and BatchNorm1d in
+            # eval mode is a per-channel affine of the LAST axis here - applied in place instead of through two [B,H,Ft]
+            # transposes around the library kernel (three passes over 0.5 GB at B = 256, Ft = 480; model.py:393-397)
+            Hh = self.att_embed[0][0].out_features
+            c = torch.empty(segs_feat.shape[0], Ft, 2 * Hh, device=segs_feat.device, dtype=torch.float32)
+            c2 = c.view(-1, 2 * Hh)
+            ops.gemm_nt(segs_feat[:, :, :2048], self.att_embed[0][0].weight.detach(), self.att_embed[0][0].bias.detach(), 1,
+                        out=c2[:, :Hh])
+            ops.gemm_nt(segs_feat[:, :, 2048:], self.att_embed[1][0].weight.detach(), self.att_embed[1][0].bias.detach(), 1,
+                        out=c2[:, Hh:])
+            bn = self.att_embed_aux[0]
+
+            def build_bn(bn=bn):
+                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                return scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous()
+            scale, shift = self._packed(('bn_affine',), (bn.weight, bn.bias, bn.running_mean, bn.running_var), build_bn)
+            c.mul_(scale).add_(shift).relu_()
+        else:
+            c = torch.cat([self._drop(self._lin(segs_feat[:, :, :2048], self.att_embed[0][0], act=1)),
+                           self._drop(self._lin(segs_feat[:, :, 2048:], self.att_embed[1][0], act=1))], dim=2)
+            c = self.att_embed_aux(c.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
         if not torch.is_grad_enabled():
             # inference: persistent cooperative HIP GRU (one launch per layer instead of ~6 per step/direction)
             c = ops.gru_bidir_2layer(c, self.context_enc, flags=self._flags())

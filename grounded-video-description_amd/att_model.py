@@ -288,14 +288,16 @@ class TopDownModel(nn.Module):
         """nn.Linear (+ReLU) on the fp32 MFMA GEMM."""
         return ops.linear(x, lin.weight, lin.bias, act)
 
-    def _lin_k32(self, x, lin, act=0):
+    def _lin_k32(self, x, lin, act=0, x_padded=False):
         """nn.Linear (+ReLU) whose input width is not a multiple of the GEMM's 32-deep k tile (fc_embed: K = 3122,
         loc_fc: K = 5) on the fp32 MFMA GEMM: input and weight zero-padded along K (the padded weight is cached at
-        inference; under autograd the pad is part of the graph)."""
-        pad = (-x.shape[-1]) % 32
+        inference; under autograd the pad is part of the graph).  x_padded: x already carries the zero columns (the fused
+        feature kernels of the inference preamble write them)."""
+        pad = (-lin.in_features) % 32
         if pad == 0:
             return self._lin(x, lin, act)
-        xp = F.pad(x, (0, pad))
+        xp = x if x_padded else F.pad(x, (0, pad))
+        assert xp.shape[-1] == lin.in_features + pad
         if torch.is_grad_enabled():
             w = F.pad(lin.weight, (0, pad))
         else:
@@ -443,9 +445,9 @@ class TopDownModel(nn.Module):
                                  a_row_map=ci.src_row)                                                      # [cap,2048]
         else:
             g_pool = ops.gemm_nt(ci.gather(ppls_feat), fc7.weight.detach(), fc7.bias.detach(), 1, m_dev=m)
-        pc = ci.gather(ppls)
-        loc_in = torch.cat([pc[:, :4] / 720., (pc[:, 4] * 1. / self.num_sampled_frm).unsqueeze(-1)], dim=1)
-        loc = self._lin_k32(loc_in, self.loc_fc[0], act=1)
+        # location features of the compacted rows in one launch, already padded to the GEMM's 32-deep k tile (model.py:357-360)
+        loc_in = ops.loc_features(ppls.contiguous(), ci.src_row, m, ci.cap, self.num_sampled_frm, ldo=32)
+        loc = self._lin_k32(loc_in, self.loc_fc[0], act=1, x_padded=True)
         # class logits: the D1 = 433 visual words zero-padded to 448 rows so that the output rows are 16-byte aligned (the
         # GEMM's vectorised LDS epilogue instead of column-strided scalar stores); the row kernel reads D1 of them
         vis_word, vis_bias = self._vis_words_padded()
@@ -514,9 +516,18 @@ class TopDownModel(nn.Module):
         pm = pnt_mask if pnt_mask.dtype == torch.uint8 else pnt_mask.to(torch.uint8)
         pm = pm.contiguous()
         # fc feature (model.py:306-308)
-        fc = segs_feat.mean(dim=1)
-        seg_info = self._drop(F.relu(self.seg_info_embed[0](num[:, 3:7].float())))
-        fc = torch.cat([F.layer_norm(fc, [fc.shape[-1]]), F.layer_norm(seg_info, [self.seg_info_size])], dim=-1)
+        fused_side = (not self.training and not torch.is_grad_enabled() and num.dtype == torch.int64
+                      and segs_feat.shape[-1] <= 4096 and self.seg_info_size <= 64
+                      and os.environ.get('GVD_SIDE_FUSED', '1') == '1')
+        if fused_side:
+            # inference: mean over frames, seg_info_embed + ReLU, both layer norms, the concat and the K pad of fc_embed as one
+            # launch instead of ~10 (they matter at batch_size = 4: csrc/compact.hip)
+            fc = ops.fc_feature(segs_feat.contiguous(), num.contiguous(), self.seg_info_embed[0].weight.detach(),
+                                self.seg_info_embed[0].bias.detach(), pad_to=32)
+        else:
+            fc = segs_feat.mean(dim=1)
+            seg_info = self._drop(F.relu(self.seg_info_embed[0](num[:, 3:7].float())))
+            fc = torch.cat([F.layer_norm(fc, [fc.shape[-1]]), F.layer_norm(seg_info, [self.seg_info_size])], dim=-1)
         compact = (allow_compact and not torch.is_grad_enabled() and not self.training
                    and os.environ.get('GVD_COMPACT', '1') == '1'
                    and self._fused_encoder_ok(self.rnn_size) and B * (R + 1) < (1 << 24)
@@ -587,7 +598,7 @@ class TopDownModel(nn.Module):
     def _preamble_finish(self, segs_feat, sample_idx, fc, pm, pool, p_pool, sim_mat, g_pool):
         """fc embedding + the frame half of the preamble (model.py:393-405)."""
         Ft = segs_feat.shape[1]
-        fc = self._drop(self._lin_k32(fc, self.fc_embed[0], act=1))
+        fc = self._drop(self._lin_k32(fc, self.fc_embed[0], act=1, x_padded=fc.shape[-1] != self.fc_embed[0].in_features))
         # frame-wise context (model.py:393-405)
         # frame embeddings (model.py:393-395) on the MFMA GEMM, straight from the two column blocks of segs_feat
         if not self.training and not torch.is_grad_enabled():
@@ -607,7 +618,10 @@ class TopDownModel(nn.Module):
                 scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
                 return scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous()
             scale, shift = self._packed(('bn_affine',), (bn.weight, bn.bias, bn.running_mean, bn.running_var), build_bn)
-            c.mul_(scale).add_(shift).relu_()
+            if os.environ.get('GVD_SIDE_FUSED', '1') == '1':
+                ops.affine_relu_rows_(c, scale, shift)
+            else:
+                c.mul_(scale).add_(shift).relu_()
         else:
             c = torch.cat([self._drop(self._lin(segs_feat[:, :, :2048], self.att_embed[0][0], act=1)),
                            self._drop(self._lin(segs_feat[:, :, 2048:], self.att_embed[1][0], act=1))], dim=2)
@@ -626,9 +640,13 @@ class TopDownModel(nn.Module):
                 c = self.context_enc(c)[0]
         else:
             c = self.context_enc(c)[0]
-        t = torch.arange(Ft, device=c.device).view(1, Ft)
-        keep = (t >= sample_idx[:, 0:1]) & (t < sample_idx[:, 1:2])           # model.py:303-305
-        conv = c.masked_fill(~keep.unsqueeze(-1), 0).contiguous()
+        if (not torch.is_grad_enabled() and sample_idx.dtype == torch.int64 and c.is_contiguous()
+                and os.environ.get('GVD_SIDE_FUSED', '1') == '1'):
+            conv = ops.zero_rows_outside_window_(c, sample_idx.contiguous())       # in place on the GRU's fresh output
+        else:
+            t = torch.arange(Ft, device=c.device).view(1, Ft)
+            keep = (t >= sample_idx[:, 0:1]) & (t < sample_idx[:, 1:2])           # model.py:303-305
+            conv = c.masked_fill(~keep.unsqueeze(-1), 0).contiguous()
         p_conv = self._lin(conv, self.ctx2att)                            # MFMA GEMM (model.py:405)
         return dict(fc=fc, pool=pool, p_pool=p_pool, conv=conv, p_conv=p_conv, g_pool=g_pool,
                     sim_mat_static=sim_mat, pnt_mask=pm)

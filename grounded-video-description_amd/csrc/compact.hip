@@ -147,3 +147,162 @@ extern "C" int gvd_check_masked_rows_zero(const float* x, int D, const uint8_t* 
   GVD_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small fused kernels of the INFERENCE preamble.  At batch_size = 4 (BASELINE configs[1]) a 'sample' call is 3.2 ms,
+// of which ~0.25 ms were ~50 ATen launches of 4-6 us each (profiles/r03/b4_dispatch_trace_q.txt): the fc feature
+// (mean, tiny Linear, two layer norms, concat, K pad), the location features (gather, three scalings, concat, K pad),
+// BatchNorm(eval) + ReLU of the frame embeddings and the sampling-window mask (arange, two compares, and, not, fill).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+// model.py:306-308: out[b] = [ layer_norm(mean_t segs[b,t,:]) | layer_norm(relu(W num[b,3:7] + bias)) | 0 pad ]
+constexpr int FC_MAXC = 16;     // columns per thread: D <= 4096
+__global__ __launch_bounds__(256) void fc_feature_kernel(const float* __restrict__ segs, const int64_t* __restrict__ num,
+                                                         const float* __restrict__ W, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int Ft, int D, int S, int ldo,
+                                                         float eps) {
+  __shared__ float s_red[4];
+  __shared__ float s_seg[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* sb = segs + (int64_t)b * Ft * D;
+  float v[FC_MAXC];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < FC_MAXC; ++i) {
+    const int c = tid + 256 * i;
+    float a = 0.f;
+    if (c < D) {
+      for (int t = 0; t < Ft; ++t) a += sb[(int64_t)t * D + c];
+      a = a / (float)Ft;
+    }
+    v[i] = a;
+    sum += a;
+  }
+  const float mean = block_sum_256(sum, s_red) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < FC_MAXC; ++i) {
+    const int c = tid + 256 * i;
+    if (c < D) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+  }
+  const float inv = rsqrtf(block_sum_256(q, s_red) / (float)D + eps);
+  float* ob = out + (int64_t)b * ldo;
+#pragma unroll
+  for (int i = 0; i < FC_MAXC; ++i) {
+    const int c = tid + 256 * i;
+    if (c < D) ob[c] = (v[i] - mean) * inv;
+  }
+  // segment-position embedding: S <= 64 outputs from 4 inputs
+  float e = 0.f;
+  if (tid < S) {
+    const int64_t* nb = num + (int64_t)b * 7 + 3;
+    e = bias[tid];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e = fmaf(W[tid * 4 + k], (float)nb[k], e);
+    e = fmaxf(e, 0.f);
+    s_seg[tid] = e;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float x = tid < S ? s_seg[tid] : 0.f;
+    const float m2 = wave_sum(x) / (float)S;
+    const float d = tid < S ? x - m2 : 0.f;
+    const float iv = rsqrtf(wave_sum(d * d) / (float)S + eps);
+    if (tid < S) ob[D + tid] = d * iv;
+  }
+  for (int c = D + S + tid; c < ldo; c += 256) ob[c] = 0.f;
+}
+
+// model.py:357-360 on the compacted row set: out[i] = [x1, y1, x2, y2] / 720, frame / T, zero pad to ldo columns
+__global__ __launch_bounds__(256) void loc_features_kernel(const float* __restrict__ ppls, const int* __restrict__ src_row,
+                                                           const int* __restrict__ m_dev, float* __restrict__ out,
+                                                           int64_t rows, int ldo, float T) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t live = m_dev ? min((int64_t)*m_dev, rows) : rows;
+  if (i >= live) return;
+  const float* p = ppls + (int64_t)(src_row ? src_row[i] : i) * 7;
+  float* o = out + i * ldo;
+  // (IEEE divisions through double: hipcc's fp32 `/` was measured 1 ulp off the correctly rounded quotient ATen produces)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (float)((double)p[k] / 720.0);
+  o[4] = (float)((double)(p[4] * 1.0f) / (double)T);
+  for (int k = 5; k < ldo; ++k) o[k] = 0.f;
+}
+
+// BatchNorm1d(eval) + ReLU over the LAST axis: x = relu(x * scale[c] + shift[c]) in place
+__global__ __launch_bounds__(256) void affine_relu_kernel(float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int64_t n4, int D4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)(i % D4) * 4;
+  gvd_f32x4 v = *reinterpret_cast<gvd_f32x4*>(x + i * 4);
+  const gvd_f32x4 s = *reinterpret_cast<const gvd_f32x4*>(scale + c), t = *reinterpret_cast<const gvd_f32x4*>(shift + c);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k] * s[k] + t[k], 0.f);
+  *reinterpret_cast<gvd_f32x4*>(x + i * 4) = v;
+}
+
+// model.py:303-305,401: rows t outside the sampling window [s, e) of their segment are cleared (one wave per row)
+__global__ __launch_bounds__(256) void zero_outside_window_kernel(float* __restrict__ x, const int64_t* __restrict__ sidx,
+                                                                  int64_t rows, int Ft, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t b = row / Ft, t = row % Ft;
+  if (t >= sidx[2 * b] && t < sidx[2 * b + 1]) return;
+  float* xr = x + row * D;
+  const gvd_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int i = lane; i < D / 4; i += 64) reinterpret_cast<gvd_f32x4*>(xr)[i] = z;
+}
+
+}  // namespace
+
+extern "C" int gvd_fc_feature(const float* segs, const int64_t* num, const float* w_seg, const float* b_seg, float* out, int B,
+                              int Ft, int D, int S, int ldo, float eps, gvd_stream_t stream) {
+  if (!segs || !num || !w_seg || !b_seg || !out || B <= 0 || Ft <= 0 || D <= 0 || D > 256 * FC_MAXC || S <= 0 || S > 64 ||
+      ldo < D + S)
+    return GVD_EINVAL;
+  hipLaunchKernelGGL(fc_feature_kernel, dim3((unsigned)B), dim3(256), 0, gvd_s(stream), segs, num, w_seg, b_seg, out, Ft, D, S,
+                     ldo, eps);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gvd_loc_features(const float* ppls, const int* src_row, const int* rows_dev, float* out, int64_t rows, int ldo,
+                                float n_frames, gvd_stream_t stream) {
+  if (!ppls || !out || rows <= 0 || ldo < 5 || n_frames <= 0.f) return GVD_EINVAL;
+  hipLaunchKernelGGL(loc_features_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, gvd_s(stream), ppls, src_row,
+                     rows_dev, out, rows, ldo, n_frames);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gvd_affine_relu_rows(float* x, const float* scale, const float* shift, int64_t rows, int D,
+                                    gvd_stream_t stream) {
+  if (!x || !scale || !shift || rows <= 0 || D <= 0 || (D & 3) || !gvd_aligned16(x) || !gvd_aligned16(scale) ||
+      !gvd_aligned16(shift))
+    return GVD_EINVAL;
+  const int64_t n4 = rows * (D / 4);
+  hipLaunchKernelGGL(affine_relu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, gvd_s(stream), x, scale, shift, n4,
+                     D / 4);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gvd_zero_rows_outside_window(float* x, const int64_t* sample_idx, int B, int Ft, int D, gvd_stream_t stream) {
+  if (!x || !sample_idx || B <= 0 || Ft <= 0 || D <= 0 || (D & 3) || !gvd_aligned16(x)) return GVD_EINVAL;
+  const int64_t rows = (int64_t)B * Ft;
+  hipLaunchKernelGGL(zero_outside_window_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, gvd_s(stream), x, sample_idx,
+                     rows, Ft, D);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}

@@ -124,6 +124,11 @@ _SIG = {
                                     c_f32p, c_u8p, C.c_void_p]),
     'gvd_gather_rows_f32': (C.c_int, [c_f32p, C.c_int64, C.c_void_p, c_f32p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                       C.c_void_p]),
+    'gvd_fc_feature': (C.c_int, [c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                C.c_void_p]),
+    'gvd_loc_features': (C.c_int, [c_f32p, C.c_void_p, C.c_void_p, c_f32p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    'gvd_affine_relu_rows': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
+    'gvd_zero_rows_outside_window': (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'gvd_check_masked_rows_zero': (C.c_int, [c_f32p, C.c_int, c_u8p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                              C.c_void_p]),
     'gvd_grid_sync_words': (C.c_int, []),
@@ -162,7 +167,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 10        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 11        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

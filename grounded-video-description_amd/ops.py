@@ -983,6 +983,50 @@ class CompactIndex:
         return out
 
 
+def fc_feature(segs_feat, num, w_seg, b_seg, pad_to=32, eps=1e-5):
+    """model.py:306-308 in one launch (gvd_fc_feature): [layer_norm(mean_t segs_feat) | layer_norm(relu(seg_info_embed(num[:, 3:7])))
+    | zero pad to a multiple of `pad_to` columns] -> [B, ldo].  segs_feat f32 [B,Ft,D] contiguous, num i64 [B,7]."""
+    require_cuda_f32(segs_feat, w_seg, b_seg)
+    B, Ft, D = segs_feat.shape
+    S = w_seg.shape[0]
+    assert segs_feat.is_contiguous() and num.dtype == torch.int64 and num.is_contiguous() and num.shape == (B, 7)
+    assert w_seg.is_contiguous() and w_seg.shape[1] == 4
+    ldo = -(-(D + S) // pad_to) * pad_to
+    out = torch.empty(B, ldo, device=segs_feat.device, dtype=torch.float32)
+    check(lib().gvd_fc_feature(ptr(segs_feat), ptr(num), ptr(w_seg), ptr(b_seg), ptr(out), B, Ft, D, S, ldo, eps, stream_ptr()),
+          'gvd_fc_feature')
+    return out
+
+
+def loc_features(ppls, src_row, rows_dev, rows, n_frames, ldo=32):
+    """model.py:357-360 on the compacted row set (gvd_loc_features): [x1,y1,x2,y2]/720, frame/T, zero pad -> [rows, ldo]."""
+    require_cuda_f32(ppls)
+    p2 = ppls.reshape(-1, ppls.shape[-1])
+    assert p2.is_contiguous() and p2.shape[1] == 7
+    out = torch.empty(rows, ldo, device=ppls.device, dtype=torch.float32)
+    check(lib().gvd_loc_features(ptr(p2), ptr(src_row), ptr(rows_dev), ptr(out), rows, ldo, float(n_frames), stream_ptr()),
+          'gvd_loc_features')
+    return out
+
+
+def affine_relu_rows_(x, scale, shift):
+    """In place x = relu(x * scale + shift) over the last axis (BatchNorm1d in eval mode + ReLU; gvd_affine_relu_rows)."""
+    require_cuda_f32(x, scale, shift)
+    assert x.is_contiguous() and scale.is_contiguous() and shift.is_contiguous()
+    D = x.shape[-1]
+    check(lib().gvd_affine_relu_rows(ptr(x), ptr(scale), ptr(shift), x.numel() // D, D, stream_ptr()), 'gvd_affine_relu_rows')
+    return x
+
+
+def zero_rows_outside_window_(x, sample_idx):
+    """In place x[b, t, :] = 0 for t outside [sample_idx[b,0], sample_idx[b,1]) (model.py:303-305,401)."""
+    require_cuda_f32(x)
+    B, Ft, D = x.shape
+    assert x.is_contiguous() and sample_idx.dtype == torch.int64 and sample_idx.is_contiguous() and sample_idx.shape == (B, 2)
+    check(lib().gvd_zero_rows_outside_window(ptr(x), ptr(sample_idx), B, Ft, D, stream_ptr()), 'gvd_zero_rows_outside_window')
+    return x
+
+
 def check_masked_rows_zero(x, pnt_mask, flag):
     """flag (int32 [1], device) |= 1 when a masked row of x [B,R,D] is not all-zero."""
     B, R, D = x.shape

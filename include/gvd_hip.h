@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 10
+#define GVD_ABI_VERSION 11
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -259,6 +259,20 @@ int gvd_compact_index(const uint8_t* mask, int64_t ld_mask, int B, int R, int* o
 /* out[i, 0:D] = in[idx[i], 0:D] for i < n_rows (or < *n_rows_dev when given): compaction of inputs, expansion of outputs */
 int gvd_gather_rows_f32(const float* in, int64_t in_ld, const int* idx, float* out, int64_t out_ld, int D, int64_t n_rows,
                         const int* n_rows_dev, gvd_stream_t stream);
+/* Small fused kernels of the inference preamble (each replaces a chain of 4-10 ATen launches; they matter at batch_size = 4):
+ *  gvd_fc_feature: out[b, 0:D] = layer_norm(mean_t segs[b,t,:]), out[b, D:D+S] = layer_norm(relu(w_seg num[b,3:7] + b_seg)),
+ *    out[b, D+S:ldo] = 0 (the K pad of the fc_embed GEMM) - model.py:306-308; segs f32 [B,Ft,D], num i64 [B,7], w_seg [S,4].
+ *  gvd_loc_features: out[i] = [x1,y1,x2,y2]/720, frame/n_frames, 0 pad to ldo columns, of proposal row src_row[i] (or i) for
+ *    i < rows (or < *rows_dev) - model.py:357-360 on the compacted row set; ppls f32 [*,7].
+ *  gvd_affine_relu_rows: x[r, c] = relu(x[r, c] * scale[c] + shift[c]) in place - BatchNorm1d(eval) + ReLU of the frame
+ *    embeddings as a per-channel affine of the last axis (model.py:114,397).
+ *  gvd_zero_rows_outside_window: x[b, t, :] = 0 for t outside [sample_idx[b,0], sample_idx[b,1]) - model.py:303-305,401. */
+int gvd_fc_feature(const float* segs, const int64_t* num, const float* w_seg, const float* b_seg, float* out, int B, int Ft,
+                   int D, int S, int ldo, float eps, gvd_stream_t stream);
+int gvd_loc_features(const float* ppls, const int* src_row, const int* rows_dev, float* out, int64_t rows, int ldo,
+                     float n_frames, gvd_stream_t stream);
+int gvd_affine_relu_rows(float* x, const float* scale, const float* shift, int64_t rows, int D, gvd_stream_t stream);
+int gvd_zero_rows_outside_window(float* x, const int64_t* sample_idx, int B, int Ft, int D, gvd_stream_t stream);
 /* flag[0] |= 1 when some masked row of x [B*R, D] is not all-zero (the precondition of the compaction) */
 int gvd_check_masked_rows_zero(const float* x, int D, const uint8_t* mask, int64_t ld_mask, int B, int R, int* flag,
                                gvd_stream_t stream);

@@ -122,6 +122,47 @@ def test_attention_step(B, R, Ft):
     assert torch.equal(logits.cpu() == O.MIN_VALUE, pm[:, 1:].bool())
 
 
+def test_fused_side_kernels_of_the_inference_preamble():
+    """gvd_fc_feature / gvd_loc_features / gvd_affine_relu_rows / gvd_zero_rows_outside_window against the ATen chains they
+    replace (model.py:306-308, 357-360, 397, 303-305 + 401)."""
+    import torch.nn.functional as F
+    g = _g(123)
+    B, Ft, D, S = 5, 7, 3072, 50
+    segs = torch.randn(B, Ft, D, generator=g).cuda()
+    num = torch.randint(0, 9, (B, 7), generator=g).cuda()
+    W, b = (torch.randn(S, 4, generator=g) * 0.5).cuda(), torch.randn(S, generator=g).cuda()
+    out = ops.fc_feature(segs, num, W, b, pad_to=32)
+    ref = torch.cat([F.layer_norm(segs.mean(1), [D]), F.layer_norm(F.relu(F.linear(num[:, 3:7].float(), W, b)), [S])], -1)
+    assert out.shape == (B, 3136) and float(out[:, D + S:].abs().max()) == 0.0
+    np.testing.assert_allclose(out[:, :D + S].cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    # location features through a row map with a device-side live count
+    R, T = 30, 3
+    ppls = (torch.rand(B, R, 7, generator=g) * 500).cuda()
+    src = torch.randperm(B * R, generator=g)[:100].to(torch.int32).cuda()
+    live = torch.tensor([77], dtype=torch.int32, device='cuda')
+    loc = ops.loc_features(ppls, src, live, 100, T, ldo=32)
+    # (the expectation is computed on the CPU, like the reference: ATen's GPU kernel turns `x / 720.` into a multiplication by
+    # the rounded reciprocal, the CPU kernel - and gvd_loc_features - divide)
+    pc = ppls.cpu().view(-1, 7)[src.cpu().long()]
+    want = torch.cat([pc[:, :4] / 720., (pc[:, 4] * 1. / T).unsqueeze(-1)], 1)
+    assert torch.equal(loc[:77, :5].cpu(), want[:77]) and float(loc[:77, 5:].abs().max()) == 0.0
+    # BatchNorm1d(eval) + ReLU as an affine of the last axis
+    bn = torch.nn.BatchNorm1d(1024).cuda().eval()
+    with torch.no_grad():
+        bn.weight.normal_(1, 0.2); bn.bias.normal_(0, 0.2); bn.running_mean.normal_(0, 0.5); bn.running_var.uniform_(0.5, 2)
+        x = torch.randn(B, Ft, 1024, generator=g).cuda()
+        want = torch.relu(bn(x.permute(0, 2, 1))).permute(0, 2, 1)
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        got = ops.affine_relu_rows_(x.clone(), scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous())
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    # sampling window
+    sidx = torch.tensor([[0, 7], [2, 5], [3, 3], [6, 7], [0, 1]]).cuda()
+    y = torch.randn(B, Ft, 1024, generator=g).cuda()
+    t = torch.arange(Ft, device='cuda').view(1, Ft)
+    keep = (t >= sidx[:, 0:1]) & (t < sidx[:, 1:2])
+    assert torch.equal(ops.zero_rows_outside_window_(y.clone(), sidx), y.masked_fill(~keep.unsqueeze(-1), 0))
+
+
 def test_tanh_fast_error_bound():
     """The score kernels' tanh (gvd_common.h: tanh_fast, 11 issue slots instead of ocml's 31) stays within 2.5e-7
     ABSOLUTE of the real tanh over the whole line, saturates exactly and propagates NaN (AttModel.py:45, 90)."""

@@ -666,7 +666,17 @@ int gvd_pd_launch(PdParams p, void* workspace, hipStream_t st) {
   hipError_t e = hipMemsetAsync(p.sync, 0, (size_t)GVD_SYNC_WORDS * sizeof(unsigned), st);
   if (e != hipSuccess) return (int)e;
   void* args[] = {&p};
-  e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(greedy_persistent_kernel), dim3(PD_G), dim3(PD_NT), args,
-                                 0, st);
+  // Plain launch after an explicit co-residency check (gvd_grid_fits: what the cooperative launch verifies), because the
+  // cooperative path costs a ~12 us dispatch gap on either side of the kernel; GVD_COOP_LAUNCH=1 restores it.  The grid barrier
+  // bounds its spins either way (status word -> GvdHipError on the host).
+  static const bool coop = getenv("GVD_COOP_LAUNCH") ? atoi(getenv("GVD_COOP_LAUNCH")) != 0 : false;
+  const void* fn = reinterpret_cast<const void*>(greedy_persistent_kernel);
+  if (coop) {
+    e = hipLaunchCooperativeKernel(fn, dim3(PD_G), dim3(PD_NT), args, 0, st);
+  } else {
+    static const bool fits = gvd_grid_fits(fn, PD_NT, PD_G);
+    if (!fits) return GVD_EINVAL;                  // the caller falls back to the kernel-per-op loop
+    e = hipLaunchKernel(fn, dim3(PD_G), dim3(PD_NT), args, 0, st);
+  }
   return e == hipSuccess ? 0 : (int)e;
 }

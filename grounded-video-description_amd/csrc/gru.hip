@@ -307,6 +307,16 @@ extern "C" int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const 
     // More than 64 rows (3+ batch tiles): 16 hidden units per workgroup, the tiles dealt to up to 4 groups of 64
     // workgroups; otherwise 8 units per workgroup and up to 2 groups of 128 (GVD_GRU_HU=8 / 16 forces one form).
     static const int hu_env = getenv("GVD_GRU_HU") ? atoi(getenv("GVD_GRU_HU")) : 0;
+    // The hand-rolled barrier form is launched PLAINLY after an explicit co-residency check (gvd_grid_fits; the cooperative
+    // path costs a ~12 us dispatch gap on either side of the kernel; GVD_COOP_LAUNCH=1 restores it); the library grid sync
+    // needs the cooperative launch.
+    static const bool coop_env = getenv("GVD_COOP_LAUNCH") ? atoi(getenv("GVD_COOP_LAUNCH")) != 0 : false;
+    const bool coop = coop_env || !sync_ws;
+    auto launch = [&](const void* f, unsigned nwg) {
+      if (coop) return hipLaunchCooperativeKernel(f, dim3(nwg), dim3(256), args, 0, st);
+      if (!gvd_grid_fits(f, 256, (int)nwg)) return hipErrorCooperativeLaunchTooLarge;
+      return hipLaunchKernel(f, dim3(nwg), dim3(256), args, 0, st);
+    };
     const bool wide = hu_env ? hu_env == 16 : nb > 64;
     const int ntiles = (nb + 31) / 32;
     hipError_t e;
@@ -318,20 +328,20 @@ extern "C" int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const 
       if (nparts > ntiles) nparts = ntiles;
       if (nparts > 4) nparts = 4;
       if (nparts < 1) nparts = 1;
-      e = hipLaunchCooperativeKernel(fn, dim3(nparts * per), dim3(256), args, 0, st);
+      e = launch(fn, (unsigned)(nparts * per));
       while (e != hipSuccess && nparts > 1) {   // not co-resident here: fewer groups
         (void)hipGetLastError();
         nparts /= 2;
-        e = hipLaunchCooperativeKernel(fn, dim3(nparts * per), dim3(256), args, 0, st);
+        e = launch(fn, (unsigned)(nparts * per));
       }
     } else {
       const void* fn = sync_ws ? reinterpret_cast<const void*>(gru_layer_kernel<false, 8>)
                                : reinterpret_cast<const void*>(gru_layer_kernel<true, 8>);
       const int nparts = (nb > 32 && gru_cus() >= 4 * GRU_NW) ? 2 : 1;
-      e = hipLaunchCooperativeKernel(fn, dim3(nparts * 2 * GRU_NW), dim3(256), args, 0, st);
+      e = launch(fn, (unsigned)(nparts * 2 * GRU_NW));
       if (e != hipSuccess && nparts == 2) {   // 256 workgroups not co-resident here: one group of 128
         (void)hipGetLastError();
-        e = hipLaunchCooperativeKernel(fn, dim3(2 * GRU_NW), dim3(256), args, 0, st);
+        e = launch(fn, (unsigned)(2 * GRU_NW));
       }
     }
     if (e != hipSuccess) return (int)e;

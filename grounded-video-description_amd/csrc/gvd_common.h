@@ -159,6 +159,26 @@ __device__ __forceinline__ void grid_barrier_tree(unsigned* sync, unsigned round
   __syncthreads();
 }
 
+// Host: can `grid` workgroups of `block` threads of kernel `fn` be resident at the same time on the current device?  (The check
+// a cooperative launch makes; the persistent kernels are launched PLAINLY after it - the cooperative path costs a ~12 us
+// dispatch gap before and after every such kernel, 0.1 ms of a 3 ms batch_size = 4 call - and bound their barrier spins.)
+static inline bool gvd_grid_fits(const void* fn, int block, int grid) {
+  // (per translation unit: a few entries, answers never change for a (kernel, block) pair on one device type; a racing
+  // first call computes the same value twice)
+  struct Entry { const void* fn; int block; long slots; };
+  static Entry cache[8] = {};
+  static int used = 0;
+  for (int i = 0; i < used; ++i)
+    if (cache[i].fn == fn && cache[i].block == block) return cache[i].slots >= grid;
+  int dev = 0, cus = 0, per = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, block, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+  const long slots = (long)per * cus;
+  if (used < 8) { cache[used].fn = fn; cache[used].block = block; cache[used].slots = slots; ++used; }
+  return slots >= grid;
+}
+
 // event-pair recorder (prof.hip); no-ops when p == nullptr
 void gvd_prof_begin(gvd_prof* p, hipStream_t st);
 void gvd_prof_end(gvd_prof* p, hipStream_t st);

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SETTINGS = [
     ('decode', dict(GVD_PERSISTENT='0', GVD_ATTN_NT='1', GVD_ATTN_CHUNK='32', GVD_GEMV_KS='2', GVD_GEMM_SMALL='0',
-                    GVD_FC7_ROWMAP='0', GVD_GRU_BARRIER='cg', GVD_FLASH_SKEW='0')),
+                    GVD_FC7_ROWMAP='0', GVD_GRU_BARRIER='cg', GVD_FLASH_SKEW='0', GVD_COOP_LAUNCH='1')),
     ('decode', dict(GVD_ATTN_NT='0', GVD_GEMV_KS='1', GVD_GEMM_VARIANT='1', GVD_GEMM_BIG='128', GVD_SIDE_FUSED='0', GVD_GRU_HU='16')),
     ('decode', dict(GVD_COMPACT='0', GVD_POOL_EMBED_OWN='0', GVD_GEMM_VARIANT='0')),
     ('decode', dict(GVD_COMPACT='0', GVD_ENC_FUSED='0', GVD_GEMM_VARIANT='2')),               # first flash kernels (16x16x4)

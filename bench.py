@@ -230,7 +230,7 @@ def _roofline_mfma(hip, run, steps, label):
             'launches_per_step': n // steps, 'steps_measured': steps}
 
 
-def section_train_b64(dev, n_steps=3):
+def section_train_b64(dev, n_steps=4):
     """BASELINE configs[2] inside the default line: one optimisation step of 64 segments (train mode: dropout, BN batch
     statistics), on the weights + inputs of the committed reference case mle_b64_v5000_ft10_trained; `parity` = the
     eval-mode 'MLE' losses of that case against the reference's own (tests/golden), before any update."""
@@ -253,7 +253,8 @@ def section_train_b64(dev, n_steps=3):
                          'within_1e-4': bool(np.abs(got - want).max() <= 1e-4)}
     model.train()
     tr = train.Trainer(model, opt)
-    tr.step(a)
+    for _ in range(2):          # warm-up: allocator growth, weight packs, the first step's bucket discovery
+        tr.step(a)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n_steps):

@@ -31,7 +31,10 @@ __global__ __launch_bounds__(256, 1) void gemm_small_kernel(const KParams p) {
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
   const int tm_ = lid % p.ntm, tn_ = lid / p.ntm;
   const int m0 = tm_ * SB, n0 = LSTM ? 0 : tn_ * SB;
-  const int M = p.M;
+  // device-side row count (compacted preamble of a small batch: the few-tile products of its 4000 region rows): the grid is
+  // sized for the worst case, row tiles past the live count leave at once
+  const int M = p.m_dev ? min(*p.m_dev, p.M) : p.M;
+  if (m0 >= M) return;
 
   const int srow = tid >> 4, kq = tid & 15;       // thread covers rows srow + 16 i, 16-byte chunk kq of a 256-byte k slice
   int arow[SNLD], wrow[SNLD];
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void gemm_small_kernel(const KParams p) {
 
 // eligibility: every K segment a multiple of 64; plain: single batch
 bool gvd_gemm_small_ok(const KParams& p, int batch) {
-  if (batch != 1 || p.m_dev || p.a_t || p.w_t) return false;
+  if (batch != 1 || p.a_t || p.w_t) return false;
   for (int s = 0; s < p.nseg; ++s)
     if (p.K[s] % SK) return false;
   return true;

@@ -122,6 +122,28 @@ def test_attention_step(B, R, Ft):
     assert torch.equal(logits.cpu() == O.MIN_VALUE, pm[:, 1:].bool())
 
 
+@pytest.mark.parametrize('M,N,K,act', [(4004, 512, 1024, 1), (4004, 448, 2048, 0), (1100, 1024, 512, 0)])
+def test_gemm_few_tile_products_with_device_row_count(M, N, K, act):
+    """The few-tile products of a small batch's compacted preamble (4000 region rows x N <= 512: fewer than 256 tiles of
+    128 x 128) take the pipelined 64 x 64 kernel also when the row count lives on the device: live rows bitwise equal to the
+    launch without a device count, rows past it untouched, values vs fp64."""
+    g = _g(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    full = ops.gemm_nt(A, W, b, act)
+    ref = A.double() @ W.double().t() + b.double()
+    if act:
+        ref = ref.clamp_min(0)
+    assert float((full.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    live = M - 333
+    m_dev = torch.tensor([live], dtype=torch.int32, device='cuda')
+    out = torch.full((M, N), 7.0, device='cuda')
+    ops.gemm_nt(A, W, b, act, out=out, m_dev=m_dev)
+    assert torch.equal(out[:live], full[:live])
+    assert bool((out[(live + 63) // 64 * 64:] == 7.0).all())
+
+
 def test_fused_side_kernels_of_the_inference_preamble():
     """gvd_fc_feature / gvd_loc_features / gvd_affine_relu_rows / gvd_zero_rows_outside_window against the ATen chains they
     replace (model.py:306-308, 357-360, 397, 303-305 + 401)."""

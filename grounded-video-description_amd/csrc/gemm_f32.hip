@@ -271,7 +271,14 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
     v.C = a->C; v.ldc = a->ldc; v.M = a->M; v.N = a->N; v.act = a->act;
     return gvd_gemv_plain(v, st);
   }
-  if (a->M <= 32) return launch<32, 128, 1, 4, false>(p, a->batch, st);
+  static const int small = getenv("GVD_GEMM_SMALL") ? atoi(getenv("GVD_GEMM_SMALL")) : 1;     // A/B knob
+  // 17..32 rows: the pipelined 64 x 64 kernel where it is eligible (half of its MFMA rows idle, but the K loop is software
+  // pipelined: LSTM cell 99 -> ~45 us, queries / logits 40 -> ~25 us at B = 32, profiles/r03/b32_w_kernel_stats.md), the
+  // general 32 x 128 kernel otherwise
+  if (a->M <= 32) {
+    if (small && a->M > 16 && gvd_gemm_small_ok(p, a->batch)) return gvd_gemm_small_launch(p, false, st);
+    return launch<32, 128, 1, 4, false>(p, a->batch, st);
+  }
   const long big = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
   static const long big_min = getenv("GVD_GEMM_BIG") ? atol(getenv("GVD_GEMM_BIG")) : 256;   // tuning knob
   if (big >= big_min) {
@@ -289,7 +296,6 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
     }
     return launch<128, 128, 2, 2, false, 1>(p, a->batch, st);
   }
-  static const int small = getenv("GVD_GEMM_SMALL") ? atoi(getenv("GVD_GEMM_SMALL")) : 1;     // A/B knob
   if (small && gvd_gemm_small_ok(p, a->batch)) return gvd_gemm_small_launch(p, false, st);
   return launch<64, 64, 2, 2, false>(p, a->batch, st);
 }
@@ -326,8 +332,8 @@ extern "C" int gvd_lstm_cell_fwd(const gvd_lstm_args* a, gvd_stream_t stream) {
     v.c_out = a->c_out; v.ldco = a->ldc_out; v.gates_out = a->gates_out; v.ldg = a->ldg;
     return gvd_gemv_lstm(v, st);
   }
-  if (a->B <= 32) return launch<32, 128, 1, 4, true>(p, 1, st);
   static const int small = getenv("GVD_GEMM_SMALL") ? atoi(getenv("GVD_GEMM_SMALL")) : 1;
-  if (small && gvd_gemm_small_ok(p, 1) && (a->H % 16) == 0) return gvd_gemm_small_launch(p, true, st);
+  if (small && gvd_gemm_small_ok(p, 1) && (a->H % 16) == 0) return gvd_gemm_small_launch(p, true, st);   // (B = 17..32 too)
+  if (a->B <= 32) return launch<32, 128, 1, 4, true>(p, 1, st);
   return launch<64, 64, 2, 2, true>(p, 1, st);
 }

@@ -58,8 +58,8 @@ def parse():
                          'N > 1 ranks on a box with ONE GPU (ranks share cuda:0; RCCL refuses two ranks on one device): used to '
                          'exercise the N-rank code path end to end where no multi-GPU node is available, never for numbers')
     ap.add_argument('--no-sections', action='store_true',
-                    help='default line only: skip the short configs[2] (train B=64) and configs[4] (beam=5 x 20 frames, '
-                         'B=64) sections and the GEMM roofline pass that the default run appends to its JSON line')
+                    help='default line only: skip the short configs[2] (train B=64), configs[4] (beam=5 x 20 frames, B=64) and '
+                         'Ft=480 (reference-default frame count, B=256) sections the default run appends to its JSON line')
     ap.add_argument('--overlap', action='store_true',
                     help='pipeline the K steps on two HIP streams (preamble of step i+1 || token loop of step i). Off by '
                          'default: co-scheduling stretches the attention kernel, so its live roofline figure would not '
@@ -314,6 +314,51 @@ def section_beam5_t20_b64(dev, n_steps=3):
     return out
 
 
+def section_ft480_b256(dev, n_steps=3):
+    """The reference's DEFAULT frame count (opts.py:50 `--t_attn_size 480`: [B,480,3072] frame features through the two
+    frame embeddings, BatchNorm, the 2-layer bi-GRU and a 480-row temporal attention stream) inside the default line:
+    greedy decode of 256 segments; `parity` = the committed reference case greedy_b64_v5000_ft480_trained decoded by the
+    same code path (2-group persistent GRU, 16 hidden units per workgroup)."""
+    import numpy as np
+    from gvd_amd import att_model, opts, synth
+    from gvd_amd.att_model import attended_region_indices
+    opt = opts.default_opt(vocab_size=5000, t_attn_size=480)
+    sd = synth.init_state_dict(opt, seed=15, profile='trained_like')
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    keys = ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')
+    out = {'batch': 256, 't_attn_size': 480}
+    gpath = os.path.join(GOLDEN_DIR, 'greedy_b64_v5000_ft480_trained.npz')
+    with torch.no_grad():
+        if os.path.exists(gpath):
+            g = np.load(gpath)
+            small = synth.make_inputs(opt, 64, seed=15, train=False)
+            seq, lps, att2, _ = model._sample(*[small[k].to(dev) for k in keys])
+            idx = attended_region_indices(att2, opt.num_sampled_frm, opt.num_prop_per_frm).cpu().numpy()
+            out['parity'] = {'golden': 'tests/golden/greedy_b64_v5000_ft480_trained.npz (reference CPU output)',
+                             'token_ids_equal': bool((seq.cpu().numpy() == g['seq']).all()),
+                             'attended_region_indices_equal': bool((idx == g['att_idx'].astype(idx.dtype)).all())}
+            del small, seq, lps, att2
+        # the 256-segment batch: four copies of a 64-segment synthetic batch (1.5 GB of frame features are not worth
+        # generating on the host for a timing run; the arithmetic does not depend on the values)
+        inp = synth.make_inputs(opt, 64, seed=101, train=False)
+        d = [torch.cat([inp[k].to(dev)] * 4, 0) for k in keys]
+        for _ in range(2):
+            model._sample(*d)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            model._sample(*d)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_steps
+    model.check_kernel_status()
+    out.update(ms_per_step=round(1e3 * dt, 3), captions_per_s=round(256 / dt, 1), steps_timed=n_steps)
+    del model, d
+    torch.cuda.empty_cache()
+    return out
+
+
 def bench_train(args, opt, sd, model, B, rank, world, dev):
     """BASELINE configs[2]/[3]: one optimisation step = 'MLE' forward (LM + attention + grounding + cls losses),
     hand-scheduled BPTT, RCCL gradient all-reduce (N>1), clip 0.1, Adam.  Train mode (dropout, BN batch stats)."""
@@ -556,6 +601,7 @@ def main():
             torch.cuda.empty_cache()
             out['config']['configs2_train_b64'] = section_train_b64(dev)
             out['config']['configs4_beam5_t20_b64'] = section_beam5_t20_b64(dev)
+            out['config']['ft480_b256'] = section_ft480_b256(dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(opt, sd, args.cpu_seconds, beam=args.beam)
         else:

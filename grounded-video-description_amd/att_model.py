@@ -284,25 +284,40 @@ class TopDownModel(nn.Module):
             bad, contract = counts.tolist()      # one device->host read
             self.raise_for_status(bad, contract)
 
-    def _lin(self, x, lin, act=0):
-        """nn.Linear (+ReLU) on the fp32 MFMA GEMM."""
-        return ops.linear(x, lin.weight, lin.bias, act)
+    def _lin(self, x, lin, act=0, p_drop=0.0):
+        """nn.Linear (+ReLU (+training-mode dropout of probability p_drop)) on the fp32 MFMA GEMM."""
+        return ops.linear(x, lin.weight, lin.bias, act, p_drop)
 
-    def _lin_k32(self, x, lin, act=0, x_padded=False):
+    def _fused_drop_p(self, p=None):
+        """Drop probability to hand to a fused Linear + ReLU + dropout site (ops.linear(..., p_drop)): the module's
+        probability in training mode, 0 in eval mode - or when the fused elementwise kernels are switched off
+        (GVD_TRAIN_FUSED_ELEMENTWISE=0), in which case the caller applies F.dropout itself via _drop_after."""
+        if not self.training or not ops.FUSED_TRAIN_ELEMENTWISE:
+            return 0.0
+        return float(self.drop_prob_lm if p is None else p)
+
+    def _drop_after(self, x, p=None):
+        """F.dropout after a site that takes its dropout fused when it can (see _fused_drop_p): the ATen pass only when the
+        fused form is switched off."""
+        if self.training and not ops.FUSED_TRAIN_ELEMENTWISE:
+            return F.dropout(x, self.drop_prob_lm if p is None else p, True)
+        return x
+
+    def _lin_k32(self, x, lin, act=0, x_padded=False, p_drop=0.0):
         """nn.Linear (+ReLU) whose input width is not a multiple of the GEMM's 32-deep k tile (fc_embed: K = 3122,
         loc_fc: K = 5) on the fp32 MFMA GEMM: input and weight zero-padded along K (the padded weight is cached at
         inference; under autograd the pad is part of the graph).  x_padded: x already carries the zero columns (the fused
         feature kernels of the inference preamble write them)."""
         pad = (-lin.in_features) % 32
         if pad == 0:
-            return self._lin(x, lin, act)
+            return self._lin(x, lin, act, p_drop)
         xp = x if x_padded else F.pad(x, (0, pad))
         assert xp.shape[-1] == lin.in_features + pad
         if torch.is_grad_enabled():
             w = F.pad(lin.weight, (0, pad))
         else:
             w = self._packed(('k32', id(lin)), (lin.weight,), lambda: F.pad(lin.weight, (0, pad)).contiguous())
-        return ops.linear(xp, w, lin.bias, act)
+        return ops.linear(xp, w, lin.bias, act, p_drop)
 
     def _drop(self, x, p=None):
         return F.dropout(x, self.drop_prob_lm if p is None else p, self.training)
@@ -323,12 +338,15 @@ class TopDownModel(nn.Module):
         return hit[1]
 
     @staticmethod
-    def _add_ln(x, y, ln):
-        """ResidualBlock tail (transformer.py:79-88): add + the custom LayerNorm, one fused row kernel forward and one
-        backward for the d_model the kernels are built for; the module's elementwise form otherwise."""
+    def _add_ln(x, y, ln, p_drop=0.0):
+        """ResidualBlock tail (transformer.py:79-88): dropout(p_drop, already resolved for the mode) on the branch y, add +
+        the custom LayerNorm: one fused row kernel forward and one backward for the d_model the kernels are built for; the
+        module's elementwise form otherwise."""
         if x.shape[-1] == 1024 and x.is_cuda and os.environ.get('GVD_LN_FUSED_BWD', '1') == '1':
-            return ops.add_layernorm(x, y, ln.gamma, ln.beta, ln.eps)
-        return ln(x + y)
+            if p_drop > 0 and not ops.FUSED_TRAIN_ELEMENTWISE:
+                y, p_drop = F.dropout(y, p_drop, True), 0.0
+            return ops.add_layernorm(x, y, ln.gamma, ln.beta, ln.eps, p_drop)
+        return ln(x + (F.dropout(y, p_drop, True) if p_drop > 0 else y))
 
     def _obj_interact_train(self, x, scale):
         """Training path of the region encoder (transformer.py:39-117) with every product on the fp32-MFMA GEMM: the
@@ -355,9 +373,9 @@ class TopDownModel(nn.Module):
             o = ops.enc_attn_core(qkv, R, nh, 1.0 / scale, p_drop)
             att = ops.linear(o.view(B * Rp, nh * HP), w_o)
             ff = lay.feedforward.layer
-            xp = self._add_ln(xp, F.dropout(att, lay.selfattn.dropout.p, self.training), lay.selfattn.layernorm)
+            xp = self._add_ln(xp, att, lay.selfattn.layernorm, lay.selfattn.dropout.p if self.training else 0.0)
             y = self._lin(self._lin(xp, ff.linear1, act=1), ff.linear2)
-            xp = self._add_ln(xp, F.dropout(y, lay.feedforward.dropout.p, self.training), lay.feedforward.layernorm)
+            xp = self._add_ln(xp, y, lay.feedforward.layernorm, lay.feedforward.dropout.p if self.training else 0.0)
         return xp.view(B, Rp, d)[:, :R]
 
     def _obj_interact_fused(self, x, ci=None):
@@ -503,9 +521,9 @@ class TopDownModel(nn.Module):
             else:
                 # ResidualBlock (transformer.py:79-88): dropout on the branch, then add + LayerNorm as one fused row
                 # kernel forward and one backward
-                x = self._add_ln(x, F.dropout(att, lay.selfattn.dropout.p, self.training), lay.selfattn.layernorm)
+                x = self._add_ln(x, att, lay.selfattn.layernorm, lay.selfattn.dropout.p if self.training else 0.0)
                 y = self._lin(self._lin(x, ff.linear1, act=1), ff.linear2)
-                x = self._add_ln(x, F.dropout(y, lay.feedforward.dropout.p, self.training), lay.feedforward.layernorm)
+                x = self._add_ln(x, y, lay.feedforward.layernorm, lay.feedforward.dropout.p if self.training else 0.0)
         return x
 
     def _preamble(self, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, allow_compact=False):
@@ -538,10 +556,11 @@ class TopDownModel(nn.Module):
             pre.update(ci=ci, pool_c=pool_c, p_pool_c=p_pool_c)
             return pre
         # fc7 over the raw fc6 region features: MFMA GEMM + fused bias/ReLU (model.py:311-313)
-        g_pool = self._drop(self._lin(ppls_feat, self.ctx2pool_grd[0], act=1))
+        g_pool = self._drop_after(self._lin(ppls_feat, self.ctx2pool_grd[0], act=1, p_drop=self._fused_drop_p()))
         vis_word = self._drop(F.relu(self.vis_embed[0].weight))
         loc_in = torch.cat([ppls[:, :, :4] / 720., (ppls[:, :, 4] * 1. / self.num_sampled_frm).unsqueeze(-1)], dim=2)
-        loc = F.dropout(self._lin_k32(loc_in, self.loc_fc[0], act=1), self.loc_fc[2].p, self.training)
+        loc = self._drop_after(self._lin_k32(loc_in, self.loc_fc[0], act=1, p_drop=self._fused_drop_p(self.loc_fc[2].p)),
+                               self.loc_fc[2].p)
         pool_done = False
         if not torch.is_grad_enabled():
             # inference: class-last similarity logits from ONE plain MFMA GEMM (the visual words are shared by the
@@ -573,7 +592,8 @@ class TopDownModel(nn.Module):
             pool, sim_t = ops.region_feature_rows_train(g_pool, loc, logits_t, pm, D1, pad_to=32)
             sim_mat = sim_t.transpose(1, 2)          # [B,D1,R] view of the class-last tensor
             pe = self.pool_embed[0]
-            pool = self._drop(ops.linear(pool, F.pad(pe.weight, (0, pool.shape[-1] - pe.weight.shape[1])), pe.bias, 1))
+            pool = self._drop_after(ops.linear(pool, F.pad(pe.weight, (0, pool.shape[-1] - pe.weight.shape[1])), pe.bias, 1,
+                                               self._fused_drop_p()))
             pool_done = True
         else:
             # (GVD_P5_FUSED_TRAIN=0) region-class similarity: batched grounder GEMM with fused bias + proposal mask (model.py:321-340)
@@ -585,7 +605,7 @@ class TopDownModel(nn.Module):
             pool = torch.cat([F.layer_norm(g_pool, [g_pool.shape[-1]]), F.layer_norm(loc, [300]),
                               F.layer_norm(label, [D1])] + ([label.new_zeros(B, R, kpad)] if kpad else []), dim=2)
             pe = self.pool_embed[0]
-            pool = self._drop(ops.linear(pool, F.pad(pe.weight, (0, kpad)), pe.bias, 1))     # model.py:384
+            pool = self._drop_after(ops.linear(pool, F.pad(pe.weight, (0, kpad)), pe.bias, 1, self._fused_drop_p()))   # model.py:384
             pool_done = True
         if not pool_done:
             pool = self._drop(F.relu(self.pool_embed[0](pool)))
@@ -598,7 +618,8 @@ class TopDownModel(nn.Module):
     def _preamble_finish(self, segs_feat, sample_idx, fc, pm, pool, p_pool, sim_mat, g_pool):
         """fc embedding + the frame half of the preamble (model.py:393-405)."""
         Ft = segs_feat.shape[1]
-        fc = self._drop(self._lin_k32(fc, self.fc_embed[0], act=1, x_padded=fc.shape[-1] != self.fc_embed[0].in_features))
+        fc = self._drop_after(self._lin_k32(fc, self.fc_embed[0], act=1, x_padded=fc.shape[-1] != self.fc_embed[0].in_features,
+                                            p_drop=self._fused_drop_p()))
         # frame-wise context (model.py:393-405)
         # frame embeddings (model.py:393-395) on the MFMA GEMM, straight from the two column blocks of segs_feat
         if not self.training and not torch.is_grad_enabled():
@@ -623,8 +644,9 @@ class TopDownModel(nn.Module):
             else:
                 c.mul_(scale).add_(shift).relu_()
         else:
-            c = torch.cat([self._drop(self._lin(segs_feat[:, :, :2048], self.att_embed[0][0], act=1)),
-                           self._drop(self._lin(segs_feat[:, :, 2048:], self.att_embed[1][0], act=1))], dim=2)
+            c = torch.cat([self._drop_after(self._lin(segs_feat[:, :, :2048], self.att_embed[0][0], act=1, p_drop=self._fused_drop_p())),
+                           self._drop_after(self._lin(segs_feat[:, :, 2048:], self.att_embed[1][0], act=1, p_drop=self._fused_drop_p()))],
+                          dim=2)
             c = self.att_embed_aux(c.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
         if not torch.is_grad_enabled():
             # inference: persistent cooperative HIP GRU (one launch per layer instead of ~6 per step/direction)

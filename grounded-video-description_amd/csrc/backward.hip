@@ -18,6 +18,7 @@ constexpr int ATT_A = 512;
 constexpr int ATT_H = 1024;
 
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ dh, int64_t lddh,
+                                                       const float* __restrict__ dh2, int64_t lddh2,
                                                        const float* __restrict__ dc_next, int64_t lddc,
                                                        const float* __restrict__ gates, int64_t ldg,
                                                        const float* __restrict__ c_prev, int64_t ldcp,
@@ -30,7 +31,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   const float* g = gates + (int64_t)b * ldg;
   const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
   const float tc = tanhf(c_new[(int64_t)b * ldcn + j]);
-  const float dhv = dh[(int64_t)b * lddh + j];
+  float dhv = dh[(int64_t)b * lddh + j];
+  if (dh2) dhv += dh2[(int64_t)b * lddh2 + j];
   float dc = dhv * go * (1.f - tc * tc);
   if (dc_next) dc += dc_next[(int64_t)b * lddc + j];
   float* dg = dgates + (int64_t)b * lddg;
@@ -186,14 +188,14 @@ __global__ __launch_bounds__(256) void attn_bwd_pfeats_kernel(const BwdPfParams 
 
 }  // namespace
 
-extern "C" int gvd_lstm_cell_bwd(const float* dh, int64_t lddh, const float* dc_next, int64_t lddc,
-                                 const float* gates, int64_t ldg, const float* c_prev, int64_t ldcp,
+extern "C" int gvd_lstm_cell_bwd(const float* dh, int64_t lddh, const float* dh2, int64_t lddh2, const float* dc_next,
+                                 int64_t lddc, const float* gates, int64_t ldg, const float* c_prev, int64_t ldcp,
                                  const float* c_new, int64_t ldcn, int B, int H, float* dgates, int64_t lddg,
                                  float* dc_prev, int64_t lddcp, gvd_stream_t stream) {
   if (!dh || !gates || !c_prev || !c_new || !dgates || !dc_prev || B <= 0 || H <= 0) return GVD_EINVAL;
   const int64_t n = (int64_t)B * H;
   hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, gvd_s(stream), dh, lddh,
-                     dc_next, lddc, gates, ldg, c_prev, ldcp, c_new, ldcn, B, H, dgates, lddg, dc_prev, lddcp);
+                     dh2, lddh2, dc_next, lddc, gates, ldg, c_prev, ldcp, c_new, ldcn, B, H, dgates, lddg, dc_prev, lddcp);
   GVD_CHECK_LAUNCH();
   return 0;
 }

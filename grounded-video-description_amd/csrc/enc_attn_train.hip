@@ -12,6 +12,7 @@
 //             read back as Pd != 0 (where y underflowed to 0 the gradient is 0 either way), so no mask tensor exists.
 // The reference (ATen) makes 4 elementwise passes forward and 6 backward over the same maps.
 #include "gvd_common.h"
+#include "philox.h"
 
 #include <stdint.h>
 
@@ -19,21 +20,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-struct U4 { uint32_t v[4]; };
-
-__device__ __forceinline__ U4 philox4x32_10(uint64_t ctr, uint64_t seed) {
-  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  return U4{{c0, c1, c2, c3}};
-}
+using U4 = GvdU4;
+__device__ __forceinline__ U4 philox4x32_10(uint64_t ctr, uint64_t seed) { return gvd_philox4x32_10(ctr, seed); }
 
 constexpr int MAXNV = 8;      // Rp <= 2048
 

@@ -10,16 +10,21 @@
 //      (reads 11 KB, writes 13 KB per row instead of ~8 passes over [B,R,2781]-sized tensors).
 // HBM-bound streaming kernels; values stay in registers between the statistics and the normalisation pass.
 #include "gvd_common.h"
+#include "philox.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-template <int D>   // D = 64 * 4 * NV
+// DROP (training): s = x + y * keep / (1 - p), the branch dropout of the ResidualBlock (transformer.py:84-87) applied while
+// y streams through - keep from Philox (philox.h: counter = flat index / 4 of the contiguous [rows, D] tensor, the same
+// mask gvd_dropout_rows draws for the same seed); the backward kernel regenerates it.
+template <int D, bool DROP>   // D = 64 * 4 * NV
 __global__ __launch_bounds__(256) void add_ln_unbiased_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ out,
-                                                              int64_t rows, const int* __restrict__ rows_dev, float eps) {
+                                                              int64_t rows, const int* __restrict__ rows_dev, float eps,
+                                                              uint32_t thresh, float keep_scale, uint64_t seed) {
   constexpr int NV = D / 256;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -32,7 +37,12 @@ __global__ __launch_bounds__(256) void add_ln_unbiased_kernel(const float* __res
   for (int i = 0; i < NV; ++i) {
     v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + i * 256 + 4 * lane));   // read-once streams
     if (yr) {
-      const f32x4 w = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(yr + i * 256 + 4 * lane));
+      f32x4 w = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(yr + i * 256 + 4 * lane));
+      if constexpr (DROP) {
+        const GvdU4 u = gvd_philox4x32_10((uint64_t)row * (uint64_t)(D / 4) + (uint64_t)(i * 64 + lane), seed);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = u.v[k] >= thresh ? w[k] * keep_scale : 0.f;
+      }
       v[i][0] += w[0]; v[i][1] += w[1]; v[i][2] += w[2]; v[i][3] += w[3];
     }
     s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
@@ -61,12 +71,16 @@ __global__ __launch_bounds__(256) void add_ln_unbiased_kernel(const float* __res
 // transformer.py:66-88): ds (= dx = dy_branch) per row, and per-workgroup partial sums of dgamma / dbeta (a workgroup
 // walks ROWS_PER_WG rows with one wave per row; lanes keep the partials of their 16 columns in registers; the host adds
 // the [nwg, D] partials in order).  Statistics are recomputed from s: nothing but x, y is kept from the forward.
+// DROP: s is recomputed as x + y * keep / (1 - p) with the forward's mask, and the branch gradient dyb = ds * keep / (1 - p)
+// is written next to ds (without dropout both addends share ds).
 constexpr int LNB_ROWS = 64;
-template <int D>
+template <int D, bool DROP>
 __global__ __launch_bounds__(256) void add_ln_unbiased_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                   const float* __restrict__ dout,
                                                                   const float* __restrict__ gamma, float* __restrict__ ds,
-                                                                  float* __restrict__ part, int64_t rows, float eps) {
+                                                                  float* __restrict__ dyb, float* __restrict__ part,
+                                                                  int64_t rows, float eps, uint32_t thresh, float keep_scale,
+                                                                  uint64_t seed) {
   constexpr int NV = D / 256;
   __shared__ float s_acc[4][2][D / 4 + 4];      // staged one quarter of the columns at a time (see below)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,11 +96,20 @@ __global__ __launch_bounds__(256) void add_ln_unbiased_bwd_kernel(const float* _
     const int64_t row = r0 + rr;
     if (row >= rows) break;
     f32x4 v[NV], d[NV];
+    f32x4 km[DROP ? NV : 1];       // keep / (1 - p) per element (DROP only)
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       v[i] = *reinterpret_cast<const f32x4*>(x + row * D + i * 256 + 4 * lane);
-      if (y) v[i] += *reinterpret_cast<const f32x4*>(y + row * D + i * 256 + 4 * lane);
+      if constexpr (DROP) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(y + row * D + i * 256 + 4 * lane);
+        const GvdU4 u = gvd_philox4x32_10((uint64_t)row * (uint64_t)(D / 4) + (uint64_t)(i * 64 + lane), seed);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          km[i][k] = u.v[k] >= thresh ? keep_scale : 0.f;
+          v[i][k] = fmaf(w[k], km[i][k], v[i][k]);
+        }
+      } else if (y) v[i] += *reinterpret_cast<const f32x4*>(y + row * D + i * 256 + 4 * lane);
       d[i] = *reinterpret_cast<const f32x4*>(dout + row * D + i * 256 + 4 * lane);
       sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
@@ -125,6 +148,10 @@ __global__ __launch_bounds__(256) void add_ln_unbiased_bwd_kernel(const float* _
     for (int i = 0; i < NV; ++i) {
       f32x4 o = {v[i][0] - gm, v[i][1] - gm, v[i][2] - gm, v[i][3] - gm};
       *reinterpret_cast<f32x4*>(ds + row * D + i * 256 + 4 * lane) = o;
+      if constexpr (DROP) {
+        const f32x4 ob = {o[0] * km[i][0], o[1] * km[i][1], o[2] * km[i][2], o[3] * km[i][3]};
+        *reinterpret_cast<f32x4*>(dyb + row * D + i * 256 + 4 * lane) = ob;
+      }
     }
   }
   // reduce the 4 waves' partials through LDS, one 256-column slab (index i) at a time
@@ -408,8 +435,21 @@ extern "C" int gvd_add_layernorm_unbiased(const float* x, const float* y, const 
   if (!x || !gamma || !beta || !out || rows <= 0 || D != 1024) return GVD_EINVAL;
   if (!gvd_aligned16(x) || (y && !gvd_aligned16(y)) || !gvd_aligned16(out) || !gvd_aligned16(gamma) || !gvd_aligned16(beta))
     return GVD_EINVAL;
-  hipLaunchKernelGGL(add_ln_unbiased_kernel<1024>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, gvd_s(stream), x, y,
-                     gamma, beta, out, rows, rows_dev, eps);
+  hipLaunchKernelGGL((add_ln_unbiased_kernel<1024, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, gvd_s(stream), x,
+                     y, gamma, beta, out, rows, rows_dev, eps, 0u, 1.0f, (uint64_t)0);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gvd_add_layernorm_unbiased_drop(const float* x, const float* y, const float* gamma, const float* beta,
+                                               float* out, int64_t rows, int D, float eps, float p_drop, uint64_t seed,
+                                               gvd_stream_t stream) {
+  if (!x || !y || !gamma || !beta || !out || rows <= 0 || D != 1024 || !(p_drop > 0.f) || !(p_drop < 1.f)) return GVD_EINVAL;
+  if (!gvd_aligned16(x) || !gvd_aligned16(y) || !gvd_aligned16(out) || !gvd_aligned16(gamma) || !gvd_aligned16(beta))
+    return GVD_EINVAL;
+  hipLaunchKernelGGL((add_ln_unbiased_kernel<1024, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, gvd_s(stream), x,
+                     y, gamma, beta, out, rows, (const int*)nullptr, eps, gvd_drop_thresh(p_drop), 1.0f / (1.0f - p_drop),
+                     seed);
   GVD_CHECK_LAUNCH();
   return 0;
 }
@@ -423,8 +463,23 @@ extern "C" int gvd_add_layernorm_unbiased_bwd(const float* x, const float* y, co
   if (!gvd_aligned16(x) || (y && !gvd_aligned16(y)) || !gvd_aligned16(dout) || !gvd_aligned16(ds) || !gvd_aligned16(gamma) ||
       !gvd_aligned16(partials))
     return GVD_EINVAL;
-  hipLaunchKernelGGL(add_ln_unbiased_bwd_kernel<1024>, dim3((unsigned)((rows + LNB_ROWS - 1) / LNB_ROWS)), dim3(256), 0,
-                     gvd_s(stream), x, y, dout, gamma, ds, partials, rows, eps);
+  hipLaunchKernelGGL((add_ln_unbiased_bwd_kernel<1024, false>), dim3((unsigned)((rows + LNB_ROWS - 1) / LNB_ROWS)), dim3(256),
+                     0, gvd_s(stream), x, y, dout, gamma, ds, (float*)nullptr, partials, rows, eps, 0u, 1.0f, (uint64_t)0);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gvd_add_layernorm_unbiased_drop_bwd(const float* x, const float* y, const float* dout, const float* gamma,
+                                                   float* ds, float* dy, float* partials, int64_t rows, int D, float eps,
+                                                   float p_drop, uint64_t seed, gvd_stream_t stream) {
+  if (!x || !y || !dout || !gamma || !ds || !dy || !partials || rows <= 0 || D != 1024 || !(p_drop > 0.f) || !(p_drop < 1.f))
+    return GVD_EINVAL;
+  if (!gvd_aligned16(x) || !gvd_aligned16(y) || !gvd_aligned16(dout) || !gvd_aligned16(ds) || !gvd_aligned16(dy) ||
+      !gvd_aligned16(gamma) || !gvd_aligned16(partials))
+    return GVD_EINVAL;
+  hipLaunchKernelGGL((add_ln_unbiased_bwd_kernel<1024, true>), dim3((unsigned)((rows + LNB_ROWS - 1) / LNB_ROWS)), dim3(256),
+                     0, gvd_s(stream), x, y, dout, gamma, ds, dy, partials, rows, eps, gvd_drop_thresh(p_drop),
+                     1.0f / (1.0f - p_drop), seed);
   GVD_CHECK_LAUNCH();
   return 0;
 }

@@ -68,14 +68,18 @@ class DecoderLoopFn(torch.autograd.Function):
         dw_t_all = torch.empty(Lc, B, nc_t, A, device=dev, dtype=fc.dtype)
         dab_r_all = torch.empty(Lc, B, nc_r, device=dev, dtype=fc.dtype)
         dab_t_all = torch.empty(Lc, B, nc_t, device=dev, dtype=fc.dtype)
+        # per-chunk partials of one step's two query gradients (rewritten every step; summed into dq12_all[t] by ONE launch)
+        dq_r_part = torch.empty(B, nc_r, A, device=dev, dtype=fc.dtype)
+        dq_t_part = torch.empty(B, nc_t, A, device=dev, dtype=fc.dtype)
         dh_att_next = dh_lang_next = None
         dc_att_next = dc_lang_next = None
         w_lang_ih, w_lang_hh, w_att_hh = P['lang_w_ih'], P['lang_w_hh'], P['att_w_hh']
         for t in range(Lc - 1, -1, -1):
             # every kernel writes its step's slice of the [Lc, ...] arrays in place: no per-step copies / partial sums
-            dh_lang = d_h_all[:, t] if dh_lang_next is None else d_h_all[:, t] + dh_lang_next
-            dg, dc_lang_next = K.lstm_cell_bwd(dh_lang, dc_lang_next, S['gates_lang'][t], S['c_lang'][t], S['c_lang'][t + 1],
-                                               dg_out=dG_lang[t])
+            # (the two addends of a hidden-state gradient - this step's output gradient and the recurrent term of step
+            # t + 1 - are added inside the pointwise kernel)
+            dg, dc_lang_next = K.lstm_cell_bwd(d_h_all[:, t], dc_lang_next, S['gates_lang'][t], S['c_lang'][t],
+                                               S['c_lang'][t + 1], dg_out=dG_lang[t], dh2=dh_lang_next)
             dX = torch.mm(dg, w_lang_ih, out=dX_all[t])         # [B,2H] = [d(att+att2) | d h_att]
             dh_lang_next = dg @ w_lang_hh
             d_att_sum = dX[:, :H]
@@ -87,14 +91,13 @@ class DecoderLoopFn(torch.autograd.Function):
             dl = d_att2w[:, t] if d_att2w is not None else None
             dq12 = dq12_all[t]
             K.attn_bwd_step(region, alpha_r[:, t], S['ctx_r'][t], d_att_sum, dl, de_out=de_r_all[t],
-                            dq_out=dq12[:, A:], dw_part=dw_r_all[t], dab_part=dab_r_all[t])
+                            dq_part=dq_r_part, dw_part=dw_r_all[t], dab_part=dab_r_all[t])
             K.attn_bwd_step(temporal, alpha_t[:, t], S['ctx_t'][t], d_att_sum, None, de_out=de_t_all[t],
-                            dq_out=dq12[:, :A], dw_part=dw_t_all[t], dab_part=dab_t_all[t])
+                            dq_part=dq_t_part, dw_part=dw_t_all[t], dab_part=dab_t_all[t])
+            K.sum_chunks_pair(dq_t_part, dq_r_part, dq12)        # [:, :A] temporal (a1), [:, A:] region (a2)
             dh_att = torch.addmm(dX[:, H:], dq12, w_stack)
-            if dh_att_next is not None:
-                dh_att += dh_att_next
             dg, dc_att_next = K.lstm_cell_bwd(dh_att, dc_att_next, S['gates_att'][t], S['c_att'][t], S['c_att'][t + 1],
-                                              dg_out=dG_att[t])
+                                              dg_out=dG_att[t], dh2=dh_att_next)
             dh_att_next = dg @ w_att_hh
         dw_r, dw_t = dw_r_all.sum((0, 1, 2)), dw_t_all.sum((0, 1, 2))
         dab_r, dab_t = dab_r_all.sum().view(1), dab_t_all.sum().view(1)

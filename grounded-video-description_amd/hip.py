@@ -84,6 +84,20 @@ class BeamStepArgs(C.Structure):
                 ('B', C.c_int), ('K', C.c_int), ('L', C.c_int), ('t', C.c_int)]
 
 
+OPT_MAX_TENSORS = 32       # GVD_OPT_MAX_TENSORS
+OPT_CHUNK = 16384          # GVD_OPT_CHUNK
+
+
+class OptGroup(C.Structure):
+    """gvd_opt_group: up to 32 parameter tensors of one optimiser launch, passed by value."""
+    _fields_ = [('p', C.c_void_p * OPT_MAX_TENSORS), ('g', C.c_void_p * OPT_MAX_TENSORS),
+                ('m', C.c_void_p * OPT_MAX_TENSORS), ('v', C.c_void_p * OPT_MAX_TENSORS),
+                ('n', C.c_int64 * OPT_MAX_TENSORS), ('chunk0', C.c_int * (OPT_MAX_TENSORS + 1)),
+                ('lr', C.c_float * OPT_MAX_TENSORS), ('bc1', C.c_float * OPT_MAX_TENSORS),
+                ('bc2_sqrt', C.c_float * OPT_MAX_TENSORS), ('vec_ok', C.c_uint8 * OPT_MAX_TENSORS),
+                ('count', C.c_int), ('part0', C.c_int)]
+
+
 # every symbol include/gvd_hip.h declares: (restype, argtypes)
 _SIG = {
     'gvd_version': (C.c_char_p, []),
@@ -106,6 +120,10 @@ _SIG = {
     'gvd_add_layernorm_unbiased_bwd_parts': (C.c_int, [C.c_int64]),
     'gvd_add_layernorm_unbiased_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int,
                                                  C.c_float, C.c_void_p]),
+    'gvd_add_layernorm_unbiased_drop': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_float,
+                                                  C.c_float, C.c_uint64, C.c_void_p]),
+    'gvd_add_layernorm_unbiased_drop_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64,
+                                                      C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
     'gvd_enc_softmax_dropout_fwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
                                               C.c_uint64, C.c_void_p]),
     'gvd_enc_softmax_dropout_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -136,8 +154,8 @@ _SIG = {
                                       C.c_void_p, C.c_void_p]),
     'gvd_gru_bwd_step': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    'gvd_lstm_cell_bwd': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64,
-                                    c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int64,
+    'gvd_lstm_cell_bwd': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p,
+                                    C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int64,
                                     C.c_void_p]),
     'gvd_attn_bwd_chunks': (C.c_int, [C.c_int, C.c_int]),
     'gvd_attn_bwd_step': (C.c_int, [C.POINTER(AttnSide), C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p,
@@ -164,10 +182,18 @@ _SIG = {
                                C.c_void_p]),
     'gvd_masked_lsm_loss': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, c_f32p,
                                       C.c_void_p]),
+    'gvd_dropout_rows': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p]),
+    'gvd_relu_dropout_bwd_parts': (C.c_int, [C.c_int64]),
+    'gvd_relu_dropout_bwd_colsum': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    'gvd_sum_chunks_pair': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_void_p]),
+    'gvd_opt_chunk': (C.c_int, []),
+    'gvd_sumsq_partials': (C.c_int, [C.c_void_p, c_f32p, C.c_void_p]),
+    'gvd_clip_coef': (C.c_int, [c_f32p, C.c_int, C.c_float, c_f32p, C.c_void_p]),
+    'gvd_adam_step': (C.c_int, [C.c_void_p, c_f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 11        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 12        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

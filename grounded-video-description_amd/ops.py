@@ -66,10 +66,10 @@ def gemm_dx(dY, W):
     return out
 
 
-def gemm_dw(dY, X):
+def gemm_dw(dY, X, split=None):
     """dW[N,K] = dY[M,N]^T @ X[M,K] (backward of y = x W^T w.r.t. W): both operands K-strided; the long contraction over
     the M = B*R rows is cut into S chunks run as a batch (deterministic split-K), partial slabs summed.  None = shape not
-    taken."""
+    taken.  split: force S (tools/dw_split_sweep.py)."""
     M, N = dY.shape
     K = X.shape[1]
     if N % 4 or K % 4 or not (dY.is_contiguous() and X.is_contiguous()):
@@ -78,6 +78,8 @@ def gemm_dw(dY, X):
     S = 1
     while tiles * S < 1024 and M % (64 * S) == 0 and M // (2 * S) >= 2048:
         S *= 2
+    if split is not None:
+        S = split
     if M % (32 * S) or tiles * S < 256:
         return None
     Mc = M // S
@@ -353,11 +355,55 @@ def masked_lsm_loss(x, label):
 # --------------------------------------------------------------------------------------------------
 # autograd-aware entry points (forward = HIP kernel; backward GEMMs are plain library GEMMs via torch)
 # --------------------------------------------------------------------------------------------------
+def draw_seed():
+    """A 62-bit Philox key for one dropout site and step, from torch's CPU generator (reproducible under
+    torch.manual_seed; no device synchronisation)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def dropout_(x, p_drop, seed):
+    """In-place F.dropout (training mode) on a contiguous fp32 tensor: x <- x * keep / (1 - p), keep from Philox keyed by
+    `seed` (csrc/train_fused.hip).  No mask tensor is produced: backward passes regenerate it or do without."""
+    require_cuda_f32(x)
+    assert x.is_contiguous() and x.numel() % 4 == 0
+    check(lib().gvd_dropout_rows(ptr(x), ptr(x), x.numel(), float(p_drop), seed, stream_ptr()), 'gvd_dropout_rows')
+    return x
+
+
+def dropout_rows(x, p_drop, seed):
+    """Out-of-place form of dropout_ (tests; the mask of the fused residual LayerNorm for the same seed)."""
+    require_cuda_f32(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(lib().gvd_dropout_rows(ptr(x), ptr(y), x.numel(), float(p_drop), seed, stream_ptr()), 'gvd_dropout_rows')
+    return y
+
+
+def relu_dropout_bwd(dy, y, p_drop):
+    """Backward of y = dropout(relu(z)) from y alone (y > 0 <=> z > 0 and kept): returns dz [M,N] and the bias gradient
+    sum_m dz [N] from ONE pass over (dy, y) (gvd_relu_dropout_bwd_colsum; the per-workgroup partials are added in order)."""
+    M, N = dy.shape
+    dz = torch.empty_like(dy)
+    parts = torch.empty(lib().gvd_relu_dropout_bwd_parts(M), N, device=dy.device, dtype=torch.float32)
+    check(lib().gvd_relu_dropout_bwd_colsum(ptr(dy), ptr(y), ptr(dz), ptr(parts), M, N, float(p_drop), stream_ptr()),
+          'gvd_relu_dropout_bwd_colsum')
+    return dz, parts.sum(0)
+
+
+FUSED_TRAIN_ELEMENTWISE = os.environ.get('GVD_TRAIN_FUSED_ELEMENTWISE', '1') == '1'   # A/B knob (0: the ATen passes)
+
+
 class _LinearFn(torch.autograd.Function):
+    """nn.Linear (+ReLU (+dropout)) forward on the MFMA GEMM; backward = [one fused pass: ReLU / dropout mask + bias
+    gradient] + the K-strided dX / dW products."""
+
     @staticmethod
-    def forward(ctx, x, w, b, act):
+    def forward(ctx, x, w, b, act, p_drop, seed):
         out = gemm_nt(x, w, b, act)
+        if p_drop > 0:
+            dropout_(out, p_drop, seed)           # in place on the product's fresh output: y = dropout(relu(z))
         ctx.act = act
+        ctx.p_drop = p_drop
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, out if act else None)
         return out
@@ -365,9 +411,17 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, out = ctx.saved_tensors
-        if ctx.act:
-            dy = torch.ops.aten.threshold_backward(dy, out, 0)      # ReLU backward in one pass (dy where out > 0)
-        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        db = None
+        fused = (ctx.act and FUSED_TRAIN_ELEMENTWISE and dy2.shape[-1] % 4 == 0 and dy2.data_ptr() % 16 == 0)
+        if fused:
+            dy2, db = relu_dropout_bwd(dy2.contiguous(), out.reshape(-1, out.shape[-1]), ctx.p_drop)
+        else:
+            if ctx.p_drop > 0:
+                dy2 = dy2 * (1.0 / (1.0 - ctx.p_drop))      # (out == 0 where dropped: the ReLU mask below covers the keep mask)
+            if ctx.act:
+                dy2 = torch.ops.aten.threshold_backward(dy2, out.reshape(-1, out.shape[-1]), 0)
+            dy2 = dy2.contiguous()
         x2 = x.reshape(-1, x.shape[-1])
         dx = dw = None
         if ctx.needs_input_grad[0]:
@@ -377,15 +431,24 @@ class _LinearFn(torch.autograd.Function):
             dw = gemm_dw(dy2, x2.detach()) if x2.is_contiguous() else None
             if dw is None:
                 dw = dy2.t() @ x2
-        db = dy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, None
+        if not (ctx.has_bias and ctx.needs_input_grad[2]):
+            db = None
+        elif db is None:
+            db = dy2.sum(0)
+        return dx, dw, db, None, None, None
 
 
-def linear(x, w, b=None, act=0):
-    """nn.Linear(+ReLU): MFMA GEMM forward; differentiable when grad mode is on."""
+def linear(x, w, b=None, act=0, p_drop=0.0):
+    """nn.Linear(+ReLU)(+F.dropout(p_drop), training mode): MFMA GEMM forward; differentiable when grad mode is on.
+    p_drop > 0 requires act = 1 (every dropout of the hot path that follows a Linear follows its ReLU: model.py:312,363,
+    384,393-395) - the backward then needs no mask."""
+    p_drop = float(p_drop)
+    assert p_drop == 0.0 or act == 1
+    seed = draw_seed() if p_drop > 0 else 0
     if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
-        return _LinearFn.apply(x, w, b, act)
-    return gemm_nt(x.detach(), w.detach(), None if b is None else b.detach(), act)
+        return _LinearFn.apply(x, w, b, act, p_drop, seed)
+    out = gemm_nt(x.detach(), w.detach(), None if b is None else b.detach(), act)
+    return dropout_(out, p_drop, seed) if p_drop > 0 else out
 
 
 class _GrounderFn(torch.autograd.Function):
@@ -521,16 +584,20 @@ class _NoCtx:
 # --------------------------------------------------------------------------------------------------
 # backward kernels of the decoder loop (used by decoder_bwd.DecoderLoopFn)
 # --------------------------------------------------------------------------------------------------
-def lstm_cell_bwd(dh, dc_next, gates, c_prev, c_new, dg_out=None):
+def lstm_cell_bwd(dh, dc_next, gates, c_prev, c_new, dg_out=None, dh2=None):
     """Pointwise LSTMCell backward -> (d pre-activation gates [B,4H], dc_prev [B,H]); `dg_out` ([B,4H], unit inner
-    stride) receives the gate gradients in place when given."""
-    require_cuda_f32(dh, dc_next, gates, c_prev, c_new)
+    stride) receives the gate gradients in place when given.  dh2: optional second addend of the hidden-state gradient
+    (the recurrent contribution of the next step), added inside the kernel."""
+    require_cuda_f32(dh, dh2, dc_next, gates, c_prev, c_new)
     B, H = c_prev.shape
     dh = dh if dh.stride(-1) == 1 else dh.contiguous()
+    if dh2 is not None and dh2.stride(-1) != 1:
+        dh2 = dh2.contiguous()
     dg = torch.empty(B, 4 * H, device=dh.device, dtype=torch.float32) if dg_out is None else dg_out
     assert dg.stride(-1) == 1 and dg.shape == (B, 4 * H)
     dcp = torch.empty(B, H, device=dh.device, dtype=torch.float32)
-    check(lib().gvd_lstm_cell_bwd(ptr(dh), dh.stride(0), ptr(dc_next), dc_next.stride(0) if dc_next is not None else 0,
+    check(lib().gvd_lstm_cell_bwd(ptr(dh), dh.stride(0), ptr(dh2), dh2.stride(0) if dh2 is not None else 0,
+                                  ptr(dc_next), dc_next.stride(0) if dc_next is not None else 0,
                                   ptr(gates), gates.stride(0), ptr(c_prev), c_prev.stride(0), ptr(c_new),
                                   c_new.stride(0), B, H, ptr(dg), dg.stride(0), ptr(dcp), H, stream_ptr()),
           'gvd_lstm_cell_bwd')
@@ -542,13 +609,15 @@ def attn_bwd_chunks(N, B):
     return lib().gvd_attn_bwd_chunks(N, B)
 
 
-def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None, de_out=None, dq_out=None, dw_part=None, dab_part=None):
+def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None, de_out=None, dq_out=None, dw_part=None, dab_part=None,
+                  dq_part=None):
     """One attention side, one step.  side: dict like attention_step's (feats, p_feats, q, w, alpha_bias
     [, att_mask, pnt_mask]).  Returns de [B,N], d_q [B,A], d_w [B,A] (per-sample partial of the alpha_net weight
     gradient), d_alpha_bias [B].
     In-place form for the BPTT loop: `de_out` [B,N] contiguous receives de, `dq_out` [B,A] (any strides) the summed
     query gradient, and `dw_part` [B,NC,A] / `dab_part` [B,NC] (NC = attn_bwd_chunks(N, B), contiguous) the UNSUMMED
-    per-chunk partials — the caller reduces them once for all steps; they are then returned as such."""
+    per-chunk partials — the caller reduces them once for all steps; they are then returned as such.  `dq_part`
+    [B,NC,A]: the query gradient is left as per-chunk partials too (the caller sums both sides with sum_chunks_pair)."""
     f = side['feats']
     B, N, H = f.shape
     A = side['p_feats'].shape[-1]
@@ -560,17 +629,32 @@ def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None, de_out=None, dq_out=No
     assert alpha.stride(-1) == 1 and ctx.stride(-1) == 1
     nc = lib().gvd_attn_bwd_chunks(N, B)
     de = torch.empty(B, N, device=f.device, dtype=torch.float32) if de_out is None else de_out
-    dq = torch.empty(B, nc, A, device=f.device, dtype=torch.float32)
+    dq = torch.empty(B, nc, A, device=f.device, dtype=torch.float32) if dq_part is None else dq_part
     dw = torch.empty(B, nc, A, device=f.device, dtype=torch.float32) if dw_part is None else dw_part
     dab = torch.empty(B, nc, device=f.device, dtype=torch.float32) if dab_part is None else dab_part
-    assert de.is_contiguous() and dw.is_contiguous() and dab.is_contiguous()
-    assert de.shape == (B, N) and dw.shape == (B, nc, A) and dab.shape == (B, nc)
+    assert de.is_contiguous() and dw.is_contiguous() and dab.is_contiguous() and dq.is_contiguous()
+    assert de.shape == (B, N) and dw.shape == (B, nc, A) and dab.shape == (B, nc) and dq.shape == (B, nc, A)
     check(lib().gvd_attn_bwd_step(C.byref(s), B, A, H, ptr(alpha), alpha.stride(0), ptr(ctx), ctx.stride(0),
                                   ptr(d_ctx), d_ctx.stride(0), ptr(d_logits),
                                   d_logits.stride(0) if d_logits is not None else 0, ptr(de), N, ptr(dq), ptr(dw),
                                   ptr(dab), stream_ptr()), 'gvd_attn_bwd_step')
-    dq_sum = torch.sum(dq, 1, out=dq_out) if dq_out is not None else dq.sum(1)
+    if dq_part is not None:
+        dq_sum = dq
+    else:
+        dq_sum = torch.sum(dq, 1, out=dq_out) if dq_out is not None else dq.sum(1)
     return de, dq_sum, (dw.sum(1) if dw_part is None else dw), (dab.sum(1) if dab_part is None else dab)
+
+
+def sum_chunks_pair(a, r, out):
+    """out[:, :A] = a.sum(1), out[:, A:] = r.sum(1) for the per-chunk partials a [B,nca,A], r [B,ncr,A] of the two
+    attention sides of one BPTT step (chunks added in order); out: [B, 2A] view with unit inner stride."""
+    require_cuda_f32(a, r, out)
+    B, nca, A = a.shape
+    assert a.is_contiguous() and r.is_contiguous() and r.shape[0] == B and r.shape[2] == A
+    assert out.shape == (B, 2 * A) and out.stride(-1) == 1
+    check(lib().gvd_sum_chunks_pair(ptr(a), nca, ptr(r), r.shape[1], B, A, ptr(out), out.stride(0), stream_ptr()),
+          'gvd_sum_chunks_pair')
+    return out
 
 
 def attn_bwd_pfeats(p_feats, q_all, de_all, w):
@@ -670,35 +754,58 @@ def add_layernorm_unbiased(x, y, gamma, beta, eps=1e-6, rows_dev=None):
 
 class _AddLnFn(torch.autograd.Function):
     """ResidualBlock + the encoder's LayerNorm (transformer.py:66-88) as ONE row kernel forward and ONE backward (training
-    path; the reference runs ~8 elementwise / reduction passes forward and ~15 backward over [B*R, 1024])."""
+    path; the reference runs ~8 elementwise / reduction passes forward and ~15 backward over [B*R, 1024]).  p_drop > 0:
+    the block's branch dropout (transformer.py:84,87) is applied inside both kernels (Philox mask regenerated from `seed`)."""
 
     @staticmethod
-    def forward(ctx, x, y, gamma, beta, eps):
-        out = add_layernorm_unbiased(x, y, gamma, beta, eps)
+    def forward(ctx, x, y, gamma, beta, eps, p_drop, seed):
+        if p_drop > 0:
+            D = x.shape[-1]
+            x2, y2 = x.reshape(-1, D), y.reshape(-1, D)
+            out = torch.empty_like(x2)
+            check(lib().gvd_add_layernorm_unbiased_drop(ptr(x2), ptr(y2), ptr(gamma), ptr(beta), ptr(out), x2.shape[0], D,
+                                                        eps, p_drop, seed, stream_ptr()), 'gvd_add_layernorm_unbiased_drop')
+            out = out.view_as(x)
+        else:
+            out = add_layernorm_unbiased(x, y, gamma, beta, eps)
         ctx.save_for_backward(x, y, gamma)
-        ctx.eps = eps
+        ctx.cfg = (eps, p_drop, seed)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, y, gamma = ctx.saved_tensors
+        eps, p_drop, seed = ctx.cfg
         D = x.shape[-1]
         x2, y2, d2 = x.reshape(-1, D), y.reshape(-1, D), dout.reshape(-1, D).contiguous()
         rows = x2.shape[0]
         ds = torch.empty_like(x2)
         nparts = lib().gvd_add_layernorm_unbiased_bwd_parts(rows)
         parts = torch.empty(nparts, 2, D, device=x.device, dtype=torch.float32)
-        check(lib().gvd_add_layernorm_unbiased_bwd(ptr(x2), ptr(y2), ptr(d2), ptr(gamma), ptr(ds), ptr(parts), rows, D,
-                                                   ctx.eps, stream_ptr()), 'gvd_add_layernorm_unbiased_bwd')
+        if p_drop > 0:
+            dy = torch.empty_like(x2)
+            check(lib().gvd_add_layernorm_unbiased_drop_bwd(ptr(x2), ptr(y2), ptr(d2), ptr(gamma), ptr(ds), ptr(dy),
+                                                            ptr(parts), rows, D, eps, p_drop, seed, stream_ptr()),
+                  'gvd_add_layernorm_unbiased_drop_bwd')
+            dy = dy.view_as(x)
+        else:
+            check(lib().gvd_add_layernorm_unbiased_bwd(ptr(x2), ptr(y2), ptr(d2), ptr(gamma), ptr(ds), ptr(parts), rows, D,
+                                                       eps, stream_ptr()), 'gvd_add_layernorm_unbiased_bwd')
+            dy = None
         ps = parts.sum(0)
         ds = ds.view_as(x)
-        return ds, ds, ps[0], ps[1], None
+        return ds, (ds if dy is None else dy), ps[0], ps[1], None, None, None
 
 
-def add_layernorm(x, y, gamma, beta, eps=1e-6):
-    """LayerNorm_unbiased(x + y): differentiable (fused forward + backward row kernels) when grad mode is on."""
+def add_layernorm(x, y, gamma, beta, eps=1e-6, p_drop=0.0):
+    """LayerNorm_unbiased(x + dropout(y, p_drop)): differentiable (fused forward + backward row kernels) when grad mode is
+    on.  p_drop is the TRAINING-mode drop probability of the branch (0: no dropout)."""
+    p_drop = float(p_drop)
+    seed = draw_seed() if p_drop > 0 else 0
     if torch.is_grad_enabled() and any(t.requires_grad for t in (x, y, gamma, beta)):
-        return _AddLnFn.apply(x.contiguous(), y.contiguous(), gamma, beta, eps)
+        return _AddLnFn.apply(x.contiguous(), y.contiguous(), gamma, beta, eps, p_drop, seed)
+    if p_drop > 0:
+        y = dropout_rows(y.detach(), p_drop, seed)
     return add_layernorm_unbiased(x.contiguous(), y.contiguous(), gamma.detach(), beta.detach(), eps)
 
 
@@ -771,7 +878,10 @@ class _EncAttnCoreFn(torch.autograd.Function):
         check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y), ptr(Pd), B * nh, Rp, R, scale, p_drop, seed, stream_ptr()),
               'gvd_enc_softmax_dropout_fwd')
         P = Pd if Pd is not None else Y
-        O = torch.zeros(B, Rp, nh * HP, device=dev, dtype=torch.float32)
+        # (the product writes all nh * HP columns of the R live rows: only the pad rows need zeros)
+        O = torch.empty(B, Rp, nh * HP, device=dev, dtype=torch.float32)
+        if Rp > R:
+            O[:, R:].zero_()
         # O_h = Pd_h V_h   (V consumed in place as a K-strided operand)
         _heads_bgemm(nh, P, 0, Rp, nh * Rp * Rp, Rp * Rp, qkv, vo, W3, Rp * W3, HP, Rp, O, 0, nh * HP, Rp * nh * HP, HP, R, HP,
                      B, w_t=1, what='PV')
@@ -790,7 +900,10 @@ class _EncAttnCoreFn(torch.autograd.Function):
         ko, vo = nh * HP, 2 * nh * HP
         P = Pd if Pd is not None else Y
         dS = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
-        dqkv = torch.zeros_like(qkv)
+        # (the dQ / dK / dV products below write all 3 * nh * HP columns of the R live rows: only the pad rows need zeros)
+        dqkv = torch.empty_like(qkv)
+        if Rp > R:
+            dqkv[:, R:].zero_()
         mb, ms = nh * Rp * Rp, Rp * Rp
         # dPd_h = dO_h V_h^T
         _heads_bgemm(nh, dO, 0, nh * HP, Rp * nh * HP, HP, qkv, vo, W3, Rp * W3, HP, HP, dS, 0, Rp, mb, ms, R, R, B,

@@ -3,6 +3,8 @@ loss = (lm + w_att2*att2 + w_grd*grd + w_cls*cls) / n_replicas, clip_grad_norm_(
 for the fc7 / vis_embed parameters).  Under torch.distributed the gradients are averaged over ranks
 (dist.GradAllReducer) between backward and the clip, which is exactly the reference's DataParallel
 semantics."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -24,6 +26,11 @@ def build_optimizer(model, opt):
                'betas': (opt.optim_alpha, opt.optim_beta)} for p, s in ((rest, 1.0), (fine, 0.1)) if p]
     if opt.optim == 'adam':
         on_gpu = all(p.is_cuda for g in groups for p in g['params'])
+        if on_gpu and os.environ.get('GVD_OWN_ADAM', '1') == '1':
+            # clip + Adam on the library's own multi-tensor kernels (optim.ClipAdam is a torch.optim.Adam: same state,
+            # same state_dict); GVD_OWN_ADAM=0: clip_grad_norm_ + torch's fused Adam
+            from .optim import ClipAdam
+            return ClipAdam(groups)
         return torch.optim.Adam(groups, fused=True) if on_gpu else torch.optim.Adam(groups)
     if opt.optim == 'sgd':
         return torch.optim.SGD(groups, momentum=0.9)
@@ -80,6 +87,11 @@ class Trainer:
             bad, contract = (0, 0) if counts is None else counts.tolist()       # the step's one host read
         if bad or contract:
             self.model.raise_for_status(bad, contract)
-        self._grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), self.opt.grad_clip)
-        self.optimizer.step()
+        if hasattr(self.optimizer, 'step_clipped'):
+            # main.py:265-266 in one go: norm from ordered partials, clip factor on the device, gradients scaled while Adam
+            # reads them (optim.ClipAdam; every parameter of the model is in one of its groups, as in main.py:660-677)
+            self._grad_norm = self.optimizer.step_clipped(self.opt.grad_clip)
+        else:
+            self._grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), self.opt.grad_clip)
+            self.optimizer.step()
         return torch.cat([l.detach() for l in losses])

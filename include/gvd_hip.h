@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 11
+#define GVD_ABI_VERSION 12
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -192,6 +192,18 @@ int gvd_add_layernorm_unbiased_bwd_parts(int64_t rows);
 int gvd_add_layernorm_unbiased_bwd(const float* x, const float* y, const float* dout, const float* gamma, float* ds,
                                    float* partials, int64_t rows, int D, float eps, gvd_stream_t stream);
 
+/* Training form of the ResidualBlock (transformer.py:79-88: `layernorm(x + dropout(layer(x)))`): the branch dropout is
+ * applied while y streams through the row kernel, s = x + y * keep / (1 - p_drop), keep ~ Bernoulli(1 - p_drop) from
+ * Philox4x32-10 (one 128-bit block per 4 consecutive elements of the contiguous [rows, D] tensor, key = seed) - the mask
+ * gvd_dropout_rows draws for the same seed.  The backward regenerates the mask, recomputes the statistics from
+ * (x, y, seed) and writes the two addends' gradients: ds (x) and dy = ds * keep / (1 - p_drop) (the branch).
+ * 0 < p_drop < 1 (without dropout: the functions above). */
+int gvd_add_layernorm_unbiased_drop(const float* x, const float* y, const float* gamma, const float* beta, float* out,
+                                    int64_t rows, int D, float eps, float p_drop, uint64_t seed, gvd_stream_t stream);
+int gvd_add_layernorm_unbiased_drop_bwd(const float* x, const float* y, const float* dout, const float* gamma, float* ds,
+                                        float* dy, float* partials, int64_t rows, int D, float eps, float p_drop,
+                                        uint64_t seed, gvd_stream_t stream);
+
 /* Training path of the encoder's self-attention core (transformer.py:90-117) over MATERIALISED, zero-padded score maps
  * [n_maps, Rp, Rp] (Rp % 32 == 0, Rp <= 2048; rows / columns >= R are padding and are written as 0):
  *   fwd: S <- softmax(scale * S[:, :R]) in place;  Pd <- S * keep / (1 - p_drop)   (Pd may be NULL iff p_drop == 0;
@@ -309,10 +321,11 @@ int gvd_gru_bwd_step(const float* dout, const float* gi, const float* gh, const 
  * ------------------------------------------------------------------------------------------- */
 
 /* Pointwise backward of nn.LSTMCell: from dh, dc_next (nullable) and the saved post-activation gates
- * (i,f,g,o), c_prev, c_new -> d(pre-activation gates) [B,4H] and dc_prev [B,H]. */
-int gvd_lstm_cell_bwd(const float* dh, int64_t lddh, const float* dc_next, int64_t lddc, const float* gates,
-                      int64_t ldg, const float* c_prev, int64_t ldcp, const float* c_new, int64_t ldcn, int B,
-                      int H, float* dgates, int64_t lddg, float* dc_prev, int64_t lddcp, gvd_stream_t stream);
+ * (i,f,g,o), c_prev, c_new -> d(pre-activation gates) [B,4H] and dc_prev [B,H].  dh2 (nullable): a second addend of the
+ * hidden-state gradient (the recurrent contribution of step t+1), added to dh on load. */
+int gvd_lstm_cell_bwd(const float* dh, int64_t lddh, const float* dh2, int64_t lddh2, const float* dc_next, int64_t lddc,
+                      const float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, const float* c_new, int64_t ldcn,
+                      int B, int H, float* dgates, int64_t lddg, float* dc_prev, int64_t lddcp, gvd_stream_t stream);
 
 /* One attention side, one step: streams feats/p_feats once.  alpha = softmax weights of the step [B,N]
  * (from the saved scores), ctx = the side's context [B,H], d_ctx / d_logits = incoming gradients.
@@ -465,6 +478,61 @@ int gvd_masked_lsm_loss(const float* x, int64_t ldx, const float* label, int64_t
  * sim_target i64 [B,K,R]; acc holds 2 + 2*ceil(B*K*R/256) floats (ordered partials, no atomics). */
 int gvd_cls_loss(const float* sim_mat, int64_t stride_b, int64_t stride_cls, int64_t stride_r, const int64_t* sim_target,
                  int B, int D1, int R, int K, float* acc, gvd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused elementwise passes of the training step (csrc/train_fused.hip) and the optimiser (csrc/optim.hip)
+ * ------------------------------------------------------------------------------------------- */
+
+/* y[i] = x[i] * keep[i] / (1 - p_drop) over a contiguous tensor of n floats (n % 4 == 0, 16-byte aligned; y may alias
+ * x): F.dropout in training mode (model.py:312,363,384,393-395; AttModel.py:161) with the Philox mask described above. */
+int gvd_dropout_rows(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, gvd_stream_t stream);
+
+/* Backward of y = dropout(relu(z)) (z = a Linear's output, e.g. model.py:312 `ctx2pool_grd`) from y alone - y > 0 iff
+ * z > 0 and the element was kept: dz[m,n] = y[m,n] > 0 ? dy[m,n] / (1 - p_drop) : 0, and partials
+ * [gvd_relu_dropout_bwd_parts(M), N] = per-workgroup column sums of dz (the bias gradient: the caller adds them over the
+ * first axis, in order).  dy, y, dz: contiguous [M, N], N % 4 == 0.  p_drop = 0: plain ReLU backward + bias gradient. */
+int gvd_relu_dropout_bwd_parts(int64_t M);
+int gvd_relu_dropout_bwd_colsum(const float* dy, const float* y, float* dz, float* partials, int64_t M, int N,
+                                float p_drop, gvd_stream_t stream);
+
+/* out[b, 0:A] = sum_c a[b,c,:], out[b, A:2A] = sum_c r[b,c,:]  (a [B,nca,A], r [B,ncr,A] contiguous; out row stride
+ * ldo): the per-chunk query-gradient partials of gvd_attn_bwd_step's two sides of one BPTT step in one launch. */
+int gvd_sum_chunks_pair(const float* a, int nca, const float* r, int ncr, int B, int A, float* out, int64_t ldo,
+                        gvd_stream_t stream);
+
+/* Up to GVD_OPT_MAX_TENSORS parameter tensors of one optimiser launch, passed by value.  Tensor t owns workgroups
+ * chunk0[t] .. chunk0[t+1]-1 (chunk0[0] = 0; ceil(n[t] / gvd_opt_chunk()) each).  vec_ok[t]: all of the tensor's
+ * pointers are 16-byte aligned (16-byte accesses; scalar otherwise).  p / m / v may be NULL for gvd_sumsq_partials. */
+#define GVD_OPT_MAX_TENSORS 32
+#define GVD_OPT_CHUNK 16384
+typedef struct {
+  float* p[GVD_OPT_MAX_TENSORS]; const float* g[GVD_OPT_MAX_TENSORS];
+  float* m[GVD_OPT_MAX_TENSORS]; float* v[GVD_OPT_MAX_TENSORS];     /* Adam's exp_avg / exp_avg_sq */
+  int64_t n[GVD_OPT_MAX_TENSORS];
+  int chunk0[GVD_OPT_MAX_TENSORS + 1];
+  float lr[GVD_OPT_MAX_TENSORS];
+  float bc1[GVD_OPT_MAX_TENSORS];            /* 1 - beta1^step */
+  float bc2_sqrt[GVD_OPT_MAX_TENSORS];       /* sqrt(1 - beta2^step) */
+  uint8_t vec_ok[GVD_OPT_MAX_TENSORS];
+  int count;
+  int part0;                                 /* gvd_sumsq_partials: index of this launch's first partial */
+} gvd_opt_group;
+
+int gvd_opt_chunk(void);
+
+/* main.py:265 `clip_grad_norm_(model.parameters(), opt.grad_clip)` without touching the gradients:
+ * gvd_sumsq_partials: partials[part0 + w] = sum of squares of workgroup w's chunk of the group's gradients;
+ * gvd_clip_coef (after all groups): out[0] = sqrt(sum of the n partials, added in a fixed order in fp64) = the total
+ * L2 norm, out[1] = min(1, max_norm / (out[0] + 1e-6)) - the factor clip_grad_norm_ would scale every gradient by. */
+int gvd_sumsq_partials(const gvd_opt_group* g, float* partials, gvd_stream_t stream);
+int gvd_clip_coef(const float* partials, int n, float max_norm, float* out, gvd_stream_t stream);
+
+/* main.py:266 `optimizer.step()` for torch.optim.Adam (L2 weight decay, no amsgrad) over the group, reading the clip
+ * factor from clip[1] (clip = gvd_clip_coef's out, or NULL for no clipping):
+ *   g' = clip * g (+ weight_decay * p);  m = beta1 m + (1 - beta1) g';  v = beta2 v + (1 - beta2) g'^2;
+ *   p -= (lr / bc1) * m / (sqrt(v) / bc2_sqrt + eps). */
+int gvd_adam_step(const gvd_opt_group* g, const float* clip, float beta1, float beta2, float eps, float weight_decay,
+                  gvd_stream_t stream);
 
 #ifdef __cplusplus
 }

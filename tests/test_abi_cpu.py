@@ -54,3 +54,47 @@ def test_integration_doc_stub_matches_the_binding():
     body = body[:body.index('\n\n')]
     names = re.findall(r"\('([A-Za-z_0-9]+)',", body)
     assert names == [f[0] for f in hip.AttnSide._fields_], names
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """Every struct of include/gvd_hip.h against its ctypes mirror in hip.py: total size and the offset of every field,
+    measured by a C program compiled from the header itself (gcc; the header is plain C)."""
+    import subprocess
+    pairs = {'gvd_gemm_seg': hip.GemmSeg, 'gvd_gemm_args': hip.GemmArgs, 'gvd_lstm_args': hip.LstmArgs,
+             'gvd_attn_side': hip.AttnSide, 'gvd_beam_step_args': hip.BeamStepArgs, 'gvd_greedy_args': hip.GreedyArgs,
+             'gvd_opt_group': hip.OptGroup}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gvd_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)]).decode().split('\n'):
+        if ln.strip():
+            a, b, c = ln.split()
+            got[(a, b)] = int(c)
+    for cname, cls in pairs.items():
+        assert got[(cname, 'size')] == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+    assert hip.OPT_MAX_TENSORS == 32 and hip.OPT_CHUNK == hip.lib().gvd_opt_chunk()
+
+
+def test_optimizer_launch_packing():
+    """optim.ClipAdam._launches: tensors split into launches of <= 32, chunk prefix sums, running partial offsets."""
+    from gvd_amd.optim import ClipAdam
+    sizes = [5, hip.OPT_CHUNK, hip.OPT_CHUNK + 1, 3 * hip.OPT_CHUNK] * 10          # 40 tensors -> 2 launches
+    items = [{'g': torch.zeros(n), 'n': n} for n in sizes]
+    groups = list(ClipAdam._launches(items))
+    assert [g.count for g in groups] == [32, 8]
+    chunks = [-(-n // hip.OPT_CHUNK) for n in sizes]
+    assert groups[0].part0 == 0 and groups[1].part0 == sum(chunks[:32])
+    for gi, g in enumerate(groups):
+        part = chunks[32 * gi:32 * gi + g.count]
+        assert list(g.chunk0[:g.count + 1]) == [sum(part[:i]) for i in range(g.count + 1)]
+        assert list(g.n[:g.count]) == sizes[32 * gi:32 * gi + g.count]

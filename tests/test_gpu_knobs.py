@@ -21,6 +21,7 @@ SETTINGS = [
     ('beam', dict(GVD_ATTN_GROUPED='0', GVD_BEAM_FUSED='0')),
     ('train', dict(GVD_ENC_TRAIN_MFMA='0', GVD_LN_FUSED_BWD='0', GVD_P5_FUSED_TRAIN='0', GVD_GRU_TRAIN='0')),
     ('train', dict(GVD_ENC_HEADS_MERGED='0', GVD_TRAIN_HEAD_PAD='192')),
+    ('train', dict(GVD_TRAIN_FUSED_ELEMENTWISE='0')),
 ]
 
 

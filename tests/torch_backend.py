@@ -64,7 +64,9 @@ def attention_step(region, temporal, want_separate=False, out=None, cr_out=None,
     return (s, cr, ct) if want_separate else s
 
 
-def lstm_cell_bwd(dh, dc_next, gates, c_prev, c_new, dg_out=None):
+def lstm_cell_bwd(dh, dc_next, gates, c_prev, c_new, dg_out=None, dh2=None):
+    if dh2 is not None:
+        dh = dh + dh2
     i, f, g, o = gates.chunk(4, 1)
     tc = torch.tanh(c_new)
     dc = dh * o * (1 - tc * tc)
@@ -80,7 +82,14 @@ def attn_bwd_chunks(N, B):
     return 3        # the HIP kernel's per-chunk partial slabs; any count checks the caller's reduction
 
 
-def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None, de_out=None, dq_out=None, dw_part=None, dab_part=None):
+def sum_chunks_pair(a, r, out):
+    out[:, :a.shape[2]] = a.sum(1)
+    out[:, a.shape[2]:] = r.sum(1)
+    return out
+
+
+def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None, de_out=None, dq_out=None, dw_part=None, dab_part=None,
+                  dq_part=None):
     feats, p_feats, q, w = side['feats'], side['p_feats'], side['q'], side['w']
     am, pm = side.get('att_mask'), side.get('pnt_mask')
     da = torch.bmm(feats, d_ctx.unsqueeze(2)).squeeze(2)
@@ -101,7 +110,11 @@ def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None, de_out=None, dq_out=No
     dab = de.sum(1)
     if de_out is not None:
         de = de_out.copy_(de)
-    if dq_out is not None:
+    if dq_part is not None:         # left as per-chunk partials (uneven split) for sum_chunks_pair
+        ncq = dq_part.shape[1]
+        wq = torch.arange(1, ncq + 1, dtype=dq.dtype) / (ncq * (ncq + 1) / 2)
+        dq = dq_part.copy_(dq.unsqueeze(1) * wq.view(1, ncq, 1))
+    elif dq_out is not None:
         dq = dq_out.copy_(dq)
     if dw_part is not None:         # partial slabs: split the value unevenly over the chunks
         nc = dw_part.shape[1]

@@ -36,8 +36,10 @@ class ClipAdam(torch.optim.Adam):
                     continue
                 if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_cuda:
                     raise GvdHipError('ClipAdam: dense fp32 GPU parameters only (there is no CPU path)')
-                if not (p.is_contiguous() and p.grad.is_contiguous()):
-                    raise GvdHipError('ClipAdam: parameters and gradients must be contiguous')
+                if not p.is_contiguous():
+                    raise GvdHipError('ClipAdam: parameters must be contiguous')
+                if not p.grad.is_contiguous():       # (autograd lays gradients out like their parameter; be safe)
+                    p.grad = p.grad.contiguous()
                 out.append((p, p.grad, group))
         return out
 

@@ -37,7 +37,7 @@ def stats(d, out, title):
     with open(out, 'w') as fh:
         fh.write('# %s\n\nrocprofv3 --kernel-trace --stats; total GPU kernel time %.3f ms; top kernels:\n\n' % (title, tot / 1e6))
         fh.write('| kernel | calls | total ms | avg us | %% |\n|---|---|---|---|---|\n')
-        for r in rows[:40]:
+        for r in rows[:int(os.environ.get('GVD_STATS_ROWS', '40'))]:
             fh.write('| `%s` | %s | %.3f | %.2f | %.1f |\n' % (r['Name'][:110], r['Calls'], float(r['TotalDurationNs']) / 1e6,
                                                            float(r['AverageNs']) / 1e3, 100 * float(r['TotalDurationNs']) / tot))
     print(open(out).read()[:3000])

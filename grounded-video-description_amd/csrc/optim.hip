@@ -77,7 +77,16 @@ __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float gr
   p -= step * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void adam_step_kernel(const gvd_opt_group g, const float* __restrict__ clip, AdamHyper h) {
+// skip (nullable): n_skip device words; any non-zero word -> the launch leaves every tensor untouched.  Lets the host
+// enqueue the optimiser BEFORE it reads the step's kernel-status / collective flags (train.Trainer): a step whose flags turn
+// out raised has not moved the parameters, and the host-side read no longer drains the queue ahead of the optimiser.
+__global__ __launch_bounds__(256) void adam_step_kernel(const gvd_opt_group g, const float* __restrict__ clip,
+                                                        const int* __restrict__ skip, int n_skip, AdamHyper h) {
+  if (skip) {
+    int any = 0;
+    for (int i = 0; i < n_skip; ++i) any |= skip[i];
+    if (any) return;
+  }
   const int t = find_tensor(g, (int)blockIdx.x);
   const int64_t n = g.n[t];
   const int64_t e0 = (int64_t)((int)blockIdx.x - g.chunk0[t]) * CHUNK;
@@ -144,13 +153,14 @@ extern "C" int gvd_clip_coef(const float* partials, int n, float max_norm, float
   return 0;
 }
 
-extern "C" int gvd_adam_step(const gvd_opt_group* g, const float* clip, float beta1, float beta2, float eps,
-                             float weight_decay, gvd_stream_t stream) {
-  if (check_group(g, true)) return GVD_EINVAL;
+extern "C" int gvd_adam_step(const gvd_opt_group* g, const float* clip, const int* skip, int n_skip, float beta1,
+                             float beta2, float eps, float weight_decay, gvd_stream_t stream) {
+  if (check_group(g, true) || (skip && n_skip <= 0) || n_skip > 64) return GVD_EINVAL;
   for (int t = 0; t < g->count; ++t)
     if (!(g->bc1[t] > 0.f) || !(g->bc2_sqrt[t] > 0.f)) return GVD_EINVAL;
   const AdamHyper h = {beta1, beta2, eps, weight_decay};
-  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)g->chunk0[g->count]), dim3(256), 0, gvd_s(stream), *g, clip, h);
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)g->chunk0[g->count]), dim3(256), 0, gvd_s(stream), *g, clip, skip,
+                     skip ? n_skip : 0, h);
   GVD_CHECK_LAUNCH();
   return 0;
 }

@@ -189,11 +189,12 @@ _SIG = {
     'gvd_opt_chunk': (C.c_int, []),
     'gvd_sumsq_partials': (C.c_int, [C.c_void_p, c_f32p, C.c_void_p]),
     'gvd_clip_coef': (C.c_int, [c_f32p, C.c_int, C.c_float, c_f32p, C.c_void_p]),
-    'gvd_adam_step': (C.c_int, [C.c_void_p, c_f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'gvd_adam_step': (C.c_int, [C.c_void_p, c_f32p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_void_p]),
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 12        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 13        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

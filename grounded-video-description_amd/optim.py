@@ -25,6 +25,7 @@ class ClipAdam(torch.optim.Adam):
         super().__init__(params, foreach=False, fused=False, **kw)
         self._partials = None
         self._clip = None
+        self._stepped = []          # state dicts whose step counter the last step_clipped() advanced (rollback)
 
     # ------------------------------------------------------------------------------------------------------------
     def _live(self):
@@ -86,14 +87,20 @@ class ClipAdam(torch.optim.Adam):
         return self._clip
 
     @torch.no_grad()
-    def step_clipped(self, max_norm=None, closure=None):
+    def step_clipped(self, max_norm=None, closure=None, skip=None):
         """clip_grad_norm_(all parameters of all groups, max_norm) + Adam.step() in one go.  Returns the pre-clip total
-        gradient norm as a device scalar (None without clipping)."""
+        gradient norm as a device scalar (None without clipping).
+        skip: optional device int32 vector; if any element is non-zero WHEN THE KERNELS RUN, the update kernels change
+        nothing (the norm is still computed).  The caller reads the vector afterwards and, if it was raised, calls
+        rollback_step_counts() - so the optimiser can be enqueued before the flags that validate the step are known."""
         if closure is not None:
             raise ValueError('ClipAdam: closures are not supported')
         live = self._live()
+        self._stepped = []
         if not live:
             return None
+        if skip is not None:
+            assert skip.is_cuda and skip.dtype == torch.int32 and skip.is_contiguous() and 0 < skip.numel() <= 64
         clip = self.grad_norm_and_clip(live, max_norm) if max_norm is not None else None
         # one launch list per (betas, eps, weight_decay) combination (the recipe has one: main.py:660-677)
         by_hyper = {}
@@ -106,6 +113,7 @@ class ClipAdam(torch.optim.Adam):
             if st['step'].is_cuda:       # (a state_dict written by torch's fused Adam keeps `step` on the device)
                 st['step'] = st['step'].detach().cpu()
             st['step'] += 1
+            self._stepped.append(st)
             t = float(st['step'])
             b1, b2 = group['betas']
             key = (b1, b2, group['eps'], group['weight_decay'])
@@ -114,8 +122,15 @@ class ClipAdam(torch.optim.Adam):
                 'bc1': 1.0 - b1 ** t, 'bc2_sqrt': math.sqrt(1.0 - b2 ** t)})
         for (b1, b2, eps, wd), items in by_hyper.items():
             for g in self._launches(items):
-                check(lib().gvd_adam_step(C.byref(g), ptr(clip), b1, b2, eps, wd, stream_ptr()), 'gvd_adam_step')
+                check(lib().gvd_adam_step(C.byref(g), ptr(clip), ptr(skip), 0 if skip is None else skip.numel(), b1, b2, eps,
+                                          wd, stream_ptr()), 'gvd_adam_step')
         return None if clip is None else clip[0]
+
+    def rollback_step_counts(self):
+        """Undo the step-counter advance of the last step_clipped() (whose device side was skipped: `skip` was raised)."""
+        for st in self._stepped:
+            st['step'] -= 1
+        self._stepped = []
 
     def step(self, closure=None):
         self.step_clipped(None, closure)

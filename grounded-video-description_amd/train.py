@@ -71,13 +71,18 @@ class Trainer:
         training too: a grid-barrier timeout must not reach the optimizer silently) - MAX-reduced over the ranks together
         with the reducer's rediscovery flag, so that under data parallelism every rank raises (or rebuilds its buckets)
         in the same step instead of leaving its peers blocked in the next collective.  The gradient norm stays a device
-        tensor (clip_grad_norm_ scales on the device)."""
+        tensor (clip_grad_norm_ scales on the device).  With the library's own optimiser the read happens AFTER clip + Adam
+        were enqueued (predicated on the device by the same word, see _finish_step_deferred; GVD_TRAIN_SYNC_FIRST=1 reads
+        first, as torch's optimiser has to)."""
         self.model.zero_grad(set_to_none=True)
         self.reducer.reset()
         losses = self.model(*args, 'MLE')
         loss = combine_losses(losses, self.opt)
         loss.backward()
         counts = self.model.kernel_status_counts() if hasattr(self.model, 'kernel_status_counts') else None
+        own = hasattr(self.optimizer, 'step_clipped')
+        if own and os.environ.get('GVD_TRAIN_SYNC_FIRST', '0') != '1':
+            return self._finish_step_deferred(losses, loss, counts)
         if self.reducer.active:
             st = torch.zeros(2, dtype=torch.int32, device=loss.device) if counts is None else counts.to(torch.int32)
             word = self.reducer.finish(status=st, defer=True).tolist()          # the step's one host read
@@ -87,11 +92,37 @@ class Trainer:
             bad, contract = (0, 0) if counts is None else counts.tolist()       # the step's one host read
         if bad or contract:
             self.model.raise_for_status(bad, contract)
-        if hasattr(self.optimizer, 'step_clipped'):
+        if own:
             # main.py:265-266 in one go: norm from ordered partials, clip factor on the device, gradients scaled while Adam
             # reads them (optim.ClipAdam; every parameter of the model is in one of its groups, as in main.py:660-677)
             self._grad_norm = self.optimizer.step_clipped(self.opt.grad_clip)
         else:
             self._grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), self.opt.grad_clip)
             self.optimizer.step()
+        return torch.cat([l.detach() for l in losses])
+
+    def _finish_step_deferred(self, losses, loss, counts):
+        """Tail of a step with the library's own optimiser: clip + Adam are ENQUEUED first, predicated on the device by the
+        step's status word (kernel-status counts of the persistent kernels; under data parallelism the reducer's
+        MAX-reduced word: rediscovery flag + those counts), and only then does the host read that word - the step's one
+        host read no longer drains the queue in front of the optimiser, whose ~10 launches (and the host work of packing
+        them) used to run with the GPU idle.  A raised word means the device skipped the update: the step counters are
+        rolled back, and the host either raises (kernel error: same step on every rank) or - rediscovery of a late-used
+        parameter - lets the reducer rebuild its buckets and runs the optimiser again, unpredicated."""
+        if self.reducer.active:
+            st = torch.zeros(2, dtype=torch.int32, device=loss.device) if counts is None else counts.to(torch.int32)
+            word = self.reducer.finish(status=st, defer=True)                    # device int32 [3], same on every rank
+        else:
+            word = None if counts is None else counts.to(torch.int32).contiguous()
+        self._grad_norm = self.optimizer.step_clipped(self.opt.grad_clip, skip=word)
+        if word is not None:
+            host = word.tolist()                                                 # the step's one host read
+            flag, bad, contract = (host[0], host[1], host[2]) if self.reducer.active else (0, host[0], host[1])
+            if flag or bad or contract:
+                self.optimizer.rollback_step_counts()
+                if self.reducer.active:
+                    self.reducer.resolve(flag)
+                if bad or contract:
+                    self.model.raise_for_status(bad, contract)
+                self._grad_norm = self.optimizer.step_clipped(self.opt.grad_clip)
         return torch.cat([l.detach() for l in losses])

@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 12
+#define GVD_ABI_VERSION 13
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -530,9 +530,13 @@ int gvd_clip_coef(const float* partials, int n, float max_norm, float* out, gvd_
 /* main.py:266 `optimizer.step()` for torch.optim.Adam (L2 weight decay, no amsgrad) over the group, reading the clip
  * factor from clip[1] (clip = gvd_clip_coef's out, or NULL for no clipping):
  *   g' = clip * g (+ weight_decay * p);  m = beta1 m + (1 - beta1) g';  v = beta2 v + (1 - beta2) g'^2;
- *   p -= (lr / bc1) * m / (sqrt(v) / bc2_sqrt + eps). */
-int gvd_adam_step(const gvd_opt_group* g, const float* clip, float beta1, float beta2, float eps, float weight_decay,
-                  gvd_stream_t stream);
+ *   p -= (lr / bc1) * m / (sqrt(v) / bc2_sqrt + eps).
+ * skip (nullable): n_skip (<= 64) device int32 words read by the kernel; if any is non-zero the launch changes NOTHING.
+ * The caller can so enqueue the step before it has read the flags that decide whether the step is valid (kernel-status
+ * words of the persistent kernels, the data-parallel reducer's MAX-reduced status word) instead of draining the queue
+ * for that read first. */
+int gvd_adam_step(const gvd_opt_group* g, const float* clip, const int* skip, int n_skip, float beta1, float beta2,
+                  float eps, float weight_decay, gvd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -78,6 +78,13 @@ def gemm_dw(dY, X, split=None):
     S = 1
     while tiles * S < 1024 and M % (64 * S) == 0 and M // (2 * S) >= 2048:
         S *= 2
+    if (tiles * S) % 512:
+        # tile counts that do not fill the 512 resident workgroup slots evenly (pool_embed 176, q|k|v 200, wo 72 tiles):
+        # more, shorter workgroups even the occupancy out - measured (profiles/r03/dw_split_sweep_z3.log) q|k|v 3.54 ->
+        # 3.26 ms at S = 16, pool_embed 2.94 -> 2.70 ms at S = 16, wo 1.26 -> 1.16 ms at S = 32; shapes whose tiles x S is a
+        # multiple of 512 (fc7, ff1, ff2, ctx2pool) are flat in S and keep the smaller slab count
+        while tiles * S < 2304 and S < 32 and M % (64 * S) == 0 and M // (2 * S) >= 1024:
+            S *= 2
     if split is not None:
         S = split
     if M % (32 * S) or tiles * S < 256:

@@ -26,13 +26,13 @@ VARIANTS = [('fused+own-adam, read after optimiser', tr_own, True, '0'), ('fused
             ('aten+torch-adam', tr_torch, False, '0')]
 for name, tr, fused, sync_first in VARIANTS:        # warm-up of every variant (allocator, bucket discovery)
     ops.FUSED_TRAIN_ELEMENTWISE = fused
-    os.environ['GVD_TRAIN_SYNC_FIRST'] = sync_first
+    os.environ['GVD_TRAIN_DEFER_STATUS'] = '0' if sync_first == '1' else '1'
     tr.step(a); tr.step(a)
 res = {n: [] for n, _, _, _ in VARIANTS}
 for r in range(rounds):
     for name, tr, fused, sync_first in VARIANTS:
         ops.FUSED_TRAIN_ELEMENTWISE = fused
-        os.environ['GVD_TRAIN_SYNC_FIRST'] = sync_first
+        os.environ['GVD_TRAIN_DEFER_STATUS'] = '0' if sync_first == '1' else '1'
         tr.step(a)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -364,8 +364,12 @@ def masked_lsm_loss(x, label):
 # --------------------------------------------------------------------------------------------------
 def draw_seed():
     """A 62-bit Philox key for one dropout site and step, from torch's CPU generator (reproducible under
-    torch.manual_seed; no device synchronisation)."""
-    return int(torch.randint(0, 2 ** 62, (1,)).item())
+    torch.manual_seed; no device synchronisation).  Under torch.distributed the rank is mixed in, so that replicas seeded
+    alike still draw different masks (nn.DataParallel's replicas draw from their own device generators, main.py:655)."""
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        seed ^= ((torch.distributed.get_rank() + 1) * 0x9E3779B97F4A7C15) & (2 ** 62 - 1)
+    return seed
 
 
 def dropout_(x, p_drop, seed):
@@ -930,7 +934,7 @@ class _EncAttnCoreFn(torch.autograd.Function):
 
 def enc_attn_core(qkv, R, n_heads, scale, p_drop=0.0):
     """See _EncAttnCoreFn.  The dropout seed is drawn from torch's CPU generator (reproducible under torch.manual_seed)."""
-    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0
+    seed = draw_seed() if p_drop > 0 else 0
     return _EncAttnCoreFn.apply(qkv, R, n_heads, scale, float(p_drop), seed)
 
 

@@ -17,7 +17,7 @@ from .hip import OPT_CHUNK, OPT_MAX_TENSORS, GvdHipError, OptGroup, check, lib, 
 
 class ClipAdam(torch.optim.Adam):
     def __init__(self, params, **kw):
-        for k in ('amsgrad', 'maximize', 'capturable', 'differentiable'):
+        for k in ('amsgrad', 'maximize', 'capturable', 'differentiable', 'decoupled_weight_decay'):
             if kw.get(k):
                 raise ValueError('ClipAdam: %s is not supported' % k)
         kw.pop('fused', None)

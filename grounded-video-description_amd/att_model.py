@@ -12,9 +12,11 @@ What runs where (DESIGN.md §2 has the table): the per-token step (two LSTM cell
 attentions, vocabulary head and token rule), every projection of the per-segment preamble (fc7,
 class similarity, pool_embed, the obj_interact encoder incl. its flash-style attention, ctx2pool /
 ctx2att, frame embeddings), the bi-GRU frame encoder, the row kernels (class softmax, layer norms),
-the target / loss reductions and the whole backward pass are hand-written HIP kernels of
-libgvd_hip.so; torch-ROCm library ops remain only for BatchNorm1d, the dropout masks and the fused
-Adam.  There is no CPU path: inputs must live on the GPU.
+the target / loss reductions, the whole backward pass, the dropout of the training path and the
+optimiser step (optim.ClipAdam) are hand-written HIP kernels of libgvd_hip.so; torch-ROCm library ops
+remain for BatchNorm1d, the three few-MB dropout sites (token / visual-word embeddings, h_lang), the
+64-row dX products of the token-loop BPTT and autograd's own gradient accumulation.  There is no CPU
+path: inputs must live on the GPU.
 
 Supported configuration = the reference's README recipe (att_model='topdown', att_input_mode='both',
 region_attn_mode='mix', transfer_mode='cls', t_attn_mode='bigru', seq_per_img=1, enable_BUTD=False).

@@ -53,6 +53,15 @@ CASES = {
     'mle_b8_v1000_ft10_bntrain': dict(mode='MLE', B=8, V=1000, Ft=10, seed=14, profile='trained_like', bn_train=True),
     # reference-default frame count (opts.py:50) at a batch where the two-group GRU kernel and the wide kernels run
     'greedy_b64_v5000_ft480_trained': dict(mode='sample', B=64, V=5000, Ft=480, seed=15, profile='trained_like'),
+    # the reference README's OTHER documented configurations (README.md:83-87,119: "for unsupervised models simply remove
+    # the --obj_interact option"; README.md:111-116: GT inference with --seq_length 40 --eval_obj_grounding_gt):
+    # `opt` = overrides of the constructor options
+    'greedy_b8_v1000_ft10_noenc': dict(mode='sample', B=8, V=1000, Ft=10, seed=16, profile='trained_like',
+                                       opt=dict(obj_interact=False)),
+    'mle_b4_v1000_ft10_noenc': dict(mode='MLE', B=4, V=1000, Ft=10, seed=17, profile='trained_like',
+                                    opt=dict(obj_interact=False)),
+    'grd_b4_v1000_ft10_l40': dict(mode='GRD', B=4, V=1000, Ft=10, seed=18, profile='trained_like',
+                                  opt=dict(seq_length=40)),
 }
 
 # loss weights used for the gradient fixtures (README.md:74-89 recipe + a non-zero w_grd so the
@@ -124,7 +133,8 @@ def build_case(name):
     import importlib
     pkg = importlib.import_module('grounded-video-description_amd')
     spec = CASES[name]
-    opt = pkg.opts.default_opt(vocab_size=spec['V'], t_attn_size=spec['Ft'], num_sampled_frm=spec.get('T', 10))
+    opt = pkg.opts.default_opt(vocab_size=spec['V'], t_attn_size=spec['Ft'], num_sampled_frm=spec.get('T', 10),
+                               **spec.get('opt', {}))
     if spec.get('bn_train'):
         opt.drop_prob_lm = 0.0
     sd = pkg.synth.init_state_dict(opt, seed=spec['seed'], profile=spec['profile'])

@@ -350,7 +350,7 @@ class TopDownModel(nn.Module):
             return ops.add_layernorm(x, y, ln.gamma, ln.beta, ln.eps, p_drop)
         return ln(x + (F.dropout(y, p_drop, True) if p_drop > 0 else y))
 
-    def _obj_interact_train(self, x, scale):
+    def _obj_interact_train(self, x, scale, key_bias=None):
         """Training path of the region encoder (transformer.py:39-117) with every product on the fp32-MFMA GEMM: the
         region axis is zero-padded to Rp (a multiple of 32) for the whole stack, q | k | v come from ONE packed projection
         with heads padded to 192 columns (the packing is an index_copy of the parameters: gradients flow back to wq / wk /
@@ -365,6 +365,8 @@ class TopDownModel(nn.Module):
         idx = torch.cat([torch.arange(sizes[h]) + h * HP for h in range(nh)]).to(x.device)
         idx3 = torch.cat([idx + j * nh * HP for j in range(3)])
         xp = F.pad(x, (0, 0, 0, Rp - R)).reshape(B * Rp, d)
+        # compacted training layout (train_compact.py): per-sample key weights [B, R] (-inf on the pad rows up to Rp)
+        kb = None if key_bias is None else F.pad(key_bias.float(), (0, Rp - R), value=float('-inf')).contiguous()
         for lay in self.obj_interact.encoder.layers:
             sa = lay.selfattn.layer
             p_drop = sa.attention.dropout.p if self.training else 0.0
@@ -372,7 +374,7 @@ class TopDownModel(nn.Module):
                 0, idx3, torch.cat([sa.wq.weight, sa.wk.weight, sa.wv.weight], 0))
             w_o = torch.zeros(d, nh * HP, device=x.device, dtype=torch.float32).index_copy(1, idx, sa.wo.weight)
             qkv = ops.linear(xp, w_qkv).view(B, Rp, 3 * nh * HP)
-            o = ops.enc_attn_core(qkv, R, nh, 1.0 / scale, p_drop)
+            o = ops.enc_attn_core(qkv, R, nh, 1.0 / scale, p_drop, kb)
             att = ops.linear(o.view(B * Rp, nh * HP), w_o)
             ff = lay.feedforward.layer
             xp = self._add_ln(xp, att, lay.selfattn.layernorm, lay.selfattn.dropout.p if self.training else 0.0)
@@ -480,7 +482,7 @@ class TopDownModel(nn.Module):
         p_pool = ops.gemm_nt(pool, self.ctx2pool.weight.detach(), self.ctx2pool.bias.detach(), m_dev=m)
         return ci, pool, p_pool, ci.expand(sim_c).transpose(1, 2)
 
-    def _obj_interact(self, x):
+    def _obj_interact(self, x, key_bias=None):
         """transformer.py:135-190,244-254 as built at model.py:126-135 (6 uneven heads, scale sqrt(d_model),
         no padding mask, custom LayerNorm)."""
         d = x.shape[-1]
@@ -492,7 +494,7 @@ class TopDownModel(nn.Module):
         if (not fused and self.flash_obj_interact and x.is_cuda and os.environ.get('GVD_ENC_TRAIN_MFMA', '1') == '1'
                 and scale == 2.0 ** round(math.log2(scale)) and d % 32 == 0 and -(-d // 6) <= ops.TRAIN_HEAD_PAD
                 and x.shape[1] % 4 == 0 and x.shape[1] >= 4 and -(-x.shape[1] // 32) * 32 <= 2048):
-            return self._obj_interact_train(x, scale)
+            return self._obj_interact_train(x, scale, key_bias)
         for lay in self.obj_interact.encoder.layers:
             sa = lay.selfattn.layer
             # projections on the MFMA GEMM, forward and (K-strided operands) backward
@@ -510,7 +512,10 @@ class TopDownModel(nn.Module):
                 heads = []
                 for qh, kh, vh in zip(q.chunk(6, -1), k.chunk(6, -1), v.chunk(6, -1)):
                     dots = torch.matmul(qh, kh.transpose(1, 2))
-                    w = F.softmax(dots if exact else dots / scale, dim=-1)
+                    dots = dots if exact else dots / scale
+                    if key_bias is not None:          # (compacted training layout on the library path)
+                        dots = dots + key_bias.unsqueeze(1)
+                    w = F.softmax(dots, dim=-1)
                     heads.append(torch.matmul(F.dropout(w, sa.attention.dropout.p, self.training), vh))
             att = self._lin(heads[0] if len(heads) == 1 else torch.cat(heads, -1), sa.wo)
             ff = lay.feedforward.layer
@@ -528,8 +533,10 @@ class TopDownModel(nn.Module):
                 x = self._add_ln(x, y, lay.feedforward.layernorm, lay.feedforward.dropout.p if self.training else 0.0)
         return x
 
-    def _preamble(self, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, allow_compact=False):
-        """Per-segment work shared by the three drivers (model.py:302-409 / 504-568 / 634-698)."""
+    def _preamble(self, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, allow_compact=False, enc_key_bias=None):
+        """Per-segment work shared by the three drivers (model.py:302-409 / 504-568 / 634-698).
+        enc_key_bias: per-sample key weights of the encoder's self-attention, given when the caller handed in the compacted
+        training layout (train_compact.py; the dense training path only)."""
         B, Ft = segs_feat.shape[0], segs_feat.shape[1]
         R = ppls.shape[1]
         D1 = self.detect_size + 1
@@ -612,7 +619,7 @@ class TopDownModel(nn.Module):
         if not pool_done:
             pool = self._drop(F.relu(self.pool_embed[0](pool)))
         if self.has_obj_interact:
-            pool = self._obj_interact(pool)
+            pool = self._obj_interact(pool, enc_key_bias)
         pool = pool.contiguous()
         p_pool = self._lin(pool, self.ctx2pool)                           # MFMA GEMM (model.py:391)
         return self._preamble_finish(segs_feat, sample_idx, fc, pm, pool, p_pool, sim_mat, g_pool)

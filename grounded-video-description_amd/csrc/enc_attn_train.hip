@@ -25,13 +25,20 @@ __device__ __forceinline__ U4 philox4x32_10(uint64_t ctr, uint64_t seed) { retur
 
 constexpr int MAXNV = 8;      // Rp <= 2048
 
+// key_bias (nullable; the compacted training layout, train_compact.py): [n_maps / maps_per_sample, Rp] added to the SCALED
+// scores of a key for every query of the sample's maps - log n on a key that stands for n identical keys, -inf on a key
+// that does not exist, 0 elsewhere.  Applied as s + bias / scale before the kernel's own exp(scale (s - max)), so that a
+// zero bias leaves the row bit-identical to the unbiased kernel.
 template <int NV>
 __global__ __launch_bounds__(256) void enc_softmax_dropout_fwd_kernel(float* __restrict__ S, float* __restrict__ Pd,
                                                                       int64_t nrows, int Rp, int R, float scale_log2e,
-                                                                      uint32_t thresh, float keep_scale, uint64_t seed) {
+                                                                      uint32_t thresh, float keep_scale, uint64_t seed,
+                                                                      const float* __restrict__ key_bias,
+                                                                      int maps_per_sample, float inv_scale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nrows) return;
+  const float* kb = key_bias ? key_bias + (row / Rp / maps_per_sample) * Rp : nullptr;
   float* sr = S + row * Rp;
   float* pr = Pd ? Pd + row * Rp : nullptr;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -55,6 +62,10 @@ __global__ __launch_bounds__(256) void enc_softmax_dropout_fwd_kernel(float* __r
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (c + k >= R) v[i][k] = -INFINITY;
+      else if (kb) {
+        const float b = kb[c + k];
+        if (b != 0.f) v[i][k] = b == -INFINITY ? -INFINITY : fmaf(b, inv_scale, v[i][k]);
+      }
       mx = fmaxf(mx, v[i][k]);
     }
   }
@@ -151,7 +162,8 @@ __global__ __launch_bounds__(256) void enc_softmax_dropout_bwd_kernel(float* __r
   }
 
 extern "C" int gvd_enc_softmax_dropout_fwd(float* S, float* Pd, int64_t n_maps, int Rp, int R, float scale, float p_drop,
-                                           uint64_t seed, gvd_stream_t stream) {
+                                           uint64_t seed, const float* key_bias, int maps_per_sample, gvd_stream_t stream) {
+  if (key_bias && (maps_per_sample <= 0 || (n_maps % maps_per_sample) != 0 || !(scale > 0.f))) return GVD_EINVAL;
   if (!S || n_maps <= 0 || Rp <= 0 || (Rp % 32) != 0 || Rp > 256 * MAXNV || R <= 0 || R > Rp || !(p_drop >= 0.f) ||
       !(p_drop < 1.f) || !gvd_aligned16(S) || (Pd && !gvd_aligned16(Pd)) || (p_drop > 0.f && !Pd))
     return GVD_EINVAL;
@@ -162,7 +174,8 @@ extern "C" int gvd_enc_softmax_dropout_fwd(float* S, float* Pd, int64_t n_maps, 
   float* pd = p_drop > 0.f ? Pd : nullptr;
   const dim3 grid((unsigned)((nrows + 3) / 4));
   GVD_NV_SWITCH(nv, hipLaunchKernelGGL(enc_softmax_dropout_fwd_kernel<NV_>, grid, dim3(256), 0, gvd_s(stream), S, pd, nrows,
-                                       Rp, R, scale * 1.44269504088896340736f, thresh, keep_scale, seed));
+                                       Rp, R, scale * 1.44269504088896340736f, thresh, keep_scale, seed, key_bias,
+                                       maps_per_sample, key_bias ? 1.0f / scale : 0.f));
   GVD_CHECK_LAUNCH();
   return 0;
 }

@@ -125,7 +125,7 @@ _SIG = {
     'gvd_add_layernorm_unbiased_drop_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64,
                                                       C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
     'gvd_enc_softmax_dropout_fwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
-                                              C.c_uint64, C.c_void_p]),
+                                              C.c_uint64, c_f32p, C.c_int, C.c_void_p]),
     'gvd_enc_softmax_dropout_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
                                               C.c_void_p]),
     'gvd_region_feature_rows': (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int64, c_u8p, C.c_int64, C.c_int64,
@@ -194,7 +194,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 13        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 14        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

@@ -873,8 +873,8 @@ class _EncAttnCoreFn(torch.autograd.Function):
     anything finite).  Returns O [B, Rp, nh * HP] (pad rows zero)."""
 
     @staticmethod
-    def forward(ctx, qkv, R, nh, scale, p_drop, seed):
-        require_cuda_f32(qkv)
+    def forward(ctx, qkv, R, nh, scale, p_drop, seed, key_bias=None):
+        require_cuda_f32(qkv, key_bias)
         assert qkv.is_contiguous()
         B, Rp, W3 = qkv.shape
         HP = W3 // (3 * nh)
@@ -886,8 +886,10 @@ class _EncAttnCoreFn(torch.autograd.Function):
         _heads_bgemm(nh, qkv, 0, W3, Rp * W3, HP, qkv, ko, W3, Rp * W3, HP, HP, Y, 0, Rp, nh * Rp * Rp, Rp * Rp, R, R, B,
                      what='QK^T')
         Pd = torch.empty_like(Y) if p_drop > 0 else None
-        check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y), ptr(Pd), B * nh, Rp, R, scale, p_drop, seed, stream_ptr()),
-              'gvd_enc_softmax_dropout_fwd')
+        if key_bias is not None:       # compacted layout: per-sample key weights (train_compact.py)
+            assert key_bias.shape == (B, Rp) and key_bias.is_contiguous()
+        check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y), ptr(Pd), B * nh, Rp, R, scale, p_drop, seed, ptr(key_bias), nh,
+                                                stream_ptr()), 'gvd_enc_softmax_dropout_fwd')
         P = Pd if Pd is not None else Y
         # (the product writes all nh * HP columns of the R live rows: only the pad rows need zeros)
         O = torch.empty(B, Rp, nh * HP, device=dev, dtype=torch.float32)
@@ -929,13 +931,14 @@ class _EncAttnCoreFn(torch.autograd.Function):
                      what='dS K')
         _heads_bgemm(nh, dS, 0, Rp, mb, ms, qkv, 0, W3, Rp * W3, HP, Rp, dqkv, ko, W3, Rp * W3, HP, R, HP, B, a_t=1, w_t=1,
                      what='dS^T Q')
-        return dqkv, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None
 
 
-def enc_attn_core(qkv, R, n_heads, scale, p_drop=0.0):
-    """See _EncAttnCoreFn.  The dropout seed is drawn from torch's CPU generator (reproducible under torch.manual_seed)."""
+def enc_attn_core(qkv, R, n_heads, scale, p_drop=0.0, key_bias=None):
+    """See _EncAttnCoreFn.  The dropout seed is drawn from torch's CPU generator (reproducible under torch.manual_seed).
+    key_bias: optional f32 [B, Rp] added to every query's scaled scores of a key (the compacted training layout)."""
     seed = draw_seed() if p_drop > 0 else 0
-    return _EncAttnCoreFn.apply(qkv, R, n_heads, scale, float(p_drop), seed)
+    return _EncAttnCoreFn.apply(qkv, R, n_heads, scale, float(p_drop), seed, key_bias)
 
 
 def region_feature_rows(g_pool, loc, sim_logits_t, pnt_mask, ln_eps=1e-5, pad_to=1, n_cls=None):

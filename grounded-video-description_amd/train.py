@@ -83,7 +83,7 @@ class Trainer:
         counts = self.model.kernel_status_counts() if hasattr(self.model, 'kernel_status_counts') else None
         own = hasattr(self.optimizer, 'step_clipped')
         if own and os.environ.get('GVD_TRAIN_DEFER_STATUS', '0') == '1':
-            return self._finish_step_deferred(losses, loss, counts)
+            return self._finish_step_deferred(losses, loss, counts, args)
         if self.reducer.active:
             st = torch.zeros(2, dtype=torch.int32, device=loss.device) if counts is None else counts.to(torch.int32)
             word = self.reducer.finish(status=st, defer=True).tolist()          # the step's one host read
@@ -91,6 +91,8 @@ class Trainer:
             bad, contract = word[1], word[2]
         else:
             bad, contract = (0, 0) if counts is None else counts.tolist()       # the step's one host read
+        if contract and not bad and self._drop_train_compaction():
+            return self.step(args)
         if bad or contract:
             self.model.raise_for_status(bad, contract)
         if own:
@@ -102,7 +104,16 @@ class Trainer:
             self.optimizer.step()
         return torch.cat([l.detach() for l in losses])
 
-    def _finish_step_deferred(self, losses, loss, counts):
+    def _drop_train_compaction(self):
+        """A step on the compacted training layout (GVD_TRAIN_COMPACT=1, train_compact.py) met masked proposals that are
+        not zero rows - inputs the reference accepts: compute, don't raise - switch this model to the full row set for
+        good and tell the caller to run the step again.  (The status word is the same on every rank, so every rank does.)"""
+        if os.environ.get('GVD_TRAIN_COMPACT', '0') != '1' or getattr(self.model, '_train_compact_off', False):
+            return False
+        self.model._train_compact_off = True
+        return True
+
+    def _finish_step_deferred(self, losses, loss, counts, args):
         """Tail of a step with the library's own optimiser: clip + Adam are ENQUEUED first, predicated on the device by the
         step's status word (kernel-status counts of the persistent kernels; under data parallelism the reducer's
         MAX-reduced word: rediscovery flag + those counts), and only then does the host read that word - the step's one
@@ -123,6 +134,8 @@ class Trainer:
                 self.optimizer.rollback_step_counts()
                 if self.reducer.active:
                     self.reducer.resolve(flag)
+                if contract and not bad and self._drop_train_compaction():
+                    return self.step(args)
                 if bad or contract:
                     self.model.raise_for_status(bad, contract)
                 self._grad_norm = self.optimizer.step_clipped(self.opt.grad_clip)

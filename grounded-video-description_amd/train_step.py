@@ -5,10 +5,12 @@ host synchronisation inside the loop: the early `break` of model.py:425 is resol
 from the ground-truth sequence), box targets for all steps come from one kernel each, and the losses
 are fused log-softmax reductions.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, train_compact
 
 
 def _seq_cnt(seq, L):
@@ -36,7 +38,23 @@ def forward_train(model, segs_feat, input_seq, gt_seq, ppls, gt_boxes, mask_boxe
     seq = gt_seq[:, 0, :]
     seq = torch.cat([torch.zeros(B, 1, dtype=seq.dtype, device=dev), seq], 1)            # model.py:285-286
     input_seq = input_seq.view(-1, input_seq.shape[2], input_seq.shape[3])
-    pre = model._preamble(segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask)
+    key_bias = None
+    if (not eval_obj_ground and torch.is_grad_enabled() and os.environ.get('GVD_TRAIN_COMPACT', '0') == '1'
+            and not getattr(model, '_train_compact_off', False) and frm_mask.dim() == 3):
+        # masked-proposal compaction of the training step (train_compact.py; OFF by default: see its status note): the
+        # step runs on [valid rows | one weighted representative masked row | pads] per segment.  The premise - masked
+        # rows are zero rows, dataloader_anet.py:343-344 - is checked on the device; train.Trainer re-runs a step whose
+        # inputs break it on the full row set
+        pm0 = (pnt_mask if pnt_mask.dtype == torch.uint8 else pnt_mask.to(torch.uint8)).contiguous()
+        c = train_compact.compact_regions(ppls, ppls_feat, pm0, frm_mask)
+        if c is not None:
+            flag = torch.zeros(1, dtype=torch.int32, device=pm0.device)
+            ops.check_masked_rows_zero(ppls_feat.contiguous(), pm0, flag)
+            ops.check_masked_rows_zero(ppls.contiguous(), pm0, flag)
+            model.__dict__.setdefault('_contract_flags', []).append(flag)
+            ppls, ppls_feat, pnt_mask, frm_mask, key_bias = c['ppls'], c['ppls_feat'], c['pnt_mask'], c['frm_mask'], c['key_bias']
+            R = c['Rc']
+    pre = model._preamble(segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, enc_key_bias=key_bias)
     pm = pre['pnt_mask']
     fm = frm_mask if frm_mask.dtype == torch.uint8 else frm_mask.to(torch.uint8)
     mb = mask_boxes if mask_boxes.dtype == torch.uint8 else mask_boxes.to(torch.uint8)
@@ -84,6 +102,6 @@ def forward_train(model, segs_feat, input_seq, gt_seq, ppls, gt_boxes, mask_boxe
     lm_loss = -(logp_t * tmask.to(logp_t.dtype)).sum() / tmask.sum()
     att2_loss = ops.masked_lsm(att2_weights, roi_labels)
     ground_loss = ops.masked_lsm(ground, roi_labels)
-    if len(model._flags()) > 4096:      # a caller that never checks must not grow the list without bound
-        model.check_kernel_status()
+    if len(model._flags()) + len(model.__dict__.get('_contract_flags', [])) > 4096:
+        model.check_kernel_status()      # a caller that never checks must not grow the lists without bound
     return lm_loss.unsqueeze(0), att2_loss.unsqueeze(0), ground_loss.unsqueeze(0), cls_loss.unsqueeze(0)

@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 13
+#define GVD_ABI_VERSION 14
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -209,8 +209,11 @@ int gvd_add_layernorm_unbiased_drop_bwd(const float* x, const float* y, const fl
  *   fwd: S <- softmax(scale * S[:, :R]) in place;  Pd <- S * keep / (1 - p_drop)   (Pd may be NULL iff p_drop == 0;
  *        keep ~ Bernoulli(1 - p_drop) from Philox4x32-10 keyed by `seed`);
  *   bwd: dP <- scale * Y * (dY - sum_j dY_j Y_j),  dY = dP * [Pd != 0] / (1 - p_drop)   (in place over dP). */
+/* key_bias (nullable): f32 [n_maps / maps_per_sample, Rp] added to the scaled scores of a key for every query of the
+ * sample's maps (log n: the key stands for n identical keys; -inf: the key does not exist; 0: plain) - the compacted
+ * training layout (train_compact.py) that drops the masked proposals the reference computes (model.py:311-391). */
 int gvd_enc_softmax_dropout_fwd(float* S, float* Pd, int64_t n_maps, int Rp, int R, float scale, float p_drop,
-                                uint64_t seed, gvd_stream_t stream);
+                                uint64_t seed, const float* key_bias, int maps_per_sample, gvd_stream_t stream);
 int gvd_enc_softmax_dropout_bwd(float* dP, const float* Pd, const float* Y, int64_t n_maps, int Rp, int R, float scale,
                                 float p_drop, gvd_stream_t stream);
 

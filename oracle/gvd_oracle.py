@@ -116,8 +116,10 @@ def custom_layernorm(x, gamma, beta, eps=1e-6):
     return gamma * (x - mean) / (std + eps) + beta
 
 
-def obj_interact(x, W, n_layers=2, n_heads=6):
-    """transformer.py:135-190,244-254 as configured at model.py:126-135 (no mask, no pos-enc, eval)."""
+def obj_interact(x, W, n_layers=2, n_heads=6, key_bias=None):
+    """transformer.py:135-190,244-254 as configured at model.py:126-135 (no mask, no pos-enc, eval).
+    key_bias (NOT in the reference; [B,R] added to every query's scores of a key: log n = the key stands for n identical
+    keys, -inf = the key does not exist): lets tests/test_train_compact_cpu.py restate the compacted training layout."""
     d_model = x.shape[-1]
     scale = math.sqrt(d_model)   # Attention(d_key=d_model): transformer.py:92,112
     for l in range(n_layers):
@@ -127,8 +129,10 @@ def obj_interact(x, W, n_layers=2, n_heads=6):
         v = F.linear(x, W[p + 'selfattn.layer.wv.weight'])
         heads = []
         for qh, kh, vh in zip(q.chunk(n_heads, -1), k.chunk(n_heads, -1), v.chunk(n_heads, -1)):
-            dots = torch.matmul(qh, kh.transpose(1, 2))
-            heads.append(torch.matmul(F.softmax(dots / scale, dim=-1), vh))
+            dots = torch.matmul(qh, kh.transpose(1, 2)) / scale
+            if key_bias is not None:
+                dots = dots + key_bias.unsqueeze(1)
+            heads.append(torch.matmul(F.softmax(dots, dim=-1), vh))
         att = F.linear(torch.cat(heads, -1), W[p + 'selfattn.layer.wo.weight'])
         x = custom_layernorm(x + att, W[p + 'selfattn.layernorm.gamma'], W[p + 'selfattn.layernorm.beta'])
         ff = linear(F.relu(linear(x, W, p + 'feedforward.layer.linear1')), W, p + 'feedforward.layer.linear2')
@@ -207,7 +211,8 @@ def frame_mask_for_step(mask_boxes_t, frm_mask, pnt_mask):
 # --------------------------------------------------------------------------------------------------
 # per-segment preamble  (model.py:302-409 / 504-568 / 634-698 — identical in the three drivers)
 # --------------------------------------------------------------------------------------------------
-def preamble(W, opt, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, fast_gru=True, bn_train=False):
+def preamble(W, opt, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, fast_gru=True, bn_train=False,
+             enc_key_bias=None):
     B, Ft = segs_feat.shape[0], segs_feat.shape[1]
     T = opt.num_sampled_frm
     D1 = opt.detect_size + 1
@@ -235,7 +240,7 @@ def preamble(W, opt, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, fast
     fc = F.relu(linear(fc, W, 'fc_embed.0'))                          # model.py:383
     pool = F.relu(linear(pool, W, 'pool_embed.0'))                    # model.py:384
     if opt.obj_interact:
-        pool = obj_interact(pool, W)                                  # model.py:387-388
+        pool = obj_interact(pool, W, key_bias=enc_key_bias)           # model.py:387-388
     p_pool = linear(pool, W, 'ctx2pool')                              # model.py:391
     # frame-wise context (model.py:393-405)
     c = torch.cat([F.relu(linear(segs_feat[:, :, :2048], W, 'att_embed.0.0')),

@@ -98,3 +98,43 @@ def test_optimizer_launch_packing():
         part = chunks[32 * gi:32 * gi + g.count]
         assert list(g.chunk0[:g.count + 1]) == [sum(part[:i]) for i in range(g.count + 1)]
         assert list(g.n[:g.count]) == sizes[32 * gi:32 * gi + g.count]
+
+
+def test_function_signatures_match_the_header():
+    """Every prototype of include/gvd_hip.h against the ctypes signature in hip._SIG: parameter count and, per parameter,
+    the kind (pointer / int / int64 / uint64 / float / size_t) - a swapped or missing argument in the binding would
+    otherwise only show up on the GPU box."""
+    src = open(os.path.join(ROOT, 'include', 'gvd_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    protos = re.findall(r'\n\s*([A-Za-z_][A-Za-z_0-9 \*]*?)\s*\b(gvd_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;', src)
+    assert len(protos) >= 50
+
+    def kind(ctype):
+        t = ctype.strip()
+        if t.endswith('*') or t in ('gvd_stream_t',):
+            return 'ptr'
+        return {'int': 'int', 'int64_t': 'i64', 'uint64_t': 'u64', 'float': 'float', 'size_t': 'u64', 'void': 'void',
+                'const char*': 'ptr'}[t.replace('const ', '')]       # (size_t and uint64_t are one ctypes class here)
+
+    def ckind(ct):
+        if ct is None:
+            return 'void'
+        if ct in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(ct, 'contents') or (isinstance(ct, type) and issubclass(ct, ctypes._Pointer)):
+            return 'ptr'
+        return {ctypes.c_int: 'int', ctypes.c_int64: 'i64', ctypes.c_uint64: 'u64', ctypes.c_float: 'float',
+                ctypes.c_size_t: 'u64'}[ct]
+    seen = set()
+    for ret, name, params in protos:
+        seen.add(name)
+        res, args = hip._SIG[name]
+        plist = [p.strip() for p in params.split(',')] if params.strip() not in ('', 'void') else []
+        want = []
+        for p in plist:
+            m = re.match(r'^(.*?)([A-Za-z_][A-Za-z_0-9]*)$', p)          # type, then the parameter name
+            want.append(kind(m.group(1)))
+        got = [ckind(a) for a in args]
+        assert got == want, '%s: binding %s vs header %s' % (name, got, want)
+        rk = kind(ret)
+        # (c_size_t and c_int64 results are declared as such; a `const char*` result is a pointer)
+        assert ckind(res) == rk, '%s: result %s vs header %s' % (name, ckind(res), rk)
+    assert seen == set(hip.EXPORTS)

@@ -756,7 +756,7 @@ def test_enc_softmax_dropout_row_kernels(n_maps, R, Rp, p):
     S0 = (torch.randn(n_maps, Rp, Rp, generator=g) * 40).cuda()
     Y = S0.clone()
     Pd = torch.full_like(Y, float('nan')) if p > 0 else None
-    check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y), ptr(Pd), n_maps, Rp, R, scale, p, 1234567, stream_ptr()), 'fwd')
+    check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y), ptr(Pd), n_maps, Rp, R, scale, p, 1234567, None, 0, stream_ptr()), 'fwd')
     want = torch.softmax(S0[:, :R, :R].double() * scale, -1)
     assert float((Y[:, :R, :R].double() - want).abs().max()) < 2e-7
     assert not Y[:, R:].any() and not Y[:, :, R:].any()
@@ -768,9 +768,9 @@ def test_enc_softmax_dropout_row_kernels(n_maps, R, Rp, p):
         assert torch.equal(Pd[:, :R, :R][keep], (Y[:, :R, :R] * (1.0 / (1.0 - p)))[keep])
         # another seed: another mask; same seed: same mask
         Y2, Pd2 = S0.clone(), torch.empty_like(S0)
-        check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y2), ptr(Pd2), n_maps, Rp, R, scale, p, 1234567, stream_ptr()), 'fwd')
+        check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y2), ptr(Pd2), n_maps, Rp, R, scale, p, 1234567, None, 0, stream_ptr()), 'fwd')
         assert torch.equal(Pd2, Pd)
-        check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y2.copy_(S0)), ptr(Pd2), n_maps, Rp, R, scale, p, 7654321, stream_ptr()), 'fwd')
+        check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y2.copy_(S0)), ptr(Pd2), n_maps, Rp, R, scale, p, 7654321, None, 0, stream_ptr()), 'fwd')
         assert not torch.equal(Pd2, Pd)
         # rows are decorrelated (no repeated pattern across rows / maps)
         k0 = keep.reshape(-1, R).float()
@@ -786,6 +786,30 @@ def test_enc_softmax_dropout_row_kernels(n_maps, R, Rp, p):
     ref = scale * y * (dY - (dY * y).sum(-1, keepdim=True))
     assert float((dS[:, :R, :R].double() - ref).abs().max()) < 1e-6
     assert not dS[:, R:].any() and not dS[:, :, R:].any()
+
+
+def test_enc_softmax_key_bias_operand():
+    """The per-sample key bias of the training softmax row kernel (compacted training layout, train_compact.py): 0 leaves a
+    row bit-identical, log n weights a key n-fold, -inf removes it; maps of one sample share its bias row."""
+    from gvd_amd.hip import check, lib, ptr, stream_ptr
+    g = _g(77)
+    B, nh, Rp = 3, 2, 64
+    scale = 1.0 / 32
+    S0 = (torch.randn(B * nh, Rp, Rp, generator=g) * 40).cuda()
+    plain = S0.clone()
+    check(lib().gvd_enc_softmax_dropout_fwd(ptr(plain), None, B * nh, Rp, Rp, scale, 0.0, 0, None, 0, stream_ptr()), 'fwd')
+    kb = torch.zeros(B, Rp)
+    y0 = S0.clone()
+    check(lib().gvd_enc_softmax_dropout_fwd(ptr(y0), None, B * nh, Rp, Rp, scale, 0.0, 0, ptr(kb.cuda()), nh, stream_ptr()), 'fwd')
+    assert torch.equal(y0, plain)                                            # zero bias: the same bits
+    kb[0, 10] = float(np.log(7.0)); kb[0, 40:] = float('-inf')               # sample 0: key 10 counts 7-fold, keys 40.. absent
+    kb[2, 0] = float(np.log(100.0)); kb[2, 1:5] = float('-inf')
+    y = S0.clone()
+    check(lib().gvd_enc_softmax_dropout_fwd(ptr(y), None, B * nh, Rp, Rp, scale, 0.0, 0, ptr(kb.cuda()), nh, stream_ptr()), 'fwd')
+    want = torch.softmax(S0.double().view(B, nh, Rp, Rp) * scale + kb.double().cuda().view(B, 1, 1, Rp), -1).view(B * nh, Rp, Rp)
+    assert float((y.double() - want).abs().max()) < 2e-7
+    assert not y.view(B, nh, Rp, Rp)[0, :, :, 40:].any() and not y.view(B, nh, Rp, Rp)[2, :, :, 1:5].any()
+    assert torch.equal(y.view(B, nh, Rp, Rp)[1], plain.view(B, nh, Rp, Rp)[1])      # sample 1 untouched
 
 
 @pytest.mark.parametrize('B,R', [(2, 1000), (3, 40)])

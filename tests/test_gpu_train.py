@@ -176,7 +176,7 @@ def test_train_compaction_matches_full_rows(golden_dir, monkeypatch):
     for n, a in res['0'][1].items():
         if float(a.norm()) > 1e-6 * gmax:
             err = float((a - res['1'][1][n]).norm() / a.norm())
-            assert err < 1e-3, (n, err)          # measured: 1.1e-5 worst (ctx2att.bias); a ReLU boundary flip costs ~1e-3
+            assert err < PROJ_TOL, (n, err)      # measured: 1.1e-5 worst (ctx2att.bias); one ReLU boundary flip costs ~1e-3
     from gvd_amd import train_compact
     c = train_compact.compact_regions(args[4], args[7], args[10], args[8])
     assert c is not None and c['Rc'] < args[4].shape[1]       # the case really runs compacted

@@ -19,10 +19,19 @@ sits in), same parameter gradients (the representative key receives the sum of t
 query feeds only masked places).  At the synthetic 20 % masking rate Rc = 832 of R = 1000: 17 % fewer rows in every row-wise
 GEMM of the step and 31 % smaller attention maps.
 
+TRAIN-MODE CAVEAT (why this stays an opt-in even once validated): with dropout live, the reference draws an independent mask
+for each of the n masked rows (ctx2pool_grd / loc_fc / pool_embed dropout, the encoder's branch dropouts), so they are no
+longer identical rows; here ONE draw stands for all n (weighted n-fold as a key).  In expectation over the masks the junk
+keys' attention mass differs in second order (n independent noisy keys vs one noisy key counted n times).  That changes the
+noise the padding rows inject into the valid rows' self-attention, not any signal, and eval-mode arithmetic - the only mode in
+which two implementations can be compared at all - is identical; but it is a different stochastic regulariser than the
+reference's, and a training run that must reproduce the reference's statistics to the letter keeps the full row set.
+
 STATUS: the index construction and the loss / gradient equivalence are pinned on the CPU against the oracle
 (tests/test_train_compact_cpu.py); the HIP side (key-bias operand of the encoder's softmax row kernel, the plumbing through
-ops.enc_attn_core) could not be run on a GPU inside round 3's budget, so the path is OFF by default and
-tools/train_compact_check.py is the first thing to run on a device.
+ops.enc_attn_core) ran on a GPU for one reference case only (mle_b4_*: losses equal, worst gradient 1.1e-5 off the full-row run;
+tests/test_gpu_train.py::test_train_compaction_matches_full_rows) inside round 3's budget, so the path is OFF by default;
+tools/sessions/gpu_round4a_compact.sh is what remains to run.
 """
 import math
 

@@ -272,9 +272,9 @@ def section_train_b64(dev, n_steps=4):
 def _train_compacted(model, tr, a, sd, gpath, n_steps):
     """The same step on the compacted training layout (GVD_TRAIN_COMPACT=1, grounded-video-description_amd/train_compact.py:
     per segment its valid proposals + ONE weighted representative of the masked ones the loader zeroed; same losses and
-    gradients - tests/test_train_compact_cpu.py, test_train_compaction_matches_full_rows).  Not yet the default path (its
-    larger cases have not been through the GPU suite), so it is reported NEXT TO the configs[2] number, never as it; a
-    failure here is recorded, it does not touch the line."""
+    gradients in eval-mode arithmetic - tests/test_train_compact_cpu.py, test_train_compaction_matches_full_rows).  An opt-in
+    (its larger cases have not been through the GPU suite; with live dropout one draw stands for the n masked rows), so it
+    is reported NEXT TO the configs[2] number, never as it; a failure here is recorded, it does not touch the line."""
     import numpy as np
     old = os.environ.get('GVD_TRAIN_COMPACT')
     os.environ['GVD_TRAIN_COMPACT'] = '1'

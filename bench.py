@@ -263,57 +263,32 @@ def section_train_b64(dev, n_steps=4):
     dt = (time.perf_counter() - t0) / n_steps
     out.update(ms_per_step=round(1e3 * dt, 3), segments_per_s=round(64 / dt, 1), steps_timed=n_steps)
     out['roofline'] = _roofline_mfma(hip, lambda: tr.step(a), 1, 'forward, dX and dW (K-strided) products of the step')
-    out['compacted_rows'] = _train_compacted(model, tr, a, sd, gpath, n_steps)
     del tr, model
     torch.cuda.empty_cache()
+    out['compacted_rows'] = _train_compacted(n_steps)
     return out
 
 
-def _train_compacted(model, tr, a, sd, gpath, n_steps):
+def _train_compacted(n_steps):
     """The same step on the compacted training layout (GVD_TRAIN_COMPACT=1, grounded-video-description_amd/train_compact.py:
     per segment its valid proposals + ONE weighted representative of the masked ones the loader zeroed; same losses and
     gradients in eval-mode arithmetic - tests/test_train_compact_cpu.py, test_train_compaction_matches_full_rows).  An opt-in
     (its larger cases have not been through the GPU suite; with live dropout one draw stands for the n masked rows), so it
-    is reported NEXT TO the configs[2] number, never as it; a failure here is recorded, it does not touch the line."""
-    import numpy as np
-    old = os.environ.get('GVD_TRAIN_COMPACT')
-    os.environ['GVD_TRAIN_COMPACT'] = '1'
-    out = {}
+    is reported NEXT TO the configs[2] number, never as it, and measured by tools/train_compact_bench.py in a SUBPROCESS:
+    whatever happens there is recorded and cannot touch this process or its line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                        'TORCHELASTIC_RUN_ID', 'GVD_TRAIN_COMPACT')}
     try:
-        if os.path.exists(gpath):
-            # parity of the compacted layout: the reference case's losses in eval-mode arithmetic (grad mode on: the
-            # compaction is a training-path feature), on the reference's own weights
-            state = {k: v.detach().clone() for k, v in model.state_dict().items()}
-            model.load_state_dict(sd)
-            model.eval()
-            got = torch.cat([l.detach().reshape(1) for l in model(*a, 'MLE')]).cpu().numpy()
-            want = np.load(gpath)['losses']
-            out['parity'] = {'max_abs_loss_diff': float(np.abs(got - want).max()),
-                             'within_1e-4': bool(np.abs(got - want).max() <= 1e-4)}
-            model.load_state_dict(state)
-            model.train()
-            model.zero_grad(set_to_none=True)
-        for _ in range(2):
-            tr.step(a)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n_steps):
-            tr.step(a)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n_steps
-        from gvd_amd import train_compact
-        c = train_compact.compact_regions(a[4], a[7], a[10], a[8])      # ppls, ppls_feat, pnt_mask, frm_mask
-        out.update(ms_per_step=round(1e3 * dt, 3), segments_per_s=round(64 / dt, 1), steps_timed=n_steps,
-                   rows_per_segment=None if c is None else int(c['Rc']), rows_full=int(a[4].shape[1]),
-                   fell_back_to_full_rows=bool(getattr(model, '_train_compact_off', False)))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'train_compact_bench.py'), str(n_steps)], env=env,
+                           cwd=ROOT, capture_output=True, text=True, timeout=300)
+        for line in r.stdout.splitlines():
+            if line.startswith('COMPACT_JSON '):
+                return json.loads(line[len('COMPACT_JSON '):])
+        return {'error': 'rc %d: %s' % (r.returncode, (r.stderr or r.stdout)[-300:])}
     except Exception as e:          # noqa: BLE001 - a side measurement must not take the benchmark line down
-        out['error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
-    finally:
-        if old is None:
-            os.environ.pop('GVD_TRAIN_COMPACT', None)
-        else:
-            os.environ['GVD_TRAIN_COMPACT'] = old
-    return out
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
 
 
 def section_beam5_t20_b64(dev, n_steps=3):

@@ -159,7 +159,6 @@ class TopDownModel(nn.Module):
                                           nn.Dropout(p))
         self._knowledge_transfer(opt)
         self.core = _Core(opt)
-        self.flash_obj_interact = os.environ.get('GVD_FLASH', '1') == '1'   # inference: fused attention kernel
         self._validate_dims(opt)
 
     def _validate_dims(self, opt):
@@ -228,20 +227,7 @@ class TopDownModel(nn.Module):
             return self._forward_train(segs_feat, seq, gt_seq, ppls, gt_boxes, mask_boxes, num, ppls_feat,
                                        frm_mask, sample_idx, pnt_mask, True)
         if opt == 'sample':
-            seq, lps, att2, sim = self._sample(segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, eval_opt)
-            counts = self.kernel_status_counts()
-            if counts is not None:
-                bad, contract = counts.tolist()     # one device->host read per call
-                if contract:
-                    # masked proposals (pnt_mask = 1) with NON-zero features / boxes: inputs the reference accepts
-                    # (model.py:311-391 computes every row) but for which the compacted preamble's premise - all masked rows
-                    # of a segment are the same zero row, dataloader_anet.py:343-344 - does not hold.  Compute, don't
-                    # raise: the batch is decoded again through the dense preamble.
-                    seq, lps, att2, sim = self._sample(segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask,
-                                                       dict(eval_opt, dense_preamble=True))
-                    c2 = self.kernel_status_counts()
-                    bad = 0 if c2 is None else c2.tolist()[0]
-                self.raise_for_status(bad, 0)       # fail loudly: a timed-out persistent kernel must not yield captions
+            seq, lps, att2, sim = self._sample_checked(segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, eval_opt)
             return seq, att2, sim
         raise ValueError(opt)
 
@@ -263,6 +249,32 @@ class TopDownModel(nn.Module):
         return torch.stack([torch.stack([f.reshape(-1).ne(0).sum() for f in fl]).sum() if fl else
                             torch.zeros((), dtype=torch.int64, device=dev) for fl in (flags, contract)])
 
+    def _sample_checked(self, segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, eval_opt):
+        """_sample + the status check of its launches (one device->host read per call), with the two conditions a
+        reference user never sees COMPUTED instead of raised:
+          * masked proposals (pnt_mask = 1) with NON-zero features / boxes - inputs the reference accepts (model.py:311-391
+            computes every row) but for which the compacted preamble's premise (all masked rows of a segment are the same
+            zero row, dataloader_anet.py:343-344) does not hold: the batch is decoded again through the dense preamble;
+          * a grid-barrier timeout of a persistent kernel (workgroups not co-resident, e.g. a shared GPU): the persistent
+            kernels are switched off for the process (ops.disable_persistent_kernels) and the batch is decoded again on the
+            kernel-per-op decoder / the cooperative GRU launch.
+        Only a failure of the retry raises."""
+        out = self._sample(segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, eval_opt)
+        counts = self.kernel_status_counts()
+        if counts is None:
+            return out
+        bad, contract = counts.tolist()             # one device->host read per call
+        if not bad and not contract:
+            return out
+        if bad:
+            ops.disable_persistent_kernels(bad)
+        opt2 = dict(eval_opt, dense_preamble=True) if contract else eval_opt
+        out = self._sample(segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, opt2)
+        c2 = self.kernel_status_counts()
+        bad2, contract2 = (0, 0) if c2 is None else c2.tolist()
+        self.raise_for_status(bad2, contract2 if contract else 0)
+        return out
+
     @staticmethod
     def raise_for_status(bad, contract):
         if contract:
@@ -272,8 +284,9 @@ class TopDownModel(nn.Module):
                               "{'dense_preamble': True} or set GVD_COMPACT=0" % contract)
         if bad:
             raise GvdHipError('%d persistent-kernel launch(es) hit a grid-barrier timeout (workgroups not co-resident, '
-                              'e.g. a shared GPU): results are invalid.  Re-run, or set GVD_PERSISTENT=0 / '
-                              'GVD_GRU_BARRIER=cg' % bad)
+                              'e.g. a shared GPU): results are invalid.  forward() / Trainer.step() / sample_pipelined() '
+                              'recompute such calls without the persistent kernels by themselves; direct callers of '
+                              '_sample call ops.disable_persistent_kernels() and run again' % bad)
 
     def check_kernel_status(self):
         """The persistent kernels (greedy decoder B <= 4, bi-GRU) bound their grid-barrier spins and latch a flag
@@ -292,18 +305,10 @@ class TopDownModel(nn.Module):
 
     def _fused_drop_p(self, p=None):
         """Drop probability to hand to a fused Linear + ReLU + dropout site (ops.linear(..., p_drop)): the module's
-        probability in training mode, 0 in eval mode - or when the fused elementwise kernels are switched off
-        (GVD_TRAIN_FUSED_ELEMENTWISE=0), in which case the caller applies F.dropout itself via _drop_after."""
-        if not self.training or not ops.FUSED_TRAIN_ELEMENTWISE:
+        probability in training mode, 0 in eval mode."""
+        if not self.training:
             return 0.0
         return float(self.drop_prob_lm if p is None else p)
-
-    def _drop_after(self, x, p=None):
-        """F.dropout after a site that takes its dropout fused when it can (see _fused_drop_p): the ATen pass only when the
-        fused form is switched off."""
-        if self.training and not ops.FUSED_TRAIN_ELEMENTWISE:
-            return F.dropout(x, self.drop_prob_lm if p is None else p, True)
-        return x
 
     def _lin_k32(self, x, lin, act=0, x_padded=False, p_drop=0.0):
         """nn.Linear (+ReLU) whose input width is not a multiple of the GEMM's 32-deep k tile (fc_embed: K = 3122,
@@ -344,22 +349,20 @@ class TopDownModel(nn.Module):
         """ResidualBlock tail (transformer.py:79-88): dropout(p_drop, already resolved for the mode) on the branch y, add +
         the custom LayerNorm: one fused row kernel forward and one backward for the d_model the kernels are built for; the
         module's elementwise form otherwise."""
-        if x.shape[-1] == 1024 and x.is_cuda and os.environ.get('GVD_LN_FUSED_BWD', '1') == '1':
-            if p_drop > 0 and not ops.FUSED_TRAIN_ELEMENTWISE:
-                y, p_drop = F.dropout(y, p_drop, True), 0.0
+        if x.shape[-1] == 1024 and x.is_cuda:
             return ops.add_layernorm(x, y, ln.gamma, ln.beta, ln.eps, p_drop)
         return ln(x + (F.dropout(y, p_drop, True) if p_drop > 0 else y))
 
     def _obj_interact_train(self, x, scale, key_bias=None):
         """Training path of the region encoder (transformer.py:39-117) with every product on the fp32-MFMA GEMM: the
         region axis is zero-padded to Rp (a multiple of 32) for the whole stack, q | k | v come from ONE packed projection
-        with heads padded to 192 columns (the packing is an index_copy of the parameters: gradients flow back to wq / wk /
-        wv / wo), the attention core is ops.enc_attn_core (materialised maps, fused softmax + dropout row kernels) and the
-        residual LayerNorms are fused row kernels forward and backward.  Pad rows never reach the loss (their gradients
+        with every head in its own 176-column slot (the packing is an index_copy of the parameters: gradients flow back to
+        wq / wk / wv / wo), the attention core is ops.enc_attn_core (flash-style forward, maps only inside the backward) and
+        the residual LayerNorms are fused row kernels forward and backward.  Pad rows never reach the loss (their gradients
         are exactly zero) and are masked out of every softmax."""
         B, R, d = x.shape
         Rp = -(-R // 32) * 32
-        nh, HP = 6, ops.train_head_pad(B, Rp, 6)
+        nh, HP = 6, ops.HEAD_PAD
         sizes = [t.shape[-1] for t in x.reshape(-1, d)[:1].chunk(nh, -1)]
         starts = [sum(sizes[:i]) for i in range(nh)]
         idx = torch.cat([torch.arange(sizes[h]) + h * HP for h in range(nh)]).to(x.device)
@@ -426,8 +429,8 @@ class TopDownModel(nn.Module):
 
     def _fused_encoder_ok(self, d):
         scale = math.sqrt(d)
-        return (self.has_obj_interact and self.flash_obj_interact and os.environ.get('GVD_ENC_FUSED', '1') == '1'
-                and scale == 2.0 ** round(math.log2(scale)) and d % 32 == 0 and -(-d // 6) <= ops.HEAD_PAD)
+        return (self.has_obj_interact and scale == 2.0 ** round(math.log2(scale)) and d % 32 == 0
+                and -(-d // 6) <= ops.HEAD_PAD)
 
     def _vis_words_padded(self):
         """relu(vis_embed.weight) and vis_classifiers_bias zero-padded along the class axis to a multiple of 32 (inference;
@@ -461,7 +464,7 @@ class TopDownModel(nn.Module):
         self.__dict__.setdefault('_contract_flags', []).append(flag)
         m = ci.m_dev
         fc7 = self.ctx2pool_grd[0]
-        if os.environ.get('GVD_FC7_ROWMAP', '1') == '1' and ppls_feat.numel() * 4 < (1 << 32):
+        if ppls_feat.numel() * 4 < (1 << 32):
             # fc7 reads its rows of the dense fc6 tensor through the compaction map (row gather fused into the GEMM)
             g_pool = ops.gemm_nt(ppls_feat.contiguous(), fc7.weight.detach(), fc7.bias.detach(), 1, m_dev=m,
                                  a_row_map=ci.src_row)                                                      # [cap,2048]
@@ -483,54 +486,34 @@ class TopDownModel(nn.Module):
         return ci, pool, p_pool, ci.expand(sim_c).transpose(1, 2)
 
     def _obj_interact(self, x, key_bias=None):
-        """transformer.py:135-190,244-254 as built at model.py:126-135 (6 uneven heads, scale sqrt(d_model),
-        no padding mask, custom LayerNorm)."""
+        """transformer.py:135-190,244-254 as built at model.py:126-135 (6 uneven heads, scale sqrt(d_model), no padding
+        mask, custom LayerNorm): the flash-style kernels without autograd, the MFMA training core with it.  Region counts
+        the training core is not built for (R % 4 != 0, more than 2048 padded rows) take the elementwise formulation
+        below: projections / feed-forward on the MFMA GEMM, the attention maps through torch."""
         d = x.shape[-1]
         scale = math.sqrt(d)
-        fused = not torch.is_grad_enabled()
-        if (fused and not self.training and self.flash_obj_interact and os.environ.get('GVD_ENC_FUSED', '1') == '1'
-                and scale == 2.0 ** round(math.log2(scale)) and d % 32 == 0 and -(-d // 6) <= ops.HEAD_PAD):
+        if not torch.is_grad_enabled() and not self.training and self._fused_encoder_ok(d):
             return self._obj_interact_fused(x)
-        if (not fused and self.flash_obj_interact and x.is_cuda and os.environ.get('GVD_ENC_TRAIN_MFMA', '1') == '1'
-                and scale == 2.0 ** round(math.log2(scale)) and d % 32 == 0 and -(-d // 6) <= ops.TRAIN_HEAD_PAD
-                and x.shape[1] % 4 == 0 and x.shape[1] >= 4 and -(-x.shape[1] // 32) * 32 <= 2048):
+        if (torch.is_grad_enabled() and x.is_cuda and scale == 2.0 ** round(math.log2(scale)) and d % 32 == 0
+                and -(-d // 6) <= ops.HEAD_PAD and x.shape[1] % 4 == 0 and x.shape[1] >= 4
+                and -(-x.shape[1] // 32) * 32 <= 2048):
             return self._obj_interact_train(x, scale, key_bias)
         for lay in self.obj_interact.encoder.layers:
             sa = lay.selfattn.layer
-            # projections on the MFMA GEMM, forward and (K-strided operands) backward
             q, k, v = self._lin(x, sa.wq), self._lin(x, sa.wk), self._lin(x, sa.wv)
-            # the reference divides the [B,R,R] score maps by sqrt(d_model) = 32 (transformer.py:92,104); scaling the
-            # [B,R,171] queries instead is bitwise identical when the scale is a power of two and 5.8x less traffic
-            exact = scale == 2.0 ** round(math.log2(scale))
-            if exact:
-                q = q / scale
-            if fused and exact and self.flash_obj_interact:
-                # inference: all 6 heads in one flash-style fp32-MFMA kernel, no [B,R,R] score maps in HBM
-                sizes = [t.shape[-1] for t in q[:1, :1].chunk(6, -1)]
-                heads = [ops.flash_attn_heads(q.contiguous(), k.contiguous(), v.contiguous(), sizes)]
-            else:
-                heads = []
-                for qh, kh, vh in zip(q.chunk(6, -1), k.chunk(6, -1), v.chunk(6, -1)):
-                    dots = torch.matmul(qh, kh.transpose(1, 2))
-                    dots = dots if exact else dots / scale
-                    if key_bias is not None:          # (compacted training layout on the library path)
-                        dots = dots + key_bias.unsqueeze(1)
-                    w = F.softmax(dots, dim=-1)
-                    heads.append(torch.matmul(F.dropout(w, sa.attention.dropout.p, self.training), vh))
-            att = self._lin(heads[0] if len(heads) == 1 else torch.cat(heads, -1), sa.wo)
+            heads = []
+            for qh, kh, vh in zip(q.chunk(6, -1), k.chunk(6, -1), v.chunk(6, -1)):
+                dots = torch.matmul(qh, kh.transpose(1, 2)) / scale           # transformer.py:92,104
+                if key_bias is not None:          # (compacted training layout)
+                    dots = dots + key_bias.unsqueeze(1)
+                w = F.softmax(dots, dim=-1)
+                heads.append(torch.matmul(F.dropout(w, sa.attention.dropout.p, self.training), vh))
+            att = self._lin(torch.cat(heads, -1), sa.wo)
             ff = lay.feedforward.layer
-            if fused:   # inference: residual add + custom LayerNorm as one HIP row kernel
-                ln = lay.selfattn.layernorm
-                x = ops.add_layernorm_unbiased(x.contiguous(), att, ln.gamma, ln.beta, ln.eps)
-                y = ff.linear2(F.relu(ff.linear1(x)))
-                ln = lay.feedforward.layernorm
-                x = ops.add_layernorm_unbiased(x, y, ln.gamma, ln.beta, ln.eps)
-            else:
-                # ResidualBlock (transformer.py:79-88): dropout on the branch, then add + LayerNorm as one fused row
-                # kernel forward and one backward
-                x = self._add_ln(x, att, lay.selfattn.layernorm, lay.selfattn.dropout.p if self.training else 0.0)
-                y = self._lin(self._lin(x, ff.linear1, act=1), ff.linear2)
-                x = self._add_ln(x, y, lay.feedforward.layernorm, lay.feedforward.dropout.p if self.training else 0.0)
+            # ResidualBlock (transformer.py:79-88): dropout on the branch, then add + LayerNorm as one fused row kernel
+            x = self._add_ln(x, att, lay.selfattn.layernorm, lay.selfattn.dropout.p if self.training else 0.0)
+            y = self._lin(self._lin(x, ff.linear1, act=1), ff.linear2)
+            x = self._add_ln(x, y, lay.feedforward.layernorm, lay.feedforward.dropout.p if self.training else 0.0)
         return x
 
     def _preamble(self, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, allow_compact=False, enc_key_bias=None):
@@ -544,8 +527,7 @@ class TopDownModel(nn.Module):
         pm = pm.contiguous()
         # fc feature (model.py:306-308)
         fused_side = (not self.training and not torch.is_grad_enabled() and num.dtype == torch.int64
-                      and segs_feat.shape[-1] <= 4096 and self.seg_info_size <= 64
-                      and os.environ.get('GVD_SIDE_FUSED', '1') == '1')
+                      and segs_feat.shape[-1] <= 4096 and self.seg_info_size <= 64)
         if fused_side:
             # inference: mean over frames, seg_info_embed + ReLU, both layer norms, the concat and the K pad of fc_embed as one
             # launch instead of ~10 (they matter at batch_size = 4: csrc/compact.hip)
@@ -557,20 +539,17 @@ class TopDownModel(nn.Module):
             fc = torch.cat([F.layer_norm(fc, [fc.shape[-1]]), F.layer_norm(seg_info, [self.seg_info_size])], dim=-1)
         compact = (allow_compact and not torch.is_grad_enabled() and not self.training
                    and os.environ.get('GVD_COMPACT', '1') == '1'
-                   and self._fused_encoder_ok(self.rnn_size) and B * (R + 1) < (1 << 24)
-                   and os.environ.get('GVD_POOL_EMBED_OWN', '1') == '1')
+                   and self._fused_encoder_ok(self.rnn_size) and B * (R + 1) < (1 << 24))
         if compact:
             ci, pool_c, p_pool_c, sim_mat = self._regions_compact(ppls, ppls_feat, pm)
             pre = self._preamble_finish(segs_feat, sample_idx, fc, pm, None, None, sim_mat, None)
             pre.update(ci=ci, pool_c=pool_c, p_pool_c=p_pool_c)
             return pre
         # fc7 over the raw fc6 region features: MFMA GEMM + fused bias/ReLU (model.py:311-313)
-        g_pool = self._drop_after(self._lin(ppls_feat, self.ctx2pool_grd[0], act=1, p_drop=self._fused_drop_p()))
+        g_pool = self._lin(ppls_feat, self.ctx2pool_grd[0], act=1, p_drop=self._fused_drop_p())
         vis_word = self._drop(F.relu(self.vis_embed[0].weight))
         loc_in = torch.cat([ppls[:, :, :4] / 720., (ppls[:, :, 4] * 1. / self.num_sampled_frm).unsqueeze(-1)], dim=2)
-        loc = self._drop_after(self._lin_k32(loc_in, self.loc_fc[0], act=1, p_drop=self._fused_drop_p(self.loc_fc[2].p)),
-                               self.loc_fc[2].p)
-        pool_done = False
+        loc = self._lin_k32(loc_in, self.loc_fc[0], act=1, p_drop=self._fused_drop_p(self.loc_fc[2].p))
         if not torch.is_grad_enabled():
             # inference: class-last similarity logits from ONE plain MFMA GEMM (the visual words are shared by the
             # batch), then mask + class softmax + the three layer norms + concat as one HIP row kernel
@@ -581,17 +560,13 @@ class TopDownModel(nn.Module):
             else:
                 vw_pad, vb_pad = self._vis_words_padded()
             logits_t = ops.gemm_nt(g_pool, vw_pad, vb_pad)                                        # [B,R,448] (D1 = 433 used)
-            own = os.environ.get('GVD_POOL_EMBED_OWN', '1') == '1'
-            pool, sim_t = ops.region_feature_rows(g_pool, loc.contiguous(), logits_t, pm, pad_to=32 if own else 1, n_cls=D1)
+            pool, sim_t = ops.region_feature_rows(g_pool, loc.contiguous(), logits_t, pm, pad_to=32, n_cls=D1)
             sim_mat = sim_t.transpose(1, 2)          # [B,D1,R] view (the reference returns this layout)
-            if own:
-                # pool_embed (model.py:384, K = 2781) on the MFMA GEMM: the row kernel wrote the concat zero-padded to
-                # K = 2784 (16-byte aligned rows, 32-multiple K); the weight gets matching zero columns once
-                pool = self._drop(ops.gemm_nt(pool, self._pool_weight_padded(pool.shape[-1]),
-                                              self.pool_embed[0].bias.detach(), 1))
-                pool_done = True
-        elif (os.environ.get('GVD_P5_FUSED_TRAIN', '1') == '1' and g_pool.shape[-1] == 2048 and D1 <= 512
-              and loc.shape[-1] <= 512):
+            # pool_embed (model.py:384, K = 2781) on the MFMA GEMM: the row kernel wrote the concat zero-padded to
+            # K = 2784 (16-byte aligned rows, 32-multiple K); the weight gets matching zero columns once
+            pool = self._drop(ops.gemm_nt(pool, self._pool_weight_padded(pool.shape[-1]),
+                                          self.pool_embed[0].bias.detach(), 1))
+        elif g_pool.shape[-1] == 2048 and D1 <= 512 and loc.shape[-1] <= 512:
             # training: the same class-last similarity GEMM + fused row kernel as inference, with a fused backward row
             # kernel (three layer-norm backwards + class-softmax backward, ops._RegionRowsFn).  The class axis is
             # zero-padded to a 32-multiple so that dX / dW of the similarity GEMM run on the K-strided MFMA kernel; the
@@ -601,11 +576,11 @@ class TopDownModel(nn.Module):
             pool, sim_t = ops.region_feature_rows_train(g_pool, loc, logits_t, pm, D1, pad_to=32)
             sim_mat = sim_t.transpose(1, 2)          # [B,D1,R] view of the class-last tensor
             pe = self.pool_embed[0]
-            pool = self._drop_after(ops.linear(pool, F.pad(pe.weight, (0, pool.shape[-1] - pe.weight.shape[1])), pe.bias, 1,
-                                               self._fused_drop_p()))
-            pool_done = True
+            pool = ops.linear(pool, F.pad(pe.weight, (0, pool.shape[-1] - pe.weight.shape[1])), pe.bias, 1,
+                              self._fused_drop_p())
         else:
-            # (GVD_P5_FUSED_TRAIN=0) region-class similarity: batched grounder GEMM with fused bias + proposal mask (model.py:321-340)
+            # (class counts beyond what the fused row kernels hold in registers, detect_size > 511) region-class similarity:
+            # batched grounder GEMM with fused bias + proposal mask (model.py:321-340), torch row ops
             sim_logits = ops.grounder(vis_word, g_pool, pm[:, 1:], mbias=self.vis_classifiers_bias, xt_shared=True)
             sim_mat = F.softmax(sim_logits, dim=1)
             # location / class-distribution features (model.py:357-364)
@@ -614,10 +589,7 @@ class TopDownModel(nn.Module):
             pool = torch.cat([F.layer_norm(g_pool, [g_pool.shape[-1]]), F.layer_norm(loc, [300]),
                               F.layer_norm(label, [D1])] + ([label.new_zeros(B, R, kpad)] if kpad else []), dim=2)
             pe = self.pool_embed[0]
-            pool = self._drop_after(ops.linear(pool, F.pad(pe.weight, (0, kpad)), pe.bias, 1, self._fused_drop_p()))   # model.py:384
-            pool_done = True
-        if not pool_done:
-            pool = self._drop(F.relu(self.pool_embed[0](pool)))
+            pool = ops.linear(pool, F.pad(pe.weight, (0, kpad)), pe.bias, 1, self._fused_drop_p())   # model.py:384
         if self.has_obj_interact:
             pool = self._obj_interact(pool, enc_key_bias)
         pool = pool.contiguous()
@@ -627,8 +599,8 @@ class TopDownModel(nn.Module):
     def _preamble_finish(self, segs_feat, sample_idx, fc, pm, pool, p_pool, sim_mat, g_pool):
         """fc embedding + the frame half of the preamble (model.py:393-405)."""
         Ft = segs_feat.shape[1]
-        fc = self._drop_after(self._lin_k32(fc, self.fc_embed[0], act=1, x_padded=fc.shape[-1] != self.fc_embed[0].in_features,
-                                            p_drop=self._fused_drop_p()))
+        fc = self._lin_k32(fc, self.fc_embed[0], act=1, x_padded=fc.shape[-1] != self.fc_embed[0].in_features,
+                           p_drop=self._fused_drop_p())
         # frame-wise context (model.py:393-405)
         # frame embeddings (model.py:393-395) on the MFMA GEMM, straight from the two column blocks of segs_feat
         if not self.training and not torch.is_grad_enabled():
@@ -648,31 +620,20 @@ class TopDownModel(nn.Module):
                 scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
                 return scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous()
             scale, shift = self._packed(('bn_affine',), (bn.weight, bn.bias, bn.running_mean, bn.running_var), build_bn)
-            if os.environ.get('GVD_SIDE_FUSED', '1') == '1':
-                ops.affine_relu_rows_(c, scale, shift)
-            else:
-                c.mul_(scale).add_(shift).relu_()
+            ops.affine_relu_rows_(c, scale, shift)
         else:
-            c = torch.cat([self._drop_after(self._lin(segs_feat[:, :, :2048], self.att_embed[0][0], act=1, p_drop=self._fused_drop_p())),
-                           self._drop_after(self._lin(segs_feat[:, :, 2048:], self.att_embed[1][0], act=1, p_drop=self._fused_drop_p()))],
+            c = torch.cat([self._lin(segs_feat[:, :, :2048], self.att_embed[0][0], act=1, p_drop=self._fused_drop_p()),
+                           self._lin(segs_feat[:, :, 2048:], self.att_embed[1][0], act=1, p_drop=self._fused_drop_p())],
                           dim=2)
             c = self.att_embed_aux(c.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
         if not torch.is_grad_enabled():
             # inference: persistent cooperative HIP GRU (one launch per layer instead of ~6 per step/direction)
             c = ops.gru_bidir_2layer(c, self.context_enc, flags=self._flags())
-        elif (os.environ.get('GVD_GRU_TRAIN', '1') == '1' and self.context_enc.hidden_size == 512
-              and self.context_enc.bidirectional and self.context_enc.batch_first):
+        else:
             # training: persistent-kernel forward + hand-scheduled BPTT (gru_fn.py) instead of the library RNN
             from . import gru_fn
             c = gru_fn.gru_bidir_2layer_train(c, self.context_enc, flags=self._flags())
-        elif not self.training:
-            # MIOpen's fused RNN has no backward in eval mode; the native GRU does (parity tests differentiate in eval)
-            with torch.backends.cudnn.flags(enabled=False):
-                c = self.context_enc(c)[0]
-        else:
-            c = self.context_enc(c)[0]
-        if (not torch.is_grad_enabled() and sample_idx.dtype == torch.int64 and c.is_contiguous()
-                and os.environ.get('GVD_SIDE_FUSED', '1') == '1'):
+        if not torch.is_grad_enabled() and sample_idx.dtype == torch.int64 and c.is_contiguous():
             conv = ops.zero_rows_outside_window_(c, sample_idx.contiguous())       # in place on the GRU's fresh output
         else:
             t = torch.arange(Ft, device=c.device).view(1, Ft)
@@ -717,7 +678,8 @@ class TopDownModel(nn.Module):
                 seq, lps, att2 = sampling.multinomial_decode(self, self._dense_regions(pre), P, opt.get('temperature', 1.0))
             elif beam_size > 1:
                 from . import beam
-                seq, lps, att2 = beam.beam_decode(self, self._dense_regions(pre), P, beam_size)
+                seq, lps, att2 = beam.beam_decode(self, self._dense_regions(pre), P, beam_size,
+                                                   fused_step=opt.get('beam_fused_step', True))
             else:
                 seq, lps, att2 = ops.greedy_decode(pre, P, pre['pnt_mask'], self.seq_length, self.unk_idx,
                                                     prof=getattr(self, 'kernel_timer', None), flags=self._flags())
@@ -763,10 +725,14 @@ class TopDownModel(nn.Module):
         counts = self.kernel_status_counts()
         if counts is not None:
             bad, contract = counts.tolist()
-            if contract and isinstance(batches, (list, tuple)):
-                # some batch broke the zero-row loader contract: recompute them on the dense preamble (a lazy producer that
-                # recycles its staging buffers cannot be replayed: that case raises below)
-                outs = [self._sample(b[0], b[1], b[2], b[3], b[4], b[5], dict(eval_opt, dense_preamble=True)) for b in batches]
+            if (bad or contract) and isinstance(batches, (list, tuple)):
+                # some batch broke the zero-row loader contract, or a persistent kernel timed out on a shared GPU: compute,
+                # don't raise (see _sample_checked) - every batch again, one by one (a lazy producer that recycles its
+                # staging buffers cannot be replayed: that case raises below)
+                if bad:
+                    ops.disable_persistent_kernels(bad)
+                opt2 = dict(eval_opt, dense_preamble=True) if contract else eval_opt
+                outs = [self._sample(b[0], b[1], b[2], b[3], b[4], b[5], opt2) for b in batches]
                 c2 = self.kernel_status_counts()
                 bad, contract = (0 if c2 is None else c2.tolist()[0]), 0
             self.raise_for_status(bad, contract)

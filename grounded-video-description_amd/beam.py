@@ -43,7 +43,7 @@ def _core_rows(P, st, xt, fc_gates, pre, pmask_rows, K, att2_out):
     return dict(h_att=h_att, c_att=c_att, h_lang=h_lang, c_lang=c_lang)
 
 
-def beam_decode(model, pre, P, K):
+def beam_decode(model, pre, P, K, fused_step=True):
     """-> seq i64 [B,L], seqLogprobs f32 [B,L], att2 i64 [B,L] (global region argmax per step)."""
     fc = pre['fc']
     B, H = fc.shape
@@ -75,7 +75,9 @@ def beam_decode(model, pre, P, K):
     base = (torch.arange(B, device=dev) * K).view(B, 1)
     kk = torch.arange(K, device=dev)
 
-    fused = os.environ.get('GVD_BEAM_FUSED', '1') == '1' and K <= 8
+    # beam widths the one-wave-per-sample step kernel holds (csrc/beam.hip: K <= 8) take it; wider beams - and tests that
+    # pass fused_step=False - the batched torch formulation of the same bookkeeping below
+    fused = fused_step and K <= 8
     if fused:
         parent = torch.empty(rows, dtype=torch.int64, device=dev)
         word_rows = torch.empty(rows, dtype=torch.int64, device=dev)

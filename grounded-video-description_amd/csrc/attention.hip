@@ -436,14 +436,10 @@ __global__ void tanh_fast_kernel(const float* x, float* y, int64_t n) {
   if (i < n) y[i] = tanh_fast(x[i]);
 }
 
-// rows per chunk: 50; halved (not below 13) while fewer than ~512 workgroups would exist (small batches)
-int tune_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
+// rows per chunk: 50 (measured best against 32 / 64, profiles/r03/attn_chunk_y.log, beam_chunk_p.log); halved (not below
+// 13) while fewer than ~512 workgroups would exist (small batches)
 int pick_chunk(int N, int B) {
-  int chunk = tune_int("GVD_ATTN_CHUNK", 50);   // tuning knob (rows per workgroup), default measured best
+  int chunk = 50;
   while (chunk > 20 && (long)B * ((N + chunk - 1) / chunk) < 512) chunk = (chunk + 1) / 2;
   if (chunk > MAX_CHUNK) chunk = MAX_CHUNK;
   if (chunk > N) chunk = N;
@@ -501,15 +497,13 @@ extern "C" int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_sid
   // Streaming hint: when one launch reads more than the 256 MB Infinity Cache can hold, nothing it reads survives to
   // the next token anyway, and nontemporal loads stream measurably faster (tools/stream_read_micro.hip: 7.1 vs 6.3 TB/s
   // read-only; this kernel 311 -> 285 us at B = 256).  Smaller launches keep plain loads so the features stay cached
-  // across tokens.  GVD_ATTN_NT=0/1 overrides.
+  // across tokens.
   const double launch_bytes = (double)B / (region->group > 1 ? region->group : 1) *
                               ((double)region->N + (temporal ? temporal->N : 0)) * (ATT_A + ATT_H) * 4.0;
-  const int nt_env = tune_int("GVD_ATTN_NT", -1);
-  const bool nt = nt_env >= 0 ? nt_env != 0 : launch_bytes > 192.0 * 1024 * 1024;
+  const bool nt = launch_bytes > 192.0 * 1024 * 1024;
   // beam search: both attentions share features within groups of G rows -> one workgroup per (chunk, sample)
   const int G = region->group;
-  const bool grouped = G >= 2 && G <= 5 && B % G == 0 && (!temporal || temporal->group == G) &&
-                       tune_int("GVD_ATTN_GROUPED", 1);
+  const bool grouped = G >= 2 && G <= 5 && B % G == 0 && (!temporal || temporal->group == G);
   if (grouped && (region->row_map || (temporal && temporal->row_map))) return GVD_EINVAL;   // (row kernel only)
   if (grouped) {
     const dim3 grid((unsigned)p.nctot, (unsigned)(B / G));

@@ -114,8 +114,9 @@ extern "C" int gvd_greedy_decode(const gvd_greedy_args* a, gvd_stream_t stream) 
     g.C = w.fc_gates; g.ldc = 4 * H; g.M = B; g.N = 4 * H; g.batch = 1;
     GVD_TRY(gvd_gemm_nt_f32(&g, stream));
   }
-  if (a->pool_row_map && gvd_pd_eligible(B, H, A, E, V, R, Ft)) return GVD_EINVAL;   // persistent kernel: dense layout
-  if (gvd_pd_eligible(B, H, A, E, V, R, Ft)) {
+  const bool persistent = !a->no_persistent && gvd_pd_eligible(B, H, A, E, V, R, Ft);
+  if (a->pool_row_map && persistent) return GVD_EINVAL;   // persistent kernel: dense layout
+  if (persistent) {
     // decode batch: the whole token loop as ONE persistent cooperative launch (decode_persistent.hip).  The event
     // timer `prof` has no per-step attention kernel to bracket on this path and records nothing.
     PdParams q = {};

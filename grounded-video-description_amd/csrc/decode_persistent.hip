@@ -665,6 +665,10 @@ int gvd_pd_launch(PdParams p, void* workspace, hipStream_t st) {
   pd_carve(&p, workspace, nct);
   hipError_t e = hipMemsetAsync(p.sync, 0, (size_t)GVD_SYNC_WORDS * sizeof(unsigned), st);
   if (e != hipSuccess) return (int)e;
+  if (gvd_spin_limit_env()) {      // test aid: forced barrier timeouts (GVD_SPIN_LIMIT)
+    e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.sync + GVD_SYNC_LIMIT), (int)gvd_spin_limit_env(), 1, st);
+    if (e != hipSuccess) return (int)e;
+  }
   void* args[] = {&p};
   // Plain launch after an explicit co-residency check (gvd_grid_fits: what the cooperative launch verifies), because the
   // cooperative path costs a ~12 us dispatch gap on either side of the kernel; GVD_COOP_LAUNCH=1 restores it.  The grid barrier

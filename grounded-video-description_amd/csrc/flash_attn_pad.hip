@@ -11,12 +11,33 @@
 //     the barrier wait and the next tile's write pass sit under 44 MFMAs (three buffers because that second half still
 //     reads the current tile after the barrier: the buffer overwritten in iteration j held tile j-2, whose last reads
 //     every wave finished before it arrived at barrier j-1); two waves per SIMD cover the softmax VALU work.
-// Arithmetic is the 16x16x4 fp32-MFMA scheme of flash_attn16_kernel (swapped products S^T = K Q^T, O^T = V^T P^T,
-// lane-local online softmax in the log2 domain, exact skip of the identity rescale): same values.
+// Arithmetic: 16x16x4 fp32 MFMAs on swapped products (S^T = K Q^T, O^T = V^T P^T), so that a lane holds 8 keys of ONE
+// query: lane-local online softmax in the log2 domain, exact skip of the identity rescale, the exp'd score register IS the
+// B operand of the PV step.
+//
+// TRAINING forward (template TRAIN; ops._EncAttnCoreFn): the same kernel over the Rp-padded training layout with
+//   * a per-key additive bias (the compacted training layout's key weights, train_compact.py), staged once into LDS,
+//   * the dropout of transformer.py:95,104 applied to the probabilities in registers (enc_dropout.h: a counter-based hash
+//     of (seed, map row, key) the backward re-evaluates) - the row sum keeps the UNdropped probabilities, as
+//     dropout(softmax(s)) @ V requires,
+//   * the log2-domain logsumexp of every query written out: the backward (enc_attn_bwd.hip) recomputes
+//     P = exp2(s - lse) tile by tile instead of reading a [B, heads, R, R] map the forward would have to write.
 #include "gvd_common.h"
-#include <stdlib.h>
+#include "enc_dropout.h"
+#include "philox.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// K / V tile staging: 0 = through registers (6 buffer loads + 6 ds_write_b128 per lane and tile), 1 = direct global -> LDS
+// loads (buffer_load_dwordx4 ... lds).  A direct load writes lane l's 16 bytes at wave base + 16 l, i.e. LDS is filled
+// in lane order and cannot be padded by the hardware - the 180-float rows (176 + one 16-byte pad chunk, which is what
+// keeps the fragment reads conflict-free) are kept anyway by treating the tile as a linear array of 16-byte chunks, 45
+// per row: the lane whose chunk is a row's pad slot (or lies past the 32nd row) issues an out-of-range address (reads as
+// zero, no memory traffic).  1536 chunks per operand tile = 8 waves x 3 instructions, same instruction count as the loads
+// of the register form, no LDS write pass, 24 fewer VGPRs.  tools/flash_glds_ab.py builds both and compares bits + time.
+#ifndef GVD_FLASH_GLDS
+#define GVD_FLASH_GLDS 0
+#endif
 
 namespace {
 
@@ -28,6 +49,10 @@ constexpr int NT = NW * 64;
 constexpr int NSB = DP / 16;        // 11
 constexpr int F4_PER_TILE = TK * DP / 4;              // 1408 16-byte pieces per operand tile
 constexpr int NLD = (F4_PER_TILE + NT - 1) / NT;      // 3 loads per thread per operand (the last round is partial)
+constexpr bool GLDS = GVD_FLASH_GLDS != 0;
+constexpr int CPR = LD / 4;                           // 45 16-byte chunks per LDS row (the last one is the pad)
+constexpr int OPSZ = GLDS ? NLD * NT * 4 : TK * LD;   // floats of one operand tile's LDS region (6144 | 5760)
+constexpr int BUFSZ = 2 * OPSZ;
 
 // Reduction over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 lane-swap instructions:
 // v_permlane16_swap a, b exchanges the odd rows of a with the even rows of b -> [a0 b0 a2 b2] / [a1 b1 a3 b3]; with
@@ -61,19 +86,24 @@ struct PParams {
   const float* q; const float* k; const float* v; float* o;
   int64_t ld, ldo;       // row strides (floats) of q/k/v and of o
   int B, R, n_heads;
+  int rstride;           // rows between consecutive samples (R at inference; Rp >= R on the padded training layout)
   float qscale;          // 1/sqrt(d_model) (a power of two in the reference configuration) times log2(e)
   // ragged (compacted) batches: sample b owns rows off[b] .. off[b+1]-1 of q/k/v/o (at most R of them); its LAST row
   // stands for n identical rows: as a key its score gets + key_w[b] = log2(n) (-inf: no such rows, key ignored)
   const int* off; const float* key_w;
-  int skew;              // phase-skew the two waves of every SIMD (see the kernel); 0 = all waves take the barrier mid-PV
+  // TRAIN only
+  const float* kbias;    // nullable [B, rstride]: added to the SCALED scores of a key (natural-log units; -inf = no such key)
+  float* lse;            // [B * n_heads, rstride]: log2-domain logsumexp of every query's (scaled, biased) scores
+  uint32_t thresh, seed_lo, seed_hi;   // dropout: element dropped iff its draw < thresh (0 = no dropout)
+  float keep_scale;      // 1 / (1 - p)
 };
 
-// ABL (profiling only, tools/flash_ablate.py): 0 = the kernel; 1 = no online softmax (scores used as they are: wrong
-// values, same MFMA / LDS / staging work); 2 = no K/V staging and no barrier after the first tile (every tile re-reads
-// buffer 0); 3 = both.  Shows where the matrix pipe's idle quarter goes.
-template <int ABL>
+constexpr int MAX_TRAIN_KEYS = 2048;      // LDS slice of the staged key bias (TRAIN)
+
+template <bool TRAIN>
 __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) {
-  __shared__ __attribute__((aligned(16))) float smem[3 * 2 * TK * LD];       // [buf][K|V][32][180] = 138,240 B
+  // [buf][K|V][32][180] = 138,240 B (+ the key bias of the sample, TRAIN: 8 KB)
+  __shared__ __attribute__((aligned(16))) float smem[3 * BUFSZ + (TRAIN ? MAX_TRAIN_KEYS : 0)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int c16 = lane & 15, g = lane >> 4;
   // linear workgroup id, XCD-aware: the query tiles of one (sample, head) run on ONE XCD so its K/V slices are fetched
@@ -84,7 +114,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
   const int h = (lid / nqt) % p.n_heads;
   const int b = lid / (nqt * p.n_heads);
   const int64_t ld = p.ld;
-  const int64_t row0 = p.off ? (int64_t)p.off[b] : (int64_t)b * p.R;        // first row of this sample
+  const int64_t row0 = p.off ? (int64_t)p.off[b] : (int64_t)b * p.rstride;  // first row of this sample
   const int R = p.off ? p.off[b + 1] - p.off[b] : p.R;                       // its row count
   if (qt * (16 * NW) >= R) return;                                           // (ragged: grid sized for the longest sample)
   const int wkey = p.off ? R - 1 : -1;                                       // the weighted key, if any
@@ -117,9 +147,33 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     loff[i] = (unsigned)(row * LD + 4 * c4);
   }
   const bool last_ok = tid + NT * (NLD - 1) < F4_PER_TILE;                   // the third round covers 384 threads
-  f32x4 gk[NLD], gv[NLD];
-  auto fetch = [&](int key0) {
+  f32x4 gk[GLDS ? 1 : NLD], gv[GLDS ? 1 : NLD];
+  // direct-to-LDS form: instruction i of wave w fills chunks (3 w + i) 64 + lane of the tile's linear chunk array
+  unsigned doff[NLD];
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  if (GLDS) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int ch = (wv * NLD + i) * 64 + lane;
+      const int row = ch / CPR, c4 = ch - row * CPR;
+      doff[i] = (row < TK && c4 < DP / 4) ? (unsigned)row * ld4 + 16u * c4 : 0x80000000u;   // pad chunk / past the tile: out of range
+    }
+  }
+  // fetch(key0, buf): start tile key0's journey to LDS buffer `buf` (register form: into gk / gv; stage() finishes it)
+  auto fetch = [&](int key0, int buf) {
     const unsigned so = (unsigned)key0 * ld4;
+    if (GLDS) {
+      float* kd = smem + buf * BUFSZ;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kd + (wv * NLD + i) * 256), 16,
+                                                 doff[i], so, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(kd + OPSZ + (wv * NLD + i) * 256), 16,
+                                                 doff[i], so, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       if (i + 1 < NLD || last_ok) {
@@ -129,8 +183,9 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     }
   };
   auto stage = [&](int buf) {
-    float* kd = smem + buf * (2 * TK * LD);
-    float* vd = kd + TK * LD;
+    if (GLDS) return;                    // (the loads wrote LDS themselves; the tile's barrier waits for them: vmcnt(0))
+    float* kd = smem + buf * BUFSZ;
+    float* vd = kd + OPSZ;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       if (i + 1 < NLD || last_ok) {
@@ -146,39 +201,51 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
   float m_run = -INFINITY, l_run = 0.f;
 
   const int ntiles = (R + TK - 1) / TK;
-  fetch(0);
+  fetch(0, 0);
   stage(0);
+  float* kb_s = smem + 3 * BUFSZ;           // TRAIN: the sample's key bias in log2 units (0 without one)
+  if (TRAIN) {
+    const float* kb = p.kbias ? p.kbias + (int64_t)b * p.rstride : nullptr;
+    for (int i = tid; i < ntiles * TK; i += NT) kb_s[i] = (kb && i < R) ? kb[i] * 1.4426950408889634f : 0.f;
+  }
   __syncthreads();
   int buf = 0;
   // A wave whose 16 queries all lie past the sample's last row (the tail of the last query tile; ragged batches: on
   // average half of that tile) only helps staging the K / V tiles and keeps the barrier count: it issues no MFMA, so its
   // SIMD's matrix pipe goes to the other resident waves.
   if (qt * (16 * NW) + wave * 16 >= R) {
-    if (ABL & 2) return;
 #pragma unroll 1
     for (int jt = 0; jt < ntiles; ++jt) {
       const int nxt = buf == 2 ? 0 : buf + 1;
       if (jt + 1 < ntiles) {
-        fetch((jt + 1) * TK);
-        stage(nxt);                      // (tile jt-2's buffer: every wave left it before the previous barrier)
+        fetch((jt + 1) * TK, nxt);       // (tile jt-2's buffer: every wave left it before the previous barrier)
+        stage(nxt);
       }
       __syncthreads();
       buf = nxt;
     }
     return;
   }
-  const bool skew = p.skew && wave >= NW / 2;      // wave-uniform
+  const bool skew = wave >= NW / 2;                // wave-uniform
+  // TRAIN: this lane's query in the dropout hash (enc_dropout.h): row id = (sample * heads + head) * rstride + query
+  const uint32_t dkey = TRAIN ? gvd_encdrop_row((uint32_t)(b * p.n_heads + h) * (uint32_t)p.rstride + (uint32_t)qrow, p.seed_lo, p.seed_hi) : 0u;
+  const bool drop = TRAIN && p.thresh != 0u;       // wave-uniform
+  const bool biased = TRAIN && p.kbias != nullptr;
   // first K fragments of the next tile, read right after the barrier that publishes it (under the last 44 MFMAs)
   f32x4 kpre[2];
   kpre[0] = *reinterpret_cast<const f32x4*>(smem + c16 * LD + 4 * g);
   kpre[1] = *reinterpret_cast<const f32x4*>(smem + (c16 + 16) * LD + 4 * g);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
   for (int jt = 0; jt < ntiles; ++jt) {
     const int key0 = jt * TK;
     const bool more = jt + 1 < ntiles;                                     // wave-uniform
-    if (more && !(ABL & 2)) fetch(key0 + TK);                              // flies under this tile's MFMAs
-    const float* sk = smem + buf * (2 * TK * LD);
-    const float* sv = sk + TK * LD;
+    const int nxt = buf == 2 ? 0 : buf + 1;
+    // tile jt+1 flies under this tile's MFMAs (direct-to-LDS form: straight into the buffer that held tile jt-2, which
+    // every wave left before the previous barrier)
+    if (more) fetch(key0 + TK, nxt);
+    const float* sk = smem + buf * BUFSZ;
+    const float* sv = sk + OPSZ;
     // Publishing tile jt+1:
     //   stage_next   LDS write pass into the buffer that held tile jt-2 (every wave left it before the previous barrier);
     //   barrier_next the tile's one barrier + the first K fragments of tile jt+1.
@@ -188,15 +255,12 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     // PV product, so that per SIMD (waves w and w + 4) one wave's softmax falls into the other's MFMA stretch (8.89 vs
     // 9.05 ms).  The buffer protocol only depends on the barrier order: every wave passes exactly one barrier per tile,
     // after its last read of tile jt-1's buffer and before its first read of tile jt+1's.
-    const int nxt = (ABL & 2) ? 0 : (buf == 2 ? 0 : buf + 1);
     auto stage_next = [&]() {
-      if (ABL & 2) return;
       if (more) stage(nxt);
     };
     auto barrier_next = [&]() {
-      if (ABL & 2) return;
       __syncthreads();
-      const float* nk = smem + nxt * (2 * TK * LD) + c16 * LD + 4 * g;       // (stale but harmless after the last tile)
+      const float* nk = smem + nxt * BUFSZ + c16 * LD + 4 * g;               // (stale but harmless after the last tile)
       kpre[0] = *reinterpret_cast<const f32x4*>(nk);
       kpre[1] = *reinterpret_cast<const f32x4*>(nk + 16 * LD);
       __builtin_amdgcn_sched_barrier(0);
@@ -236,9 +300,12 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
       for (int dt = 0; dt < NSB; ++dt) dst[dt] = vp[16 * dt];
     };
     vload(vf[0], 0);
-    if (!(ABL & 1)) {
     // ---- online softmax: this lane holds keys 16 u + 4 g + reg of its query
     float mt = -INFINITY;
+    if (biased) {                                  // per-key bias (log2 units; -inf removes the key)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) sacc[u] += *reinterpret_cast<const f32x4*>(kb_s + key0 + 16 * u + 4 * g);
+    }
     // masks only where they can apply (wave-uniform): the sample's last key tile (keys past R, the weighted key)
     if (key0 + TK > R || (wkey >= key0 && wkey < key0 + TK)) {
 #pragma unroll
@@ -272,6 +339,12 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
 #pragma unroll
       for (int dt = 0; dt < NSB; ++dt) oacc[dt] *= alpha;
     }
+    if (drop) {                                    // dropout on the probabilities that enter the PV product only
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          sacc[u][r] = gvd_encdrop_keep(dkey, (uint32_t)(key0 + 16 * u + 4 * g + r), p.thresh) ? sacc[u][r] * p.keep_scale : 0.f;
     }
     // ---- O^T += V^T P^T: step = 4 u + s4 contracts key 16 u + 4 g + s4 = score register s4 of sub-tile u; the V
     // fragments of step+1 are read while step multiplies.  Between steps 3 and 4: LDS write pass of the next tile +
@@ -292,6 +365,8 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
 
   const float l_tot = rows_sum(l_run);
   const float inv = 1.0f / l_tot;
+  if (TRAIN && qrow < R && g == 0)
+    p.lse[(int64_t)(b * p.n_heads + h) * p.rstride + qrow] = m_run + __builtin_amdgcn_logf(l_tot);   // (v_log_f32 = log2)
   if (qrow < R) {
     float* orow = p.o + (row0 + qrow) * p.ldo + h * DP + 4 * g;
 #pragma unroll
@@ -309,19 +384,34 @@ extern "C" int gvd_flash_attn_padded_f32(const float* q, const float* k, const f
       ldo < (int64_t)n_heads * DP || (int64_t)R * ld * 4 >= (int64_t)1 << 31 || (row_off && !last_key_log2_weight))
     return GVD_EINVAL;
   PParams p = {};
-  p.q = q; p.k = k; p.v = v; p.o = o; p.ld = ld; p.ldo = ldo; p.B = B; p.R = R; p.n_heads = n_heads;
+  p.q = q; p.k = k; p.v = v; p.o = o; p.ld = ld; p.ldo = ldo; p.B = B; p.R = R; p.n_heads = n_heads; p.rstride = R;
   p.qscale = 1.4426950408889634f * scale;
   p.off = row_off; p.key_w = last_key_log2_weight;
-  static const int skew = getenv("GVD_FLASH_SKEW") ? atoi(getenv("GVD_FLASH_SKEW")) : 1;    // A/B knob
-  static const int abl = getenv("GVD_FLASH_ABLATE") ? atoi(getenv("GVD_FLASH_ABLATE")) : 0;  // profiling only: WRONG results
-  p.skew = skew;
   const unsigned nwg = (unsigned)((R + 16 * NW - 1) / (16 * NW)) * n_heads * B;
-  switch (abl) {
-    case 1: hipLaunchKernelGGL(flash_attn_pad_kernel<1>, dim3(nwg), dim3(NT), 0, gvd_s(stream), p); break;
-    case 2: hipLaunchKernelGGL(flash_attn_pad_kernel<2>, dim3(nwg), dim3(NT), 0, gvd_s(stream), p); break;
-    case 3: hipLaunchKernelGGL(flash_attn_pad_kernel<3>, dim3(nwg), dim3(NT), 0, gvd_s(stream), p); break;
-    default: hipLaunchKernelGGL(flash_attn_pad_kernel<0>, dim3(nwg), dim3(NT), 0, gvd_s(stream), p);
-  }
+  hipLaunchKernelGGL(flash_attn_pad_kernel<false>, dim3(nwg), dim3(NT), 0, gvd_s(stream), p);
+  GVD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gvd_flash_attn_train_fwd_f32(const float* qkv, int64_t ld, float* o, int64_t ldo, float* lse, int B, int Rp,
+                                            int R, int n_heads, int head_pad, float scale, const float* key_bias,
+                                            float p_drop, uint64_t seed, gvd_stream_t stream) {
+  if (!qkv || !o || !lse || B <= 0 || R <= 0 || Rp < R || Rp > MAX_TRAIN_KEYS || (Rp % 32) != 0 || n_heads <= 0 ||
+      head_pad != DP || (ld % 4) != 0 || (ldo % 4) != 0 || !gvd_aligned16(qkv) || !gvd_aligned16(o) ||
+      ld < (int64_t)3 * n_heads * DP || ldo < (int64_t)n_heads * DP || (int64_t)R * ld * 4 >= (int64_t)1 << 31 ||
+      !(p_drop >= 0.f) || !(p_drop < 1.f) || (key_bias && !gvd_aligned16(key_bias)) ||
+      (int64_t)B * n_heads * Rp >= (int64_t)1 << 32)
+    return GVD_EINVAL;
+  PParams p = {};
+  p.q = qkv; p.k = qkv + (int64_t)n_heads * DP; p.v = qkv + (int64_t)2 * n_heads * DP; p.o = o;
+  p.ld = ld; p.ldo = ldo; p.B = B; p.R = R; p.n_heads = n_heads; p.rstride = Rp;
+  p.qscale = 1.4426950408889634f * scale;
+  p.kbias = key_bias; p.lse = lse;
+  p.thresh = p_drop > 0.f ? gvd_drop_thresh(p_drop) : 0u;
+  p.keep_scale = 1.0f / (1.0f - p_drop);
+  p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+  const unsigned nwg = (unsigned)((R + 16 * NW - 1) / (16 * NW)) * n_heads * B;
+  hipLaunchKernelGGL(flash_attn_pad_kernel<true>, dim3(nwg), dim3(NT), 0, gvd_s(stream), p);
   GVD_CHECK_LAUNCH();
   return 0;
 }

@@ -271,32 +271,18 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
     v.C = a->C; v.ldc = a->ldc; v.M = a->M; v.N = a->N; v.act = a->act;
     return gvd_gemv_plain(v, st);
   }
-  static const int small = getenv("GVD_GEMM_SMALL") ? atoi(getenv("GVD_GEMM_SMALL")) : 1;     // A/B knob
   // 17..32 rows: the pipelined 64 x 64 kernel where it is eligible (half of its MFMA rows idle, but the K loop is software
   // pipelined: LSTM cell 99 -> ~45 us, queries / logits 40 -> ~25 us at B = 32, profiles/r03/b32_w_kernel_stats.md), the
   // general 32 x 128 kernel otherwise
   if (a->M <= 32) {
-    if (small && a->M > 16 && gvd_gemm_small_ok(p, a->batch)) return gvd_gemm_small_launch(p, false, st);
+    if (a->M > 16 && gvd_gemm_small_ok(p, a->batch)) return gvd_gemm_small_launch(p, false, st);
     return launch<32, 128, 1, 4, false>(p, a->batch, st);
   }
+  // >= 256 tiles of 128 x 128: the software-pipelined kernel with direct global->LDS operand loads (gemm_pipe.hip).  Measured
+  // and removed: a double-buffered register-staged 128 x 128 form, 64-deep K tiles, a 256 x 128 tile.
   const long big = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
-  static const long big_min = getenv("GVD_GEMM_BIG") ? atol(getenv("GVD_GEMM_BIG")) : 256;   // tuning knob
-  if (big >= big_min) {
-    // default: single LDS buffer + register prefetch (36.9 KB -> 3 workgroups/CU): measured 126.6 vs 122.8 TF/s for
-    // the double-buffered form on the fc7 shape (tools/gemm_micro.py); GVD_GEMM_VARIANT=0 selects the latter.
-    // Tried and rejected: 64-deep K tiles (variant 2: no change, barriers are not the limit) and a 256x128 tile
-    // (272 registers -> 1 wave/SIMD: 116 TF/s).  PMC: 81 % MFMA-busy vs rocBLAS 95 % with one pipelined wave/SIMD.
-    static const int variant = getenv("GVD_GEMM_VARIANT") ? atoi(getenv("GVD_GEMM_VARIANT")) : 3;
-    if (variant == 3) return gvd_gemm_pipe_launch(p, a->batch, st);      // software-pipelined kernel (gemm_pipe.hip)
-    if (variant == 0) return launch<128, 128, 2, 2, false, 2>(p, a->batch, st);
-    if (variant == 2) {      // 64-deep K tiles (half the barriers per flop); needs every segment K % 64 == 0
-      bool ok64 = true;
-      for (int s = 0; s < a->nseg; ++s) ok64 = ok64 && (a->seg[s].K % 64) == 0;
-      if (ok64) return launch<128, 128, 2, 2, false, 1, 64>(p, a->batch, st);
-    }
-    return launch<128, 128, 2, 2, false, 1>(p, a->batch, st);
-  }
-  if (small && gvd_gemm_small_ok(p, a->batch)) return gvd_gemm_small_launch(p, false, st);
+  if (big >= 256) return gvd_gemm_pipe_launch(p, a->batch, st);
+  if (gvd_gemm_small_ok(p, a->batch)) return gvd_gemm_small_launch(p, false, st);
   return launch<64, 64, 2, 2, false>(p, a->batch, st);
 }
 
@@ -332,8 +318,7 @@ extern "C" int gvd_lstm_cell_fwd(const gvd_lstm_args* a, gvd_stream_t stream) {
     v.c_out = a->c_out; v.ldco = a->ldc_out; v.gates_out = a->gates_out; v.ldg = a->ldg;
     return gvd_gemv_lstm(v, st);
   }
-  static const int small = getenv("GVD_GEMM_SMALL") ? atoi(getenv("GVD_GEMM_SMALL")) : 1;
-  if (small && gvd_gemm_small_ok(p, 1) && (a->H % 16) == 0) return gvd_gemm_small_launch(p, true, st);   // (B = 17..32 too)
+  if (gvd_gemm_small_ok(p, 1) && (a->H % 16) == 0) return gvd_gemm_small_launch(p, true, st);   // (B = 17..32 too)
   if (a->B <= 32) return launch<32, 128, 1, 4, true>(p, 1, st);
   return launch<64, 64, 2, 2, true>(p, 1, st);
 }

@@ -20,34 +20,14 @@
 // Numerics are identical to gemm_f32.hip: the same v_mfma_f32_32x32x2_f32 chain in the same k order per output.
 #include "gemm_common.h"
 
-// Profiling builds only (tools/gemm_ablate.py compiles variants of this file with -DGVD_PIPE_ABL=n; results are WRONG, the
-// MFMA work is unchanged): bit 0 = no per-k-tile barrier, bit 1 = no register->LDS write pass, bit 2 = no global loads after
-// the first tile, bit 3 = no epilogue (nothing stored).  The product build leaves it 0.
-#ifndef GVD_PIPE_ABL
-#define GVD_PIPE_ABL 0
-#endif
-#ifndef GVD_PIPE_AGPR
-#define GVD_PIPE_AGPR 0
-#endif
-// DIRECT-TO-LDS OPERANDS (default on; -DGVD_PIPE_LDSDMA=0 = the register-staged form; tools/gemm_ldsdma_check.py compares the
-// two bit for bit on the device): operand tiles of the plain (not
-// K-strided) products go global -> LDS by direct loads (buffer_load_dwordx4 ... lds, 16 bytes per lane on gfx950), without
-// the register round trip and its ds_write_b128 pass (6 of the kernel's 10 idle points, tools/gemm_ablate.py).  A direct
-// load writes lane l's 16 bytes to LDS at base + 16 l, so the tile is stored UNPADDED (32 floats per row, 8 rows per wave
-// instruction) with an XOR swizzle instead of the 36-float rows: 16-byte slot s of row m holds the k-chunk s ^ (m & 7); the
+// DIRECT-TO-LDS OPERANDS: operand tiles of the plain (not K-strided) products go global -> LDS by direct loads
+// (buffer_load_dwordx4 ... lds, 16 bytes per lane on gfx950), without a register round trip and its ds_write_b128 pass (6 of
+// the register-staged kernel's 10 idle points in an ablation: 141.1 -> 149.5 TF/s without that pass).  A
+// direct load writes lane l's 16 bytes to LDS at base + 16 l, so the tile is stored UNPADDED (32 floats per row, 8 rows per
+// wave instruction) with an XOR swizzle instead of 36-float rows: 16-byte slot s of row m holds the k-chunk s ^ (m & 7); the
 // loading lane fetches the k-chunk that belongs at its slot, the fragment reads of 8 consecutive rows hit 8 different slots.
-#ifndef GVD_PIPE_LDSDMA
-#define GVD_PIPE_LDSDMA 1
-#endif
-// EXPERIMENTAL (default off): the same for the K-STRIDED operands of the backward products.  Verified bitwise equal to the
-// register-staged K-strided path on dX / ragged dX / split dW / ragged dW (tools/gemm_ldsdma_check.py, session AJ), +1 % on
-// dX; not yet run through the training test files, hence not the default.  Such a tile is 32 memory rows (k) of 128 floats; a wave instruction covers
-// two of them (lane l: k row 2 w + 8 i + l / 32, 16-byte slot l % 32), stored unpadded (128 floats per k row) with slot
-// s of k row j holding column chunk s ^ (8 * ((j / 4) & 1)): the two halves of a wave (k rows 4 apart) then read their
-// ds_read_b32 fragments from different banks, as the 132-float rows of the register-staged form arrange.
-#ifndef GVD_PIPE_LDSDMA_T
-#define GVD_PIPE_LDSDMA_T 0
-#endif
+// Bitwise equal to the register-staged form it replaced (same k order).  K-strided operands (the backward products) keep the
+// register-staged path below: their tiles are [32 k][128] with ds_read_b32 fragments, and direct loads measured +1 % there.
 
 namespace {
 
@@ -71,21 +51,13 @@ struct Seg {
 template <bool EPI_LDS, bool AT = false, bool BT = false, bool EDGE = false>
 __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];     // 73,728 B -> two workgroups per CU
-  constexpr bool DMA = (GVD_PIPE_LDSDMA != 0) && ((!AT && !BT) || (GVD_PIPE_LDSDMA_T != 0));
+  constexpr bool DMA = !AT && !BT;               // plain products: direct-to-LDS operand loads
   constexpr int DLD = BK;                        // DMA layout of a plain operand tile: unpadded rows of 32 floats
-  constexpr int TLD = 128;                       // DMA layout of a K-strided operand tile: unpadded k rows of 128 floats
-  constexpr int A_STRIDE = DMA ? (AT ? BK * TLD : BM * DLD) : BM * LDK;      // floats per LDS buffer of the A / W tile
-  constexpr int W_STRIDE = DMA ? (BT ? BK * TLD : BN * DLD) : BN * LDK;
+  constexpr int A_STRIDE = DMA ? BM * DLD : BM * LDK;      // floats per LDS buffer of the A / W tile
+  constexpr int W_STRIDE = DMA ? BN * DLD : BN * LDK;
   float* As = smem;
   float* Ws = smem + 2 * A_STRIDE;
 
-#if GVD_PIPE_AGPR
-  // An inline-asm AGPR operand makes the function "may need AGPRs": the instruction selector then emits the MFMAs in their
-  // AGPR form (accumulators in the acc register file with its own ports) instead of the VGPR form it prefers when the
-  // whole kernel fits 256 VGPRs - in VGPR form every MFMA's 16-register accumulator traffic shares the VGPR ports with the
-  // operand fetch of the ds_write_b128 pass.
-  { float agpr_hint = 0.f; asm volatile("" : "+a"(agpr_hint)); }
-#endif
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, half = lane >> 5;
@@ -124,9 +96,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   // K-strided operands: thread covers memory rows (k) tk + 8 i, 16-byte column chunk tc (columns = output rows / cols;
   // chunks past the edge are clamped to the last whole chunk - M, N are multiples of 4 there)
   const int tk = tid >> 5, tc = tid & 31;
-  // (DMA layout: the lane's slot tc of k row tk + 8 i holds column chunk tc ^ 8 ((tk / 4) & 1))
-  const int tcs = DMA ? (tc ^ (((tk >> 2) & 1) * 8)) : tc;
-  const int acol = min(m0 + 4 * tcs, M - 4) - m0, wcol = min(n0 + 4 * tcs, p.N - 4) - n0;
+  const int acol = min(m0 + 4 * tc, M - 4) - m0, wcol = min(n0 + 4 * tc, p.N - 4) - n0;
 
   Seg sg;
   int seg = 0, kpos = 0;                                    // position of the NEXT tile to fetch
@@ -204,30 +174,14 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   auto dma = [&](int buf) {
     const unsigned so = 4u * (unsigned)((ktail && kpos + BK > kend) ? kend - BK : kpos);
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    if (AT) {                                   // two k rows of 128 floats per wave instruction
-      const __amdgpu_buffer_rsrc_t ra = gvd_rsrc(pa_t + (int64_t)kpos * lda_t);
 #pragma unroll
-      for (int i = 0; i < NLD; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)&As[buf * A_STRIDE + (2 * wv + 8 * i) * TLD],
-                                                 16, sg.voa[i], 0, 0, 0);
-    } else {
+    for (int i = 0; i < NLD; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(sg.ra, (__attribute__((address_space(3))) void*)&As[buf * A_STRIDE + (8 * wv + 32 * i) * DLD],
+                                               16, sg.voa[i], so, 0, 0);
 #pragma unroll
-      for (int i = 0; i < NLD; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(sg.ra, (__attribute__((address_space(3))) void*)&As[buf * A_STRIDE + (8 * wv + 32 * i) * DLD],
-                                                 16, sg.voa[i], so, 0, 0);
-    }
-    if (BT) {
-      const __amdgpu_buffer_rsrc_t rw = gvd_rsrc(pw_t + (int64_t)kpos * ldw_t);
-#pragma unroll
-      for (int i = 0; i < NLD; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)&Ws[buf * W_STRIDE + (2 * wv + 8 * i) * TLD],
-                                                 16, sg.vow[i], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NLD; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(sg.rw, (__attribute__((address_space(3))) void*)&Ws[buf * W_STRIDE + (8 * wv + 32 * i) * DLD],
-                                                 16, sg.vow[i], so, 0, 0);
-    }
+    for (int i = 0; i < NLD; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(sg.rw, (__attribute__((address_space(3))) void*)&Ws[buf * W_STRIDE + (8 * wv + 32 * i) * DLD],
+                                               16, sg.vow[i], so, 0, 0);
     kpos += BK;
     if (kpos == kend && seg + 1 < nseg) {
       ++seg;
@@ -259,38 +213,18 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   static_assert(BK * LDT <= BM * LDK, "a K-strided tile fits the operand buffer");
   const float* Afr = AT ? &As[half * 4 * LDT + rb + r] : &As[(rb + r) * LDK + half * 4];
   const float* Wfr = BT ? &Ws[half * 4 * LDT + cb + r] : &Ws[(cb + r) * LDK + half * 4];
-  // DMA layouts.  Plain tile: k-chunk 2 q + half of row m sits in slot (2 q + half) ^ (m & 7); rb / cb are multiples of
-  // 32, so m & 7 = r & 7.  K-strided tile: value (k row j = 8 q + 4 half + t, column m) sits at j * 128 +
-  // 4 ((m / 4) ^ 8 ((j / 4) & 1)) + m % 4, and (j / 4) & 1 = half.
-  const float* Adm = AT ? &As[half * 4 * TLD + ((((rb + r) >> 2) ^ (half * 8)) << 2) + (r & 3)] : &As[(rb + r) * DLD];
-  const float* Wdm = BT ? &Ws[half * 4 * TLD + ((((cb + r) >> 2) ^ (half * 8)) << 2) + (r & 3)] : &Ws[(cb + r) * DLD];
-  // (second 32-wide block of the wave: +32 columns = +8 chunks, same swizzle bit)
-  const int adm1 = AT ? (((((rb + r) >> 2) + 8) ^ (half * 8)) << 2) - ((((rb + r) >> 2) ^ (half * 8)) << 2) : 32 * DLD;
-  const int wdm1 = BT ? (((((cb + r) >> 2) + 8) ^ (half * 8)) << 2) - ((((cb + r) >> 2) ^ (half * 8)) << 2) : 32 * DLD;
+  // DMA layout of a plain tile: k-chunk 2 q + half of row m sits in slot (2 q + half) ^ (m & 7); rb / cb are multiples of
+  // 32, so m & 7 = r & 7.
+  const float* Adm = &As[(rb + r) * DLD];
+  const float* Wdm = &Ws[(cb + r) * DLD];
   const int rsw = r & 7;
   auto frags = [&](f32x4 (&a)[2], f32x4 (&b)[2], int buf, int q) {
     if (DMA) {
       const int so4 = ((2 * q + half) ^ rsw) * 4;
-      if (AT) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          a[0][t] = Adm[buf * A_STRIDE + (q * 8 + t) * TLD];
-          a[1][t] = Adm[buf * A_STRIDE + (q * 8 + t) * TLD + adm1];
-        }
-      } else {
-        a[0] = *reinterpret_cast<const f32x4*>(Adm + buf * A_STRIDE + so4);
-        a[1] = *reinterpret_cast<const f32x4*>(Adm + buf * A_STRIDE + adm1 + so4);
-      }
-      if (BT) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          b[0][t] = Wdm[buf * W_STRIDE + (q * 8 + t) * TLD];
-          b[1][t] = Wdm[buf * W_STRIDE + (q * 8 + t) * TLD + wdm1];
-        }
-      } else {
-        b[0] = *reinterpret_cast<const f32x4*>(Wdm + buf * W_STRIDE + so4);
-        b[1] = *reinterpret_cast<const f32x4*>(Wdm + buf * W_STRIDE + wdm1 + so4);
-      }
+      a[0] = *reinterpret_cast<const f32x4*>(Adm + buf * A_STRIDE + so4);
+      a[1] = *reinterpret_cast<const f32x4*>(Adm + buf * A_STRIDE + 32 * DLD + so4);
+      b[0] = *reinterpret_cast<const f32x4*>(Wdm + buf * W_STRIDE + so4);
+      b[1] = *reinterpret_cast<const f32x4*>(Wdm + buf * W_STRIDE + 32 * DLD + so4);
       __builtin_amdgcn_sched_barrier(0);
       return;
     }
@@ -363,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
   frags(a0, b0, 0, 0);
 #pragma unroll 1
   for (int kt = 0; kt + 1 < nkt; ++kt) {
-    if (!(GVD_PIPE_ABL & 4)) fetch();          // tile kt+1: in flight under the first three quarters
+    fetch();                                   // tile kt+1: in flight under the first three quarters
     frags(a1, b1, buf, 1);
     mfma16(a0, b0);
     frags(a0, b0, buf, 2);
@@ -374,10 +308,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       mfma4(a0, b0, t);
-      if (!(GVD_PIPE_ABL & 2)) stage_part(buf ^ 1, t);
+      stage_part(buf ^ 1, t);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!(GVD_PIPE_ABL & 1)) __syncthreads();
+    __syncthreads();
     frags(a0, b0, buf ^ 1, 0);
     mfma16(a1, b1);
     buf ^= 1;
@@ -397,17 +331,6 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
     mfma16(a1, b1);
   }
 
-  if (GVD_PIPE_ABL & 8) {       // keep the accumulators alive without storing a tile
-    float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
-    if (sacc == 12345.678f) p.C[0] = sacc;
-    return;
-  }
   if (!EPI_LDS) {
     // (narrow tiles: the wave's second row block is not part of the tile - push it past M so nothing is stored)
     if (narrow) gemm_epilogue_plain<1, 2>(p, M, reinterpret_cast<const f32x16(&)[1][2]>(acc[0]), bz, m0 + rb, n0 + cb, r, half);
@@ -464,7 +387,7 @@ int pipe_launch_t(const KParams& p, dim3 grid, bool lds_epi, hipStream_t st) {
 }
 }  // namespace
 
-bool gvd_gemm_pipe_takes_ktail() { return GVD_PIPE_LDSDMA != 0; }
+bool gvd_gemm_pipe_takes_ktail() { return true; }
 
 // ---- measurement hook (bench.py `roofline_mfma`): while armed, every pipelined-GEMM launch is bracketed by an event pair on
 // its stream and a one-thread kernel adds the launch's flops - 2 x rows x N x K x batch with the DEVICE-side row count where

@@ -305,8 +305,7 @@ extern "C" int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const 
     void* args[] = {&p};
     // cooperative launch in both modes: it validates that all workgroups are co-resident.
     // More than 64 rows (3+ batch tiles): 16 hidden units per workgroup, the tiles dealt to up to 4 groups of 64
-    // workgroups; otherwise 8 units per workgroup and up to 2 groups of 128 (GVD_GRU_HU=8 / 16 forces one form).
-    static const int hu_env = getenv("GVD_GRU_HU") ? atoi(getenv("GVD_GRU_HU")) : 0;
+    // workgroups; otherwise 8 units per workgroup and up to 2 groups of 128.
     // The hand-rolled barrier form is launched PLAINLY after an explicit co-residency check (gvd_grid_fits; the cooperative
     // path costs a ~12 us dispatch gap on either side of the kernel; GVD_COOP_LAUNCH=1 restores it); the library grid sync
     // needs the cooperative launch.
@@ -317,7 +316,7 @@ extern "C" int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const 
       if (!gvd_grid_fits(f, 256, (int)nwg)) return hipErrorCooperativeLaunchTooLarge;
       return hipLaunchKernel(f, dim3(nwg), dim3(256), args, 0, st);
     };
-    const bool wide = hu_env ? hu_env == 16 : nb > 64;
+    const bool wide = nb > 64;
     const int ntiles = (nb + 31) / 32;
     hipError_t e;
     if (wide) {

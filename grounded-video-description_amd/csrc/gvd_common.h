@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <mutex>
 #include "../../include/gvd_hip.h"
 
 #define GVD_WAVE 64
@@ -103,6 +105,8 @@ typedef unsigned gvd_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int GVD_SYNC_GROUPS = 16;
 constexpr int GVD_SYNC_WORDS = 64 + 2 * 32 * GVD_SYNC_GROUPS;   // uint32 words of one barrier object (zeroed by the host)
 constexpr int GVD_SYNC_ERR = 32;                                // word raised when a bounded spin ran out
+constexpr int GVD_SYNC_LIMIT = 33;                              // optional spin-limit override (0 = GVD_SPIN_LIMIT); test aid:
+                                                                // the host writes it when the environment sets GVD_SPIN_LIMIT
 constexpr unsigned GVD_SPIN_LIMIT = 4000000u;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gvd_rsrc(const void* base) {
@@ -146,10 +150,14 @@ __device__ __forceinline__ void grid_barrier_tree(unsigned* sync, unsigned round
                              __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    unsigned spins = 0;
+    unsigned spins = 0, limit = GVD_SPIN_LIMIT;
     while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round + 1) {
+      if (spins == 0) {          // (slow path only: a workgroup that has to wait reads the override once per barrier)
+        const unsigned o = __hip_atomic_load(sync + GVD_SYNC_LIMIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (o) limit = o;
+      }
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > GVD_SPIN_LIMIT) {
+      if (++spins > limit) {
         __hip_atomic_store(sync + GVD_SYNC_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         dead = true;
         break;
@@ -163,11 +171,13 @@ __device__ __forceinline__ void grid_barrier_tree(unsigned* sync, unsigned round
 // a cooperative launch makes; the persistent kernels are launched PLAINLY after it - the cooperative path costs a ~12 us
 // dispatch gap before and after every such kernel, 0.1 ms of a 3 ms batch_size = 4 call - and bound their barrier spins.)
 static inline bool gvd_grid_fits(const void* fn, int block, int grid) {
-  // (per translation unit: a few entries, answers never change for a (kernel, block) pair on one device type; a racing
-  // first call computes the same value twice)
+  // (per translation unit: a few entries, answers never change for a (kernel, block) pair on one device type; concurrent
+  // first calls - two host threads driving two streams - are serialised by the mutex)
   struct Entry { const void* fn; int block; long slots; };
   static Entry cache[8] = {};
   static int used = 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
   for (int i = 0; i < used; ++i)
     if (cache[i].fn == fn && cache[i].block == block) return cache[i].slots >= grid;
   int dev = 0, cus = 0, per = 0;
@@ -177,6 +187,17 @@ static inline bool gvd_grid_fits(const void* fn, int block, int grid) {
   const long slots = (long)per * cus;
   if (used < 8) { cache[used].fn = fn; cache[used].block = block; cache[used].slots = slots; ++used; }
   return slots >= grid;
+}
+
+// GVD_SPIN_LIMIT (environment, test aid): spin-limit override the host writes into word GVD_SYNC_LIMIT of a barrier object
+// (0 = unset).  tests force 1 to exercise the timeout -> status word -> fallback path without a shared GPU.
+static inline unsigned gvd_spin_limit_env() {
+  static const unsigned v = [] {
+    const char* e = getenv("GVD_SPIN_LIMIT");
+    const long x = e ? atol(e) : 0;
+    return x > 0 ? (unsigned)x : 0u;
+  }();
+  return v;
 }
 
 // event-pair recorder (prof.hip); no-ops when p == nullptr

@@ -235,8 +235,11 @@ class GradAllReducer:
             word[0] = 1
         if status is not None:
             word[1:] = status.to(device=dev, dtype=torch.int32).reshape(-1)
-        wh = dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        # the status word goes LAST: the number of buckets a rank's hooks launched during backward depends on which of its
+        # parameters got a gradient (one that lacks it locally holds its bucket back until here), so only "after every
+        # bucket" is the same position in the collective sequence on every rank
         self._launch_ready(force=True)
+        wh = dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         self._drain()
         wh.wait()
         self._late = False

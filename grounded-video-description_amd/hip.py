@@ -71,7 +71,7 @@ class GreedyArgs(C.Structure):
                 ('att2_h2att_w', c_f32p), ('att2_h2att_b', c_f32p), ('att2_alpha_w', c_f32p), ('att2_alpha_b', c_f32p),
                 ('logit_w', c_f32p), ('logit_b', c_f32p),
                 ('B', C.c_int), ('Ft', C.c_int), ('R', C.c_int), ('H', C.c_int), ('A', C.c_int), ('E', C.c_int),
-                ('V', C.c_int), ('L', C.c_int), ('unk_idx', C.c_int),
+                ('V', C.c_int), ('L', C.c_int), ('unk_idx', C.c_int), ('no_persistent', C.c_int),
                 ('seq', c_i64p), ('seq_logprobs', c_f32p), ('att2_weights', c_f32p), ('workspace', C.c_void_p),
                 ('prof', C.c_void_p), ('status', C.c_void_p), ('trace', C.c_void_p)]
 
@@ -124,18 +124,18 @@ _SIG = {
                                                   C.c_float, C.c_uint64, C.c_void_p]),
     'gvd_add_layernorm_unbiased_drop_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64,
                                                       C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
-    'gvd_enc_softmax_dropout_fwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
-                                              C.c_uint64, c_f32p, C.c_int, C.c_void_p]),
-    'gvd_enc_softmax_dropout_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
-                                              C.c_void_p]),
+    'gvd_flash_attn_train_fwd_f32': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, C.c_float, c_f32p, C.c_float, C.c_uint64, C.c_void_p]),
+    'gvd_enc_attn_bwd_maps': (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64,
+                                        C.c_void_p]),
+    'gvd_enc_dropout_mask': (C.c_int, [c_u8p, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_void_p]),
     'gvd_region_feature_rows': (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int64, c_u8p, C.c_int64, C.c_int64,
                                           c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_void_p, C.c_int, C.c_float,
                                           C.c_void_p]),
     'gvd_region_feature_rows_bwd': (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_u8p, C.c_int64, C.c_int64,
                                               c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64,
                                               C.c_int, C.c_float, C.c_void_p]),
-    'gvd_flash_attn_f32': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int64, C.c_int,
-                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
     'gvd_flash_attn_padded_f32': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int,
                                             C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'gvd_compact_index': (C.c_int, [c_u8p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -194,7 +194,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 14        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 15        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

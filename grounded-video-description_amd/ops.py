@@ -308,6 +308,7 @@ def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None, flags=None):
     a.B, a.Ft, a.R, a.H, a.A, a.E, a.V, a.L, a.unk_idx = B, Ft, R, H, A, E, V, L, unk_idx
     a.seq, a.seq_logprobs, a.att2_weights, a.workspace = ptr(seq), ptr(lps), ptr(att2), ptr(ws)
     a.prof = prof.h if prof is not None else None
+    a.no_persistent = 0 if _persistent['on'] else 1
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     a.status = ptr(status)
     trace = None
@@ -401,7 +402,6 @@ def relu_dropout_bwd(dy, y, p_drop):
     return dz, parts.sum(0)
 
 
-FUSED_TRAIN_ELEMENTWISE = os.environ.get('GVD_TRAIN_FUSED_ELEMENTWISE', '1') == '1'   # A/B knob (0: the ATen passes)
 
 
 class _LinearFn(torch.autograd.Function):
@@ -424,7 +424,7 @@ class _LinearFn(torch.autograd.Function):
         x, w, out = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
         db = None
-        fused = (ctx.act and FUSED_TRAIN_ELEMENTWISE and dy2.shape[-1] % 4 == 0 and dy2.data_ptr() % 16 == 0)
+        fused = ctx.act and dy2.shape[-1] % 4 == 0 and dy2.data_ptr() % 16 == 0
         if fused:
             dy2, db = relu_dropout_bwd(dy2.contiguous(), out.reshape(-1, out.shape[-1]), ctx.p_drop)
         else:
@@ -684,6 +684,32 @@ def attn_bwd_pfeats(p_feats, q_all, de_all, w):
 
 GRU_BARRIER = os.environ.get('GVD_GRU_BARRIER', 'counter')   # 'counter' (hand-rolled) | 'cg' (library grid sync)
 
+# Process-wide switch of the persistent kernels with the hand-rolled grid barrier (greedy decoder batch_size <= 4, bi-GRU
+# recurrence).  They need all their workgroups co-resident; on a GPU shared with other work a barrier spin can run out
+# (status word raised, results invalid).  The first such timeout turns them off for the rest of the process - a property
+# of the device the process runs on, not of one model: the decoder then runs its kernel-per-op loop, the GRU its
+# cooperative launch with the library grid sync - and the caller recomputes (att_model.TopDownModel.forward, train.Trainer).
+_persistent = {'on': True, 'timeouts': 0}
+
+
+def persistent_kernels_enabled():
+    return _persistent['on']
+
+
+def disable_persistent_kernels(n_timeouts=1):
+    _persistent['timeouts'] += int(n_timeouts)
+    if _persistent['on']:
+        _persistent['on'] = False
+        import warnings
+        warnings.warn('libgvd_hip: %d persistent-kernel launch(es) hit a grid-barrier timeout (workgroups not co-resident: '
+                      'a shared GPU?); recomputing and continuing on the kernel-per-op decoder / the cooperative GRU launch '
+                      'for the rest of this process' % n_timeouts, RuntimeWarning, stacklevel=3)
+
+
+def _spin_limit_env():
+    v = os.environ.get('GVD_SPIN_LIMIT')          # test aid: forced barrier timeouts (csrc/gvd_common.h GVD_SYNC_LIMIT)
+    return int(v) if v and int(v) > 0 else 0
+
 
 def gru_layer(gi, w_f, b_f, w_b, b_b, B, T, Hh, flags=None, barrier=None):
     """The recurrence of one bidirectional GRU layer as ONE persistent cooperative kernel (gvd_gru_bidir_layer).
@@ -693,8 +719,12 @@ def gru_layer(gi, w_f, b_f, w_b, b_b, B, T, Hh, flags=None, barrier=None):
     assert gi.is_contiguous() and w_f.is_contiguous() and w_b.is_contiguous() and b_f.is_contiguous() and b_b.is_contiguous()
     out = torch.empty(B, T, 2 * Hh, device=gi.device, dtype=torch.float32)
     sync = None
-    if (barrier or GRU_BARRIER) == 'counter':
+    if barrier is None:
+        barrier = GRU_BARRIER if _persistent['on'] else 'cg'
+    if barrier == 'counter':
         sync = torch.zeros(lib().gvd_grid_sync_words() * ((B + 255) // 256), dtype=torch.int32, device=gi.device)
+        if _spin_limit_env():
+            sync.view(-1, lib().gvd_grid_sync_words())[:, 33] = _spin_limit_env()
     check(lib().gvd_gru_bidir_layer(ptr(gi), ptr(w_f), ptr(b_f), ptr(w_b), ptr(b_b), ptr(out), B, T, Hh,
                                     ptr(sync), stream_ptr()), 'gvd_gru_bidir_layer')
     gru_layer.last_sync = sync
@@ -820,22 +850,6 @@ def add_layernorm(x, y, gamma, beta, eps=1e-6, p_drop=0.0):
     return add_layernorm_unbiased(x.contiguous(), y.contiguous(), gamma.detach(), beta.detach(), eps)
 
 
-TRAIN_HEAD_PAD = 192      # training attention core: heads zero-padded to a multiple of the GEMM's 32-deep k tile
-
-
-def train_head_pad(B, Rp, n_heads):
-    """Head slot width of the training attention core: 176 columns as in inference (8 % fewer flops in the q|k|v / wo
-    projections and the six attention products than 192-column slots) whenever every product of the launch runs on the
-    pipelined GEMM, whose K-tail-of-16 path (csrc/gemm_pipe.hip: the last k tile is fetched shifted back by 16 columns and
-    only its last two quarters are multiplied) takes the K = 176 contractions; 192 (six whole 32-deep k tiles) for small
-    launches that run on the general kernel.  Verified on the device against the 192-slot form
-    (tests/test_gpu_kernels.py::test_enc_attn_core_176_column_head_slots) and by the reference gradient goldens.
-    GVD_TRAIN_HEAD_PAD=192 forces the wide slots."""
-    if os.environ.get('GVD_TRAIN_HEAD_PAD', '176') == '176' and B * n_heads * (-(-Rp // 128)) ** 2 >= 256:
-        return 176
-    return TRAIN_HEAD_PAD
-
-
 def _bgemm(A, a_off, lda, a_bs, W, w_off, ldw, w_bs, K, Cout, c_off, ldc, c_bs, M, N, batch, a_t=0, w_t=0, what='bgemm',
            inner=0, a_is=0, w_is=0, c_is=0):
     """One batched launch of the MFMA GEMM on sub-blocks of larger tensors (element offsets into A / W / Cout).
@@ -854,23 +868,30 @@ def _bgemm(A, a_off, lda, a_bs, W, w_off, ldw, w_bs, K, Cout, c_off, ldc, c_bs, 
 def _heads_bgemm(nh, A, a_off, lda, a_bs, a_hs, W, w_off, ldw, w_bs, w_hs, K, Cout, c_off, ldc, c_bs, c_hs, M, N, B, a_t=0,
                  w_t=0, what='bgemm'):
     """The same product for every (sample, head): ONE launch over the two-level batch B x nh (heads live at stride *_hs
-    inside the sample's block) — or, with GVD_ENC_HEADS_MERGED=0, one launch per head over the B samples."""
-    if os.environ.get('GVD_ENC_HEADS_MERGED', '1') == '1':
-        _bgemm(A, a_off, lda, a_bs, W, w_off, ldw, w_bs, K, Cout, c_off, ldc, c_bs, M, N, B * nh, a_t=a_t, w_t=w_t, what=what,
-               inner=nh, a_is=a_hs, w_is=w_hs, c_is=c_hs)
-        return
-    for h in range(nh):
-        _bgemm(A, a_off + h * a_hs, lda, a_bs, W, w_off + h * w_hs, ldw, w_bs, K, Cout, c_off + h * c_hs, ldc, c_bs, M, N, B,
-               a_t=a_t, w_t=w_t, what=what)
+    inside the sample's block)."""
+    _bgemm(A, a_off, lda, a_bs, W, w_off, ldw, w_bs, K, Cout, c_off, ldc, c_bs, M, N, B * nh, a_t=a_t, w_t=w_t, what=what,
+           inner=nh, a_is=a_hs, w_is=w_hs, c_is=c_hs)
+
+
+def enc_dropout_mask(n_maps, Rp, p_drop, seed, device='cuda'):
+    """Test aid: the keep mask of the training attention core's dropout for `seed`, u8 [n_maps, Rp, Rp]."""
+    out = torch.empty(n_maps, Rp, Rp, dtype=torch.uint8, device=device)
+    check(lib().gvd_enc_dropout_mask(ptr(out), n_maps, Rp, float(p_drop), seed, stream_ptr()), 'gvd_enc_dropout_mask')
+    return out
 
 
 class _EncAttnCoreFn(torch.autograd.Function):
     """Self-attention core of one encoder layer on the training path (transformer.py:90-117): per head
-    softmax(Q K^T / sqrt(d)) -> dropout -> @ V, all six products of forward + backward on the pipelined fp32-MFMA GEMM
-    over zero-padded operands, softmax + dropout (and their backward) as one row kernel each (csrc/enc_attn_train.hip).
+    softmax(Q K^T / sqrt(d)) -> dropout -> @ V.
 
-    qkv: [B, Rp, 3 * nh * HP] (packed q | k | v, heads padded to HP columns, Rp % 32 == 0; the pad rows R..Rp-1 may hold
-    anything finite).  Returns O [B, Rp, nh * HP] (pad rows zero)."""
+    Forward: the flash-style kernel of the inference path in its training form (csrc/flash_attn_pad.hip: dropout on the
+    probabilities in registers, per-key bias, logsumexp written out) - no [B, heads, Rp, Rp] map is written or kept.
+    Backward: ONE kernel recomputes the probabilities tile by tile from Q K^T and the saved logsumexp next to dO V^T and
+    writes the two maps the remaining products need (csrc/enc_attn_bwd.hip: Pd for dV = Pd^T dO, dS for dQ = dS K and
+    dK = dS^T Q, on the pipelined fp32-MFMA GEMM with K-strided operands); the maps live for the duration of this call.
+
+    qkv: [B, Rp, 3 * nh * HP] (packed q | k | v, heads padded to HP = 176 columns, Rp % 32 == 0; the pad rows R..Rp-1 may
+    hold anything finite).  Returns O [B, Rp, nh * HP] (pad rows zero)."""
 
     @staticmethod
     def forward(ctx, qkv, R, nh, scale, p_drop, seed, key_bias=None):
@@ -878,54 +899,44 @@ class _EncAttnCoreFn(torch.autograd.Function):
         assert qkv.is_contiguous()
         B, Rp, W3 = qkv.shape
         HP = W3 // (3 * nh)
-        assert W3 == 3 * nh * HP and HP % 16 == 0 and Rp % 32 == 0 and R % 4 == 0 and 4 <= R <= Rp
+        assert W3 == 3 * nh * HP and HP == HEAD_PAD and Rp % 32 == 0 and R % 4 == 0 and 4 <= R <= Rp
         dev = qkv.device
-        Y = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
-        ko, vo = nh * HP, 2 * nh * HP
-        # S_h = Q_h K_h^T for all (sample, head) pairs
-        _heads_bgemm(nh, qkv, 0, W3, Rp * W3, HP, qkv, ko, W3, Rp * W3, HP, HP, Y, 0, Rp, nh * Rp * Rp, Rp * Rp, R, R, B,
-                     what='QK^T')
-        Pd = torch.empty_like(Y) if p_drop > 0 else None
         if key_bias is not None:       # compacted layout: per-sample key weights (train_compact.py)
             assert key_bias.shape == (B, Rp) and key_bias.is_contiguous()
-        check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y), ptr(Pd), B * nh, Rp, R, scale, p_drop, seed, ptr(key_bias), nh,
-                                                stream_ptr()), 'gvd_enc_softmax_dropout_fwd')
-        P = Pd if Pd is not None else Y
-        # (the product writes all nh * HP columns of the R live rows: only the pad rows need zeros)
+        # (the kernel writes all nh * HP columns of the R live rows: only the pad rows need zeros)
         O = torch.empty(B, Rp, nh * HP, device=dev, dtype=torch.float32)
         if Rp > R:
             O[:, R:].zero_()
-        # O_h = Pd_h V_h   (V consumed in place as a K-strided operand)
-        _heads_bgemm(nh, P, 0, Rp, nh * Rp * Rp, Rp * Rp, qkv, vo, W3, Rp * W3, HP, Rp, O, 0, nh * HP, Rp * nh * HP, HP, R, HP,
-                     B, w_t=1, what='PV')
-        ctx.save_for_backward(qkv, Y, Pd)
-        ctx.cfg = (R, nh, scale, p_drop)
+        lse = torch.empty(B * nh, Rp, device=dev, dtype=torch.float32)
+        check(lib().gvd_flash_attn_train_fwd_f32(ptr(qkv), W3, ptr(O), nh * HP, ptr(lse), B, Rp, R, nh, HP, scale,
+                                                 ptr(key_bias), p_drop, seed, stream_ptr()), 'gvd_flash_attn_train_fwd_f32')
+        ctx.save_for_backward(qkv, O, lse, key_bias)
+        ctx.cfg = (R, nh, scale, p_drop, seed)
         return O
 
     @staticmethod
     def backward(ctx, dO):
-        qkv, Y, Pd = ctx.saved_tensors
-        R, nh, scale, p_drop = ctx.cfg
+        qkv, O, lse, key_bias = ctx.saved_tensors
+        R, nh, scale, p_drop, seed = ctx.cfg
         B, Rp, W3 = qkv.shape
         HP = W3 // (3 * nh)
         dO = dO.contiguous()
         dev = qkv.device
         ko, vo = nh * HP, 2 * nh * HP
-        P = Pd if Pd is not None else Y
+        delta = torch.empty(B * nh, Rp, device=dev, dtype=torch.float32)
+        Pd = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
         dS = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
+        check(lib().gvd_enc_attn_bwd_maps(ptr(qkv), W3, ptr(dO), ptr(O), nh * HP, ptr(lse), ptr(key_bias), ptr(delta),
+                                          ptr(Pd), ptr(dS), B, Rp, R, nh, HP, scale, p_drop, seed, stream_ptr()),
+              'gvd_enc_attn_bwd_maps')
         # (the dQ / dK / dV products below write all 3 * nh * HP columns of the R live rows: only the pad rows need zeros)
         dqkv = torch.empty_like(qkv)
         if Rp > R:
             dqkv[:, R:].zero_()
         mb, ms = nh * Rp * Rp, Rp * Rp
-        # dPd_h = dO_h V_h^T
-        _heads_bgemm(nh, dO, 0, nh * HP, Rp * nh * HP, HP, qkv, vo, W3, Rp * W3, HP, HP, dS, 0, Rp, mb, ms, R, R, B,
-                     what='dO V^T')
         # dV_h = Pd_h^T dO_h   (both operands K-strided; pad rows of Pd are zero)
-        _heads_bgemm(nh, P, 0, Rp, mb, ms, dO, 0, nh * HP, Rp * nh * HP, HP, Rp, dqkv, vo, W3, Rp * W3, HP, R, HP, B,
+        _heads_bgemm(nh, Pd, 0, Rp, mb, ms, dO, 0, nh * HP, Rp * nh * HP, HP, Rp, dqkv, vo, W3, Rp * W3, HP, R, HP, B,
                      a_t=1, w_t=1, what='P^T dO')
-        check(lib().gvd_enc_softmax_dropout_bwd(ptr(dS), ptr(Pd), ptr(Y), B * nh, Rp, R, scale, p_drop, stream_ptr()),
-              'gvd_enc_softmax_dropout_bwd')
         # dQ_h = dS_h K_h ;  dK_h = dS_h^T Q_h
         _heads_bgemm(nh, dS, 0, Rp, mb, ms, qkv, ko, W3, Rp * W3, HP, Rp, dqkv, 0, W3, Rp * W3, HP, R, HP, B, w_t=1,
                      what='dS K')
@@ -934,10 +945,12 @@ class _EncAttnCoreFn(torch.autograd.Function):
         return dqkv, None, None, None, None, None, None
 
 
-def enc_attn_core(qkv, R, n_heads, scale, p_drop=0.0, key_bias=None):
-    """See _EncAttnCoreFn.  The dropout seed is drawn from torch's CPU generator (reproducible under torch.manual_seed).
-    key_bias: optional f32 [B, Rp] added to every query's scaled scores of a key (the compacted training layout)."""
-    seed = draw_seed() if p_drop > 0 else 0
+def enc_attn_core(qkv, R, n_heads, scale, p_drop=0.0, key_bias=None, seed=None):
+    """See _EncAttnCoreFn.  The dropout seed is drawn from torch's CPU generator (reproducible under torch.manual_seed)
+    unless given.  key_bias: optional f32 [B, Rp] added to every query's scaled scores of a key (the compacted training
+    layout)."""
+    if seed is None:
+        seed = draw_seed() if p_drop > 0 else 0
     return _EncAttnCoreFn.apply(qkv, R, n_heads, scale, float(p_drop), seed, key_bias)
 
 
@@ -1029,20 +1042,6 @@ def region_feature_rows_compact(g_pool, loc, sim_logits, row_mask, rows_dev, pad
                                         ptr(out), K, ptr(sim), M, ptr(rows_dev), G, ln_eps, stream_ptr()),
           'gvd_region_feature_rows(compact)')
     return out, sim
-
-
-def flash_attn_heads(q, k, v, head_sizes):
-    """o[..., head h] = softmax(q_h k_h^T) v_h for the column chunks `head_sizes` (q pre-scaled); q,k,v [B,R,D]."""
-    require_cuda_f32(q, k, v)
-    B, R, D = q.shape
-    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and sum(head_sizes) == D
-    o = torch.empty_like(q)
-    n = len(head_sizes)
-    c0 = (C.c_int * n)(*[sum(head_sizes[:i]) for i in range(n)])
-    w = (C.c_int * n)(*head_sizes)
-    check(lib().gvd_flash_attn_f32(ptr(q), ptr(k), ptr(v), ptr(o), B, R, D, n, c0, w, stream_ptr()),
-          'gvd_flash_attn_f32')
-    return o
 
 
 HEAD_PAD = 176      # padded head width of the fused obj_interact attention (11 MFMA k-blocks of 16)

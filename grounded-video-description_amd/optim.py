@@ -124,6 +124,11 @@ class ClipAdam(torch.optim.Adam):
             for g in self._launches(items):
                 check(lib().gvd_adam_step(C.byref(g), ptr(clip), ptr(skip), 0 if skip is None else skip.numel(), b1, b2, eps,
                                           wd, stream_ptr()), 'gvd_adam_step')
+        # the kernels wrote p / exp_avg / exp_avg_sq through raw pointers: tell autograd's version counters, as torch's
+        # in-place Adam does - anything keyed on `_version` (att_model._packed: the re-laid-out inference weights; saved
+        # tensors of a retained graph) must see that the parameters changed
+        torch.autograd.graph.increment_version([t for p, _, _ in live
+                                                for t in (p, self.state[p]['exp_avg'], self.state[p]['exp_avg_sq'])])
         return None if clip is None else clip[0]
 
     def rollback_step_counts(self):

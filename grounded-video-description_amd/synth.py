@@ -109,53 +109,64 @@ def init_state_dict(opt, seed=0, profile='default'):
     return sd
 
 
-def make_inputs(opt, batch_size, seed=0, train=True, t_attn_size=None, max_boxes=8, max_cap_len=None):
+def make_inputs(opt, batch_size, seed=0, train=True, t_attn_size=None, max_boxes=8, max_cap_len=None, device=None):
     """Synthetic batch with the exact dtypes/shapes main.py hands to `model(...)`.
 
     Returns a dict of CPU tensors: segs_feat f32[B,Ft,3072], seq i64[B,1,L+1,4], gt_seq i64[B,10,L],
     num i64[B,7], ppls f32[B,R,7], gt_boxes f32[B,NB,6], mask_boxes u8[B,1,NB,L+1],
     ppls_feat f32[B,R,2048], frm_mask u8[B,R,NB], sample_idx i64[B,2], pnt_mask u8[B,R+1].
     With `train=False` the training-only tensors are the `[B]` uint8 dummies main.py:353 passes.
+
+    device (train=False only): generate ON that device with its own generator - same distributions, other values than the
+    CPU stream (whose seeds the committed reference cases are keyed on).  For ranks that only need a workload: 8 ranks
+    drawing 2.1 GB of host normals each with cpu_count / 8 threads cost minutes of a multi-GPU lease.
     """
-    g = torch.Generator().manual_seed(7919 * (seed + 1) + batch_size)
+    if device is not None and torch.device(device).type != 'cpu':
+        assert not train, 'device-side generation covers the inference inputs only'
+        dev = torch.device(device)
+        g = torch.Generator(device=dev).manual_seed(7919 * (seed + 1) + batch_size)
+    else:
+        dev = torch.device('cpu')
+        g = torch.Generator().manual_seed(7919 * (seed + 1) + batch_size)
     B = batch_size
     T, P = opt.num_sampled_frm, opt.num_prop_per_frm
     R = T * P
     Ft = opt.t_attn_size if t_attn_size is None else t_attn_size
     L, V, D = opt.seq_length, opt.vocab_size, opt.detect_size
+    kw = dict(generator=g, device=dev)
 
     # proposals: x1,y1,x2,y2,frame,cls,score (dataloader_anet.py:188-194); masked rows zeroed (343-344)
-    x1 = torch.rand(B, R, generator=g) * 500.0
-    y1 = torch.rand(B, R, generator=g) * 500.0
-    w = 5.0 + torch.rand(B, R, generator=g) * 200.0
-    h = 5.0 + torch.rand(B, R, generator=g) * 200.0
-    frame = (torch.arange(R) // P).float().unsqueeze(0).expand(B, R)
-    cls = torch.randint(0, 1601, (B, R), generator=g).float()
-    score = torch.rand(B, R, generator=g)
+    x1 = torch.rand(B, R, **kw) * 500.0
+    y1 = torch.rand(B, R, **kw) * 500.0
+    w = 5.0 + torch.rand(B, R, **kw) * 200.0
+    h = 5.0 + torch.rand(B, R, **kw) * 200.0
+    frame = (torch.arange(R, device=dev) // P).float().unsqueeze(0).expand(B, R)
+    cls = torch.randint(0, 1601, (B, R), **kw).float()
+    score = torch.rand(B, R, **kw)
     ppls = torch.stack([x1, y1, x1 + w, y1 + h, frame, cls, score], dim=2).contiguous()
     ppl_mask = (score <= opt.prop_thresh)
     ppls = ppls.masked_fill(ppl_mask.unsqueeze(-1), 0.0)
-    ppls_feat = torch.relu(torch.randn(B, R, opt.att_feat_size, generator=g))
+    ppls_feat = torch.relu(torch.randn(B, R, opt.att_feat_size, **kw))
     ppls_feat = ppls_feat.masked_fill(ppl_mask.unsqueeze(-1), 0.0)
-    pnt_mask = torch.cat([torch.zeros(B, 1, dtype=torch.uint8), ppl_mask.to(torch.uint8)], dim=1)
+    pnt_mask = torch.cat([torch.zeros(B, 1, dtype=torch.uint8, device=dev), ppl_mask.to(torch.uint8)], dim=1)
 
-    segs_feat = torch.randn(B, Ft, opt.fc_feat_size, generator=g)
-    s0 = torch.randint(0, max(Ft // 2, 1), (B,), generator=g)
-    s1 = s0 + 1 + torch.randint(0, max(Ft - Ft // 2, 1), (B,), generator=g)
+    segs_feat = torch.randn(B, Ft, opt.fc_feat_size, **kw)
+    s0 = torch.randint(0, max(Ft // 2, 1), (B,), **kw)
+    s1 = s0 + 1 + torch.randint(0, max(Ft - Ft // 2, 1), (B,), **kw)
     sample_idx = torch.stack([s0, s1.clamp(max=Ft)], dim=1).long()
 
-    n_seg = torch.randint(2, 9, (B,), generator=g)
-    seg_idx = (torch.rand(B, generator=g) * n_seg.float()).long()
-    nb = torch.randint(3, max_boxes + 1, (B,), generator=g) if train else torch.zeros(B, dtype=torch.long)
+    n_seg = torch.randint(2, 9, (B,), **kw)
+    seg_idx = (torch.rand(B, **kw) * n_seg.float()).long()
+    nb = torch.randint(3, max_boxes + 1, (B,), **kw) if train else torch.zeros(B, dtype=torch.long, device=dev)
     # main.py:223,572 copy the float `num` into a LongTensor: the two timestamps truncate to 0/1
-    num = torch.stack([torch.ones(B, dtype=torch.long), torch.full((B,), R, dtype=torch.long), nb,
-                       seg_idx, n_seg, torch.zeros(B, dtype=torch.long),
-                       torch.randint(0, 2, (B,), generator=g)], dim=1)
+    num = torch.stack([torch.ones(B, dtype=torch.long, device=dev), torch.full((B,), R, dtype=torch.long, device=dev), nb,
+                       seg_idx, n_seg, torch.zeros(B, dtype=torch.long, device=dev),
+                       torch.randint(0, 2, (B,), **kw)], dim=1)
 
     out = dict(segs_feat=segs_feat, num=num, ppls=ppls, ppls_feat=ppls_feat,
                sample_idx=sample_idx, pnt_mask=pnt_mask)
     if not train:
-        dummy = torch.zeros(B, dtype=torch.uint8)
+        dummy = torch.zeros(B, dtype=torch.uint8, device=dev)
         out.update(seq=dummy, gt_seq=dummy, gt_boxes=dummy, mask_boxes=dummy, frm_mask=dummy)
         return out
 

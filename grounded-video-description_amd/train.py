@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import dist as gdist
+from . import ops
 
 
 def build_optimizer(model, opt):
@@ -25,13 +26,12 @@ def build_optimizer(model, opt):
     groups = [{'params': p, 'lr': opt.learning_rate * s, 'weight_decay': opt.weight_decay,
                'betas': (opt.optim_alpha, opt.optim_beta)} for p, s in ((rest, 1.0), (fine, 0.1)) if p]
     if opt.optim == 'adam':
-        on_gpu = all(p.is_cuda for g in groups for p in g['params'])
-        if on_gpu and os.environ.get('GVD_OWN_ADAM', '1') == '1':
-            # clip + Adam on the library's own multi-tensor kernels (optim.ClipAdam is a torch.optim.Adam: same state,
-            # same state_dict); GVD_OWN_ADAM=0: clip_grad_norm_ + torch's fused Adam
+        if all(p.is_cuda for g in groups for p in g['params']):
+            # clip + Adam on the library's own multi-tensor kernels (optim.ClipAdam IS a torch.optim.Adam: same state,
+            # same state_dict)
             from .optim import ClipAdam
             return ClipAdam(groups)
-        return torch.optim.Adam(groups, fused=True) if on_gpu else torch.optim.Adam(groups)
+        return torch.optim.Adam(groups)      # (CPU parameters: the control-flow tests)
     if opt.optim == 'sgd':
         return torch.optim.SGD(groups, momentum=0.9)
     if opt.optim == 'adamax':
@@ -71,19 +71,18 @@ class Trainer:
         training too: a grid-barrier timeout must not reach the optimizer silently) - MAX-reduced over the ranks together
         with the reducer's rediscovery flag, so that under data parallelism every rank raises (or rebuilds its buckets)
         in the same step instead of leaving its peers blocked in the next collective.  The gradient norm stays a device
-        tensor (clip_grad_norm_ scales on the device).  GVD_TRAIN_DEFER_STATUS=1 (own optimiser only): the read happens
-        AFTER clip + Adam were enqueued, predicated on the device by the same word (see _finish_step_deferred; measured:
-        92.86 vs 92.95 ms per batch_size = 64 step - the host is far enough ahead of the GPU for the read not to matter, so
-        the plain order stays the default)."""
+        tensor (the clip factor is computed and applied on the device)."""
         self.model.zero_grad(set_to_none=True)
         self.reducer.reset()
+        if hasattr(self.model, 'kernel_status_counts'):
+            # status words left behind by earlier inference calls through the private _sample (a caller that never checked
+            # them) are not this step's: they must neither fail it nor be mistaken for a compaction-contract violation
+            self.model.kernel_status_counts()
         losses = self.model(*args, 'MLE')
         loss = combine_losses(losses, self.opt)
         loss.backward()
         counts = self.model.kernel_status_counts() if hasattr(self.model, 'kernel_status_counts') else None
         own = hasattr(self.optimizer, 'step_clipped')
-        if own and os.environ.get('GVD_TRAIN_DEFER_STATUS', '0') == '1':
-            return self._finish_step_deferred(losses, loss, counts, args)
         if self.reducer.active:
             st = torch.zeros(2, dtype=torch.int32, device=loss.device) if counts is None else counts.to(torch.int32)
             word = self.reducer.finish(status=st, defer=True).tolist()          # the step's one host read
@@ -91,7 +90,7 @@ class Trainer:
             bad, contract = word[1], word[2]
         else:
             bad, contract = (0, 0) if counts is None else counts.tolist()       # the step's one host read
-        if contract and not bad and self._drop_train_compaction():
+        if self._recompute(bad, contract):
             return self.step(args)
         if bad or contract:
             self.model.raise_for_status(bad, contract)
@@ -104,6 +103,20 @@ class Trainer:
             self.optimizer.step()
         return torch.cat([l.detach() for l in losses])
 
+    def _recompute(self, bad, contract):
+        """The two conditions of a step a reference user never sees are COMPUTED, not raised (the status word is the same
+        on every rank, so every rank takes the same branch): a grid-barrier timeout of the persistent bi-GRU kernel (shared
+        GPU) switches the persistent kernels off for the process, masked proposals that are not zero rows switch the
+        compacted training layout off for this model; either way the caller runs the step again (forward + backward:
+        fresh dropout draws - the invalid attempt updated nothing)."""
+        again = False
+        if bad and ops.persistent_kernels_enabled():
+            ops.disable_persistent_kernels(bad)
+            again = True
+        if contract and self._drop_train_compaction():
+            again = True
+        return again
+
     def _drop_train_compaction(self):
         """A step on the compacted training layout (GVD_TRAIN_COMPACT=1, train_compact.py) met masked proposals that are
         not zero rows - inputs the reference accepts: compute, don't raise - switch this model to the full row set for
@@ -112,31 +125,3 @@ class Trainer:
             return False
         self.model._train_compact_off = True
         return True
-
-    def _finish_step_deferred(self, losses, loss, counts, args):
-        """Tail of a step with the library's own optimiser: clip + Adam are ENQUEUED first, predicated on the device by the
-        step's status word (kernel-status counts of the persistent kernels; under data parallelism the reducer's
-        MAX-reduced word: rediscovery flag + those counts), and only then does the host read that word - the step's one
-        host read no longer drains the queue in front of the optimiser, whose ~10 launches (and the host work of packing
-        them) used to run with the GPU idle.  A raised word means the device skipped the update: the step counters are
-        rolled back, and the host either raises (kernel error: same step on every rank) or - rediscovery of a late-used
-        parameter - lets the reducer rebuild its buckets and runs the optimiser again, unpredicated."""
-        if self.reducer.active:
-            st = torch.zeros(2, dtype=torch.int32, device=loss.device) if counts is None else counts.to(torch.int32)
-            word = self.reducer.finish(status=st, defer=True)                    # device int32 [3], same on every rank
-        else:
-            word = None if counts is None else counts.to(torch.int32).contiguous()
-        self._grad_norm = self.optimizer.step_clipped(self.opt.grad_clip, skip=word)
-        if word is not None:
-            host = word.tolist()                                                 # the step's one host read
-            flag, bad, contract = (host[0], host[1], host[2]) if self.reducer.active else (0, host[0], host[1])
-            if flag or bad or contract:
-                self.optimizer.rollback_step_counts()
-                if self.reducer.active:
-                    self.reducer.resolve(flag)
-                if contract and not bad and self._drop_train_compaction():
-                    return self.step(args)
-                if bad or contract:
-                    self.model.raise_for_status(bad, contract)
-                self._grad_norm = self.optimizer.step_clipped(self.opt.grad_clip)
-        return torch.cat([l.detach() for l in losses])

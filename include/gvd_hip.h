@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 14
+#define GVD_ABI_VERSION 15
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -204,18 +204,29 @@ int gvd_add_layernorm_unbiased_drop_bwd(const float* x, const float* y, const fl
                                         float* dy, float* partials, int64_t rows, int D, float eps, float p_drop,
                                         uint64_t seed, gvd_stream_t stream);
 
-/* Training path of the encoder's self-attention core (transformer.py:90-117) over MATERIALISED, zero-padded score maps
- * [n_maps, Rp, Rp] (Rp % 32 == 0, Rp <= 2048; rows / columns >= R are padding and are written as 0):
- *   fwd: S <- softmax(scale * S[:, :R]) in place;  Pd <- S * keep / (1 - p_drop)   (Pd may be NULL iff p_drop == 0;
- *        keep ~ Bernoulli(1 - p_drop) from Philox4x32-10 keyed by `seed`);
- *   bwd: dP <- scale * Y * (dY - sum_j dY_j Y_j),  dY = dP * [Pd != 0] / (1 - p_drop)   (in place over dP). */
-/* key_bias (nullable): f32 [n_maps / maps_per_sample, Rp] added to the scaled scores of a key for every query of the
- * sample's maps (log n: the key stands for n identical keys; -inf: the key does not exist; 0: plain) - the compacted
- * training layout (train_compact.py) that drops the masked proposals the reference computes (model.py:311-391). */
-int gvd_enc_softmax_dropout_fwd(float* S, float* Pd, int64_t n_maps, int Rp, int R, float scale, float p_drop,
-                                uint64_t seed, const float* key_bias, int maps_per_sample, gvd_stream_t stream);
-int gvd_enc_softmax_dropout_bwd(float* dP, const float* Pd, const float* Y, int64_t n_maps, int Rp, int R, float scale,
-                                float p_drop, gvd_stream_t stream);
+/* Training path of the encoder's self-attention core (transformer.py:90-117: softmax(Q K^T / sqrt d) -> dropout -> @ V)
+ * over the padded training layout: qkv f32 [B, Rp, ld >= 3 * n_heads * head_pad] = packed q | k | v with every head in its
+ * own zero-padded head_pad-column slot (head_pad = 176), Rp % 32 == 0, rows >= R of a sample are padding.
+ *
+ * forward (flash-style, csrc/flash_attn_pad.hip): o f32 [B, Rp, ldo >= n_heads * head_pad] (rows < R written, pad columns
+ *   zero), lse f32 [B * n_heads, Rp] = log2-domain logsumexp of every query's scaled + biased scores.  key_bias (nullable)
+ *   f32 [B, Rp] is added to the scaled scores of a key for every query of the sample (log n: the key stands for n identical
+ *   keys; -inf: no such key; the compacted training layout, train_compact.py).  Dropout of probability p_drop on the
+ *   attention weights from a counter-based hash of (seed, map row, key) (csrc/enc_dropout.h); no [B, heads, R, R] map is
+ *   written.
+ * backward maps (csrc/enc_attn_bwd.hip): delta f32 [B * n_heads, Rp] <- rowsum(dO * O), then per (sample, head) the two
+ *   products S = Q K^T and dY = dO V^T in one kernel whose epilogue recomputes P = exp2(c S + bias - lse), re-evaluates the
+ *   keep mask and writes Pd = P * keep / (1 - p) and dS = scale * P * (dY * keep / (1 - p) - delta), both
+ *   f32 [B * n_heads, Rp, Rp] with rows / columns >= R zero - the operands of dV = Pd^T dO, dQ = dS K, dK = dS^T Q
+ *   (gvd_gemm_nt_f32 with K-strided operands).  B * n_heads <= 65535. */
+int gvd_flash_attn_train_fwd_f32(const float* qkv, int64_t ld, float* o, int64_t ldo, float* lse, int B, int Rp, int R,
+                                 int n_heads, int head_pad, float scale, const float* key_bias, float p_drop, uint64_t seed,
+                                 gvd_stream_t stream);
+int gvd_enc_attn_bwd_maps(const float* qkv, int64_t ld, const float* dO, const float* O, int64_t ldo, const float* lse2,
+                          const float* key_bias, float* delta, float* Pd, float* dS, int B, int Rp, int R, int n_heads,
+                          int head_pad, float scale, float p_drop, uint64_t seed, gvd_stream_t stream);
+/* Test aid: the keep mask of that dropout, u8 [n_maps, Rp, Rp] (1 = kept), map row = map * Rp + query. */
+int gvd_enc_dropout_mask(uint8_t* out, int64_t n_maps, int Rp, float p_drop, uint64_t seed, gvd_stream_t stream);
 
 /* Per proposal row (model.py:336-364): p = softmax over the n_cls similarity logits (all -1e8 when the row is
  * masked: row_mask[(row / mask_rows_per_batch) * mask_ld + row % mask_rows_per_batch] != 0), written to sim_out
@@ -239,14 +250,8 @@ int gvd_region_feature_rows_bwd(const float* g_pool, const float* loc, int n_loc
                                 float* d_logits, int64_t d_logits_ld, int64_t rows, int G, float ln_eps,
                                 gvd_stream_t stream);
 
-/* Fused multi-head self-attention of the obj_interact encoder (transformer.py:90-123; heads = Tensor.chunk of the
- * model width): o[b,:,c0_h:c0_h+w_h] = softmax(q_h k_h^T) v_h for every head h, flash-style in fp32 on the matrix
- * cores (no [B,R,R] score maps in HBM).  q must already carry the 1/sqrt(d_model) scale.  q,k,v,o: [B,R,ld]
- * (o may not alias them); head_col0/head_width: host arrays of n_heads (<= 8) entries, width <= 176. */
-int gvd_flash_attn_f32(const float* q, const float* k, const float* v, float* o, int B, int R, int64_t ld,
-                       int n_heads, const int* head_col0, const int* head_width, gvd_stream_t stream);
-
-/* The same attention over PADDED heads (the inference path of the obj_interact encoder): head h of q, k, v occupies
+/* Fused multi-head self-attention of the obj_interact encoder (transformer.py:90-123), flash-style in fp32 on the matrix
+ * cores (no [B,R,R] score maps in HBM), over PADDED heads (the inference path of the encoder): head h of q, k, v occupies
  * columns [h*head_pad, (h+1)*head_pad) of rows with stride ld, real columns first, pad columns exactly zero (the fused
  * QKV projection against row-permuted, zero-padded weights writes them that way), so every head is 16-byte aligned.
  * o: [B,R,ldo] in the same padded layout (pad columns come out zero).  scores = scale * q.k (scale = 1/sqrt(d_model),
@@ -411,6 +416,8 @@ typedef struct {
   const float *att2_h2att_w, *att2_h2att_b, *att2_alpha_w, *att2_alpha_b; /* core.attention2.* */
   const float *logit_w, *logit_b;                       /* logit.* [V,H] */
   int B, Ft, R, H, A, E, V, L, unk_idx;
+  int no_persistent;   /* non-zero: always the kernel-per-op loop, never the persistent decode-batch kernel (the caller's
+                          retry after that kernel's grid barrier timed out, att_model.TopDownModel) */
   /* outputs */
   int64_t* seq;        /* [B,L] */
   float* seq_logprobs; /* [B,L] */

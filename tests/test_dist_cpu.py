@@ -99,6 +99,28 @@ def _worker(rank, world, port, outdir):
     word = red.finish(status=torch.tensor([rank * 7, 0], dtype=torch.int32), defer=True).tolist()
     red.resolve(word[0])
     ok &= word == [0, 7 * (world - 1), 0]
+    # an IN-BUCKET parameter without a gradient on one rank (m[3] is bucketed since the rediscovery; rank 0 does not run
+    # it): rank 0's hooks cannot launch m[3]'s bucket (nor any later one) during backward, rank 1's launch all of them.
+    # The status word must still sit at the same position of the collective sequence on both ranks (after the last
+    # bucket) - a word issued before the forced launches would pair with a bucket on the other rank
+    for p in m.parameters():
+        p.grad = None
+    red.reset()
+    h = m[2](torch.relu(m[0](x)))
+    (m[3](h) if rank == 1 else h).pow(2).mean().backward()
+    in_backward = red._next
+    local5 = [None if p.grad is None else p.grad.clone() for p in m.parameters()]
+    word = red.finish(status=torch.tensor([3 + rank, 1 - rank], dtype=torch.int32), defer=True).tolist()
+    red.resolve(word[0])
+    ok &= word == [0, 3 + world - 1, 1]
+    counts = [None] * world
+    dist.all_gather_object(counts, in_backward)
+    ok &= counts[1] == len(red.buckets) and counts[0] < counts[1]      # the two ranks really launched differently
+    g5 = [None] * world
+    dist.all_gather_object(g5, local5)
+    for i, p in enumerate(m.parameters()):
+        want = sum((g[i] if g[i] is not None else torch.zeros_like(p)) for g in g5) / world
+        ok &= p.grad is not None and torch.allclose(p.grad, want, atol=1e-7)
     # (2) the real loss on this rank's shard of a batch (oracle), averaged grads == mean of shard grads
     opt = gvd_amd.opts.default_opt(vocab_size=120, t_attn_size=6)
     sd = synth.init_state_dict(opt, seed=4)

@@ -203,9 +203,9 @@ def test_beam_search_matches_oracle(B, K, seed):
 
 
 @pytest.mark.parametrize('K', [2, 5, 8])
-def test_beam_step_kernel_equals_batched_torch_bookkeeping(K, monkeypatch):
+def test_beam_step_kernel_equals_batched_torch_bookkeeping(K):
     """gvd_beam_step (one launch per step: candidate merge, history fork, finished-beam record) against the batched torch
-    formulation it replaces (GVD_BEAM_FUSED=0): ids, log-probs and attended regions bit for bit, on logits shaped so that
+    formulation it replaces (eval_opt beam_fused_step=False; beam widths above 8 always take it): ids, log-probs and attended regions bit for bit, on logits shaped so that
     beams finish at different steps (END-heavy profile) and with exact score ties (K = 8 > distinct top words)."""
     opt = gvd_amd.opts.default_opt(vocab_size=40, t_attn_size=6)
     inp = synth.make_inputs(opt, 5, seed=9, train=False)
@@ -217,9 +217,8 @@ def test_beam_step_kernel_equals_batched_torch_bookkeeping(K, monkeypatch):
         model = _model(opt, sd)
         res = {}
         for fused in ('1', '0'):
-            monkeypatch.setenv('GVD_BEAM_FUSED', fused)
             with torch.no_grad():
-                res[fused] = model._sample(*args, {'beam_size': K})[:3]
+                res[fused] = model._sample(*args, {'beam_size': K, 'beam_fused_step': fused == '1'})[:3]
         for a, b in zip(res['1'], res['0']):
             assert torch.equal(a, b)
         nonzero += int((res['1'][0] != 0).sum())

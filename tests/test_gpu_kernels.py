@@ -273,7 +273,6 @@ def test_masked_lsm_loss():
 def test_attention_beam_group_kernel_is_bitwise_the_row_kernel(K, Bs, N, Ft):
     """Beam search: the K beam rows of a sample share its features.  The grouped kernel (one workgroup per chunk and
     SAMPLE, features read once for K queries) must give bit-for-bit what the per-row kernel gives on the expanded rows."""
-    import os
     g = _g(K * 100 + N)
     A, H = 512, 1024
     feats, p_feats = torch.randn(Bs, N, H, generator=g), torch.randn(Bs, N, A, generator=g)
@@ -283,30 +282,22 @@ def test_attention_beam_group_kernel_is_bitwise_the_row_kernel(K, Bs, N, Ft):
     b2, b1 = torch.randn(1, generator=g), torch.randn(1, generator=g)
     mask = (torch.rand(Bs * K, N + 1, generator=g) < 0.2).to(torch.uint8)
     mask[:, 0] = 0
-    outs = {}
-    for mode, nt in (('1', '0'), ('0', '0'), ('1n', '1'), ('0n', '1')):       # grouped / per-row x plain / nontemporal loads
-        os.environ['GVD_ATTN_GROUPED'] = mode[0]
-        os.environ['GVD_ATTN_NT'] = nt
-        lo = torch.zeros(Bs * K, N).cuda()
-        region = dict(feats=feats.cuda(), p_feats=p_feats.cuda(), q=q.cuda()[:, A:], w=w2.cuda(), alpha_bias=b2.cuda(),
-                      att_mask=mask.cuda()[:, 1:], pnt_mask=mask.cuda()[:, 1:], logits_out=lo, group=K)
-        temporal = dict(feats=tf.cuda(), p_feats=tp.cuda(), q=q.cuda()[:, :A], w=w1.cuda(), alpha_bias=b1.cuda(), group=K)
-        out, cr, ct = ops.attention_step(region, temporal, want_separate=True)
-        torch.cuda.synchronize()
-        outs[mode] = (out.cpu(), cr.cpu(), ct.cpu(), lo.cpu())
-    os.environ.pop('GVD_ATTN_GROUPED', None)
-    os.environ.pop('GVD_ATTN_NT', None)
-    for other in ('0', '1n', '0n'):
-        for a, b in zip(outs['1'], outs[other]):
-            assert torch.equal(a, b)
-    # and both equal the row kernel on explicitly expanded features (group = 0)
+    lo = torch.zeros(Bs * K, N).cuda()
+    region = dict(feats=feats.cuda(), p_feats=p_feats.cuda(), q=q.cuda()[:, A:], w=w2.cuda(), alpha_bias=b2.cuda(),
+                  att_mask=mask.cuda()[:, 1:], pnt_mask=mask.cuda()[:, 1:], logits_out=lo, group=K)
+    temporal = dict(feats=tf.cuda(), p_feats=tp.cuda(), q=q.cuda()[:, :A], w=w1.cuda(), alpha_bias=b1.cuda(), group=K)
+    out, cr, ct = ops.attention_step(region, temporal, want_separate=True)
+    torch.cuda.synchronize()
+    # the row kernel on explicitly expanded features (group = 0): the same bits
+    lo2 = torch.zeros(Bs * K, N).cuda()
     region = dict(feats=feats.repeat_interleave(K, 0).cuda(), p_feats=p_feats.repeat_interleave(K, 0).cuda(),
                   q=q.cuda()[:, A:], w=w2.cuda(), alpha_bias=b2.cuda(), att_mask=mask.cuda()[:, 1:],
-                  pnt_mask=mask.cuda()[:, 1:])
+                  pnt_mask=mask.cuda()[:, 1:], logits_out=lo2)
     temporal = dict(feats=tf.repeat_interleave(K, 0).cuda(), p_feats=tp.repeat_interleave(K, 0).cuda(), q=q.cuda()[:, :A],
                     w=w1.cuda(), alpha_bias=b1.cuda())
-    ref = ops.attention_step(region, temporal)
-    np.testing.assert_allclose(outs['1'][0].numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    ref, rr, rt = ops.attention_step(region, temporal, want_separate=True)
+    for a, b in ((out, ref), (cr, rr), (ct, rt), (lo, lo2)):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize('barrier', ['counter', 'cg'])
@@ -363,77 +354,6 @@ def test_region_feature_rows():
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize('B,R', [(2, 1000), (3, 77), (1, 128), (2, 33)])
-def test_flash_attention_heads(B, R):
-    """Fused 6-head self-attention (uneven heads 171x5+169) vs the reference's per-head bmm/softmax/bmm."""
-    g = _g(B * R)
-    D = 1024
-    q = torch.randn(B, R, D, generator=g) * 0.3
-    k = torch.randn(B, R, D, generator=g)
-    v = torch.randn(B, R, D, generator=g)
-    sizes = [t.shape[-1] for t in q[:1, :1].chunk(6, -1)]
-    heads = []
-    for qh, kh, vh in zip(q.chunk(6, -1), k.chunk(6, -1), v.chunk(6, -1)):
-        heads.append(torch.matmul(torch.softmax(torch.matmul(qh, kh.transpose(1, 2)), -1), vh))
-    ref = torch.cat(heads, -1)
-    out = ops.flash_attn_heads(q.cuda(), k.cuda(), v.cuda(), sizes).cpu()
-    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
-
-
-@pytest.mark.parametrize('M,N,K,act', [(33000, 1024, 1024, 0), (32771, 2048, 2048, 1), (40001, 433, 2048, 0),
-                                       (36000, 3168, 1024, 0), (33000, 1024, 1056, 0), (33000, 1024, 2784, 1),
-                                       (70000, 512, 1024, 0)])
-def test_gemm_pipe_kernel(M, N, K, act):
-    """Large projections (>= 256 tiles of 128 x 128) run the software-pipelined kernel (gemm_pipe.hip): ragged M / N edges
-    (clamped operand rows), the LDS-transposed and the direct epilogue (N % 4 != 0), every K the hot path uses.  Against
-    fp64, and BITWISE against the general kernel (the same rows as small row blocks -> 64 x 64 tiles, same k order)."""
-    g = _g(M + N + K)
-    A = torch.randn(M, K, generator=g).cuda()
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
-    b = torch.randn(N, generator=g).cuda()
-    out = ops.gemm_nt(A, W, b, act)
-    rows = torch.cat([torch.arange(0, 300), torch.arange(M // 2 - 100, M // 2 + 100), torch.arange(M - 300, M)]).cuda()
-    ref = A[rows].double() @ W.double().t() + b.double()
-    if act:
-        ref = ref.clamp(min=0)
-    np.testing.assert_allclose(out[rows].cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-5, atol=3e-5)
-    for r0 in (0, M // 2 - 61, M - 1000):
-        small = ops.gemm_nt(A[r0:r0 + 1000].contiguous(), W, b, act)          # 8 x ntn tiles < 256 -> general kernel
-        assert torch.equal(small, out[r0:r0 + 1000]), 'pipelined and general GEMM kernels differ bitwise'
-
-
-def test_gemm_pipe_batched_masked_segments():
-    """The pipelined kernel behind the batched grounder call (2-D bias, row bias, byte mask: direct epilogue) and behind
-    a 3-segment K (A and W given as column blocks), vs fp64."""
-    g = _g(77)
-    B, Mq, R, K = 40, 433, 1000, 2048                 # 4 x 8 x 40 = 1280 tiles
-    xt = (torch.randn(Mq, K, generator=g) * 0.05).cuda()
-    feats = torch.relu(torch.randn(B, R, K, generator=g)).cuda()
-    pm = (torch.rand(B, R, generator=g) < 0.3).to(torch.uint8).cuda()
-    mb = torch.randn(Mq, generator=g).cuda()
-    out = ops.grounder_dot(xt, feats, pm, mbias=mb, xt_shared=True)
-    for bi in (0, 17, 39):
-        ref = (xt.double() @ feats[bi].double().t() + mb.double().unsqueeze(1)).float()
-        ref = ref.masked_fill(pm[bi].bool().unsqueeze(0), O.MIN_VALUE)
-        np.testing.assert_allclose(out[bi].cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-4)
-    # three K segments: [M,2048] | [M,320] | [M,448] against column blocks of one weight
-    M, N = 33000, 1024
-    A = torch.randn(M, 2816, generator=g).cuda()
-    W = (torch.randn(N, 2816, generator=g) / 50).cuda()
-    from gvd_amd.hip import GemmArgs, GemmSeg, check, lib, ptr, stream_ptr
-    import ctypes as C
-    outs = torch.empty(M, N, device='cuda')
-    a = GemmArgs()
-    a.nseg = 3
-    for i, (c0, kk) in enumerate(((0, 2048), (2048, 320), (2368, 448))):
-        a.seg[i] = GemmSeg(C.c_void_p(A.data_ptr() + 4 * c0), 2816, 0, C.c_void_p(W.data_ptr() + 4 * c0), 2816, 0, kk)
-    a.C = ptr(outs); a.ldc = N
-    a.M, a.N, a.batch, a.act = M, N, 1, 0
-    check(lib().gvd_gemm_nt_f32(C.byref(a), stream_ptr()), 'gemm 3 segments')
-    one = ops.gemm_nt(A, W)
-    assert torch.equal(outs, one), 'segmented K must give the bits of the single-segment product (same k order)'
-
-
 @pytest.mark.parametrize('B,R', [(2, 1000), (3, 77), (1, 128), (2, 129), (1, 33)])
 def test_flash_attention_padded_heads(B, R):
     """The padded-head attention kernel (flash_attn_pad.hip) behind the fused QKV projection: vs the reference's per-head
@@ -473,37 +393,27 @@ def test_region_feature_rows_padded():
     assert float(b[:, :, 2781:].abs().max()) == 0.0
 
 
-def test_fused_encoder_path_matches_library_path():
-    """obj_interact inference on the fused HIP path (one padded QKV GEMM, padded-head attention, own GEMMs) vs the
-    unfused path (library projections + first flash kernel) on the same weights: same math, fp32 rounding apart."""
-    import os
+def test_fused_encoder_path_matches_oracle():
+    """obj_interact inference on the fused HIP path (one padded QKV GEMM, padded-head flash attention, own GEMMs, fused
+    residual LayerNorm) vs the oracle's restatement of transformer.py:135-190 on the same weights - and again after an
+    in-place weight change: the packed (re-laid-out) weight copies must follow."""
     from gvd_amd import att_model, synth
     opt = gvd_amd.opts.default_opt(vocab_size=300, t_attn_size=10)
     sd = synth.init_state_dict(opt, seed=21)
     m = att_model.TopDownModel(opt)
     m.load_state_dict(sd)
     m = m.cuda().eval()
-    x = torch.relu(torch.randn(3, 1000, 1024, generator=_g(3))).cuda()
-    old = os.environ.get('GVD_ENC_FUSED')
-    try:
-        with torch.no_grad():
-            os.environ['GVD_ENC_FUSED'] = '0'
-            ref = m._obj_interact(x)
-            os.environ['GVD_ENC_FUSED'] = '1'
-            got = m._obj_interact(x)
-            # weights changed in place -> the packed copies must follow
-            m.obj_interact.encoder.layers[0].selfattn.layer.wq.weight.mul_(0.5)
-            os.environ['GVD_ENC_FUSED'] = '0'
-            ref2 = m._obj_interact(x)
-            os.environ['GVD_ENC_FUSED'] = '1'
-            got2 = m._obj_interact(x)
-    finally:
-        if old is None:
-            os.environ.pop('GVD_ENC_FUSED', None)
-        else:
-            os.environ['GVD_ENC_FUSED'] = old
-    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(got2.cpu().numpy(), ref2.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    x = torch.relu(torch.randn(3, 1000, 1024, generator=_g(3)))
+    with torch.no_grad():
+        ref = O.obj_interact(x, sd)
+        got = m._obj_interact(x.cuda())
+        # weights changed in place -> the packed copies must follow
+        m.obj_interact.encoder.layers[0].selfattn.layer.wq.weight.mul_(0.5)
+        sd2 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        ref2 = O.obj_interact(x, sd2)
+        got2 = m._obj_interact(x.cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(got2.cpu().numpy(), ref2.numpy(), rtol=1e-4, atol=1e-4)
     assert not torch.allclose(ref, ref2, atol=1e-3)
 
 
@@ -747,147 +657,119 @@ def test_add_layernorm_fused_backward(rows):
     assert torch.equal(got[0], got[1])
 
 
-@pytest.mark.parametrize('n_maps,R,Rp,p', [(5, 1000, 1024, 0.2), (3, 40, 64, 0.2), (2, 300, 320, 0.0)])
-def test_enc_softmax_dropout_row_kernels(n_maps, R, Rp, p):
-    """Training softmax + dropout over zero-padded score maps (transformer.py:100-108) and its backward."""
-    from gvd_amd.hip import check, lib, ptr, stream_ptr
-    g = _g(R + Rp)
-    scale = 1.0 / 32
-    S0 = (torch.randn(n_maps, Rp, Rp, generator=g) * 40).cuda()
-    Y = S0.clone()
-    Pd = torch.full_like(Y, float('nan')) if p > 0 else None
-    check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y), ptr(Pd), n_maps, Rp, R, scale, p, 1234567, None, 0, stream_ptr()), 'fwd')
-    want = torch.softmax(S0[:, :R, :R].double() * scale, -1)
-    assert float((Y[:, :R, :R].double() - want).abs().max()) < 2e-7
-    assert not Y[:, R:].any() and not Y[:, :, R:].any()
-    if p > 0:
-        assert not Pd[:, R:].any() and not Pd[:, :, R:].any()
-        keep = Pd[:, :R, :R] != 0
-        frac = float(keep.float().mean())
-        assert abs(frac - (1 - p)) < 4 * (p * (1 - p) / keep.numel()) ** 0.5 + 1e-4, frac
-        assert torch.equal(Pd[:, :R, :R][keep], (Y[:, :R, :R] * (1.0 / (1.0 - p)))[keep])
-        # another seed: another mask; same seed: same mask
-        Y2, Pd2 = S0.clone(), torch.empty_like(S0)
-        check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y2), ptr(Pd2), n_maps, Rp, R, scale, p, 1234567, None, 0, stream_ptr()), 'fwd')
-        assert torch.equal(Pd2, Pd)
-        check(lib().gvd_enc_softmax_dropout_fwd(ptr(Y2.copy_(S0)), ptr(Pd2), n_maps, Rp, R, scale, p, 7654321, None, 0, stream_ptr()), 'fwd')
-        assert not torch.equal(Pd2, Pd)
-        # rows are decorrelated (no repeated pattern across rows / maps)
-        k0 = keep.reshape(-1, R).float()
-        assert float((k0[0] == k0[1]).float().mean()) < 0.8
-    dP0 = torch.randn(n_maps, Rp, Rp, generator=g).cuda()
-    dS = dP0.clone()
-    dS[:, R:] = float('nan'); dS[:, :, R:] = float('nan')        # the GEMM leaves the pad region unwritten
-    check(lib().gvd_enc_softmax_dropout_bwd(ptr(dS), ptr(Pd), ptr(Y), n_maps, Rp, R, scale, p, stream_ptr()), 'bwd')
-    y = Y[:, :R, :R].double()
-    dY = dP0[:, :R, :R].double()
-    if p > 0:
-        dY = dY * (Pd[:, :R, :R] != 0) / (1 - p)
-    ref = scale * y * (dY - (dY * y).sum(-1, keepdim=True))
-    assert float((dS[:, :R, :R].double() - ref).abs().max()) < 1e-6
-    assert not dS[:, R:].any() and not dS[:, :, R:].any()
-
-
-def test_enc_softmax_key_bias_operand():
-    """The per-sample key bias of the training softmax row kernel (compacted training layout, train_compact.py): 0 leaves a
-    row bit-identical, log n weights a key n-fold, -inf removes it; maps of one sample share its bias row."""
-    from gvd_amd.hip import check, lib, ptr, stream_ptr
-    g = _g(77)
-    B, nh, Rp = 3, 2, 64
-    scale = 1.0 / 32
-    S0 = (torch.randn(B * nh, Rp, Rp, generator=g) * 40).cuda()
-    plain = S0.clone()
-    check(lib().gvd_enc_softmax_dropout_fwd(ptr(plain), None, B * nh, Rp, Rp, scale, 0.0, 0, None, 0, stream_ptr()), 'fwd')
-    kb = torch.zeros(B, Rp)
-    y0 = S0.clone()
-    check(lib().gvd_enc_softmax_dropout_fwd(ptr(y0), None, B * nh, Rp, Rp, scale, 0.0, 0, ptr(kb.cuda()), nh, stream_ptr()), 'fwd')
-    assert torch.equal(y0, plain)                                            # zero bias: the same bits
-    kb[0, 10] = float(np.log(7.0)); kb[0, 40:] = float('-inf')               # sample 0: key 10 counts 7-fold, keys 40.. absent
-    kb[2, 0] = float(np.log(100.0)); kb[2, 1:5] = float('-inf')
-    y = S0.clone()
-    check(lib().gvd_enc_softmax_dropout_fwd(ptr(y), None, B * nh, Rp, Rp, scale, 0.0, 0, ptr(kb.cuda()), nh, stream_ptr()), 'fwd')
-    want = torch.softmax(S0.double().view(B, nh, Rp, Rp) * scale + kb.double().cuda().view(B, 1, 1, Rp), -1).view(B * nh, Rp, Rp)
-    assert float((y.double() - want).abs().max()) < 2e-7
-    assert not y.view(B, nh, Rp, Rp)[0, :, :, 40:].any() and not y.view(B, nh, Rp, Rp)[2, :, :, 1:5].any()
-    assert torch.equal(y.view(B, nh, Rp, Rp)[1], plain.view(B, nh, Rp, Rp)[1])      # sample 1 untouched
-
-
-@pytest.mark.parametrize('B,R', [(2, 1000), (3, 40)])
-def test_enc_attn_core_training_matches_autograd(B, R, monkeypatch):
-    """ops.enc_attn_core (six MFMA products + the two row kernels) against the per-head torch formulation of
-    transformer.py:90-117 with dropout off: output and the gradient w.r.t. the packed q | k | v."""
-    g = _g(B * R)
-    nh, HP, d = 6, ops.TRAIN_HEAD_PAD, 1024
-    Rp = -(-R // 32) * 32
+def _packed_qkv(B, Rp, nh, HP, g, d=1024, scale_q=1.0):
+    """Random packed q | k | v [B, Rp, 3 nh HP] with the real 171 x 5 + 169 head widths (pad columns zero)."""
     sizes = [t.shape[-1] for t in torch.zeros(1, d).chunk(nh, -1)]
     qkv = torch.zeros(B, Rp, 3, nh, HP)
     for h in range(nh):
         qkv[:, :, :, h, :sizes[h]] = torch.randn(B, Rp, 3, sizes[h], generator=g)
-    qkv = qkv.reshape(B, Rp, 3 * nh * HP).cuda().requires_grad_(True)
-    dO = torch.randn(B, Rp, nh * HP, generator=g).cuda()
-    dO[:, R:] = 0                                        # pad rows never receive gradient
-    O = ops.enc_attn_core(qkv, R, nh, 1.0 / 32, 0.0)
-    O.backward(dO)
-    got = qkv.grad.clone()
+    qkv[:, :, 0] *= scale_q
+    return qkv.reshape(B, Rp, 3 * nh * HP), sizes
+
+
+def _attn_core_reference(qkv, R, nh, HP, scale, key_bias=None, keep=None, p=0.0):
+    """fp64 autograd formulation of transformer.py:90-117 per head over the packed layout: -> (O [B,R,nh*HP], leaf)."""
+    B, Rp, _ = qkv.shape
     q64 = qkv.detach().double().view(B, Rp, 3, nh, HP).requires_grad_(True)
     outs = []
     for h in range(nh):
         qh, kh, vh = (q64[:, :R, j, h] for j in range(3))
-        w = torch.softmax(torch.matmul(qh, kh.transpose(1, 2)) / 32, -1)
+        dots = torch.matmul(qh, kh.transpose(1, 2)) * scale
+        if key_bias is not None:
+            dots = dots + key_bias[:, :R].double().unsqueeze(1)
+        w = torch.softmax(dots, -1)
+        if keep is not None:
+            w = w * keep[:, h, :R, :R].double() / (1 - p)
         outs.append(torch.matmul(w, vh))
-    ref = torch.stack(outs, 2).reshape(B, R, nh * HP)
+    return torch.stack(outs, 2).reshape(B, R, nh * HP), q64
+
+
+@pytest.mark.parametrize('B,R,p', [(2, 1000, 0.0), (3, 40, 0.0), (2, 1000, 0.2), (3, 132, 0.35)])
+def test_enc_attn_core_training_matches_autograd(B, R, p):
+    """ops.enc_attn_core - flash-style forward with in-register dropout, backward = one kernel that recomputes the
+    probabilities from the saved logsumexp + three MFMA products - against the per-head fp64 autograd formulation of
+    transformer.py:90-117 with the SAME keep mask (gvd_enc_dropout_mask re-evaluates the hash of csrc/enc_dropout.h):
+    output and the gradient w.r.t. the packed q | k | v; pad rows zero; reproducible under the seed."""
+    g = _g(B * R + int(100 * p))
+    nh, HP = 6, ops.HEAD_PAD
+    Rp = -(-R // 32) * 32
+    qkv, _ = _packed_qkv(B, Rp, nh, HP, g, scale_q=3.0)
+    qkv = qkv.cuda().requires_grad_(True)
+    dO = torch.randn(B, Rp, nh * HP, generator=g).cuda()
+    dO[:, R:] = 0                                        # pad rows never receive gradient
+    seed = 0x1234_5678_9ABC_DEF0 + R
+    out = ops.enc_attn_core(qkv, R, nh, 1.0 / 32, p, seed=seed)
+    out.backward(dO)
+    got = qkv.grad.clone()
+    keep = ops.enc_dropout_mask(B * nh, Rp, p, seed).view(B, nh, Rp, Rp) if p > 0 else None
+    ref, q64 = _attn_core_reference(qkv, R, nh, HP, 1.0 / 32, keep=keep, p=p)
     ref.backward(dO[:, :R].double())
-    assert float((O[:, :R].double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
-    assert not O[:, R:].any()
+    assert float((out[:, :R].double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    assert not out[:, R:].any()
     want = q64.grad.reshape(B, Rp, 3 * nh * HP)
     err = float((got.double() - want).abs().max())
-    assert err < 3e-5 * float(want.abs().max()), err
+    assert err < 5e-5 * float(want.abs().max()), err
     assert not got[:, R:].any()
-    # one launch per product over the two-level (sample, head) batch == one launch per head, bit for bit
-    monkeypatch.setenv('GVD_ENC_HEADS_MERGED', '0')
-    qkv.grad = None
-    O2 = ops.enc_attn_core(qkv, R, nh, 1.0 / 32, 0.0)
-    O2.backward(dO)
-    assert torch.equal(O2, O) and torch.equal(qkv.grad, got)
-    monkeypatch.delenv('GVD_ENC_HEADS_MERGED')
-    # dropout on: runs, reproducible under the torch seed, and differs from the p = 0 output
-    torch.manual_seed(5)
-    o1 = ops.enc_attn_core(qkv.detach(), R, nh, 1.0 / 32, 0.2)
-    torch.manual_seed(5)
-    o2 = ops.enc_attn_core(qkv.detach(), R, nh, 1.0 / 32, 0.2)
-    assert torch.equal(o1, o2) and not torch.equal(o1, O.detach())
+    # same seed -> same bits; another seed -> another mask
+    again = ops.enc_attn_core(qkv.detach(), R, nh, 1.0 / 32, p, seed=seed)
+    assert torch.equal(again, out.detach())
+    if p > 0:
+        other = ops.enc_attn_core(qkv.detach(), R, nh, 1.0 / 32, p, seed=seed + 1)
+        assert not torch.equal(other, out.detach())
+        torch.manual_seed(5)
+        o1 = ops.enc_attn_core(qkv.detach(), R, nh, 1.0 / 32, p)       # seed from torch's CPU generator
+        torch.manual_seed(5)
+        o2 = ops.enc_attn_core(qkv.detach(), R, nh, 1.0 / 32, p)
+        assert torch.equal(o1, o2)
 
 
-def test_enc_attn_core_176_column_head_slots():
-    """The training attention core over 176-column head slots (the default for launches on the pipelined GEMM) (K = 176 contractions through the pipelined GEMM's
-    shifted tail tile) equals the 192-slot form up to fp32 rounding - output and gradient."""
-    g = _g(41)
-    B, R, nh, d = 2, 1000, 6, 1024
-    Rp = -(-R // 32) * 32
-    sizes = [t.shape[-1] for t in torch.zeros(1, d).chunk(nh, -1)]
-    vals = [torch.randn(B, Rp, 3, sizes[h], generator=g) for h in range(nh)]
-    dO_h = [torch.randn(B, Rp, sizes[h], generator=g) for h in range(nh)]
-    res = {}
-    for HP in (192, 176):
-        qkv = torch.zeros(B, Rp, 3, nh, HP)
-        dO = torch.zeros(B, Rp, nh, HP)
-        for h in range(nh):
-            qkv[:, :, :, h, :sizes[h]] = vals[h]
-            dO[:, :R, h, :sizes[h]] = dO_h[h][:, :R]
-        qkv = qkv.reshape(B, Rp, 3 * nh * HP).cuda().requires_grad_(True)
-        O = ops.enc_attn_core(qkv, R, nh, 1.0 / 32, 0.0)
-        O.backward(dO.reshape(B, Rp, nh * HP).cuda())
-        res[HP] = (O.detach().view(B, Rp, nh, HP), qkv.grad.view(B, Rp, 3, nh, HP))
-    for h in range(nh):
-        a, b = res[192][0][:, :, h, :sizes[h]], res[176][0][:, :, h, :sizes[h]]
-        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
-        ga, gb = res[192][1][:, :, :, h, :sizes[h]], res[176][1][:, :, :, h, :sizes[h]]
-        assert float((ga - gb).abs().max()) <= 3e-5 * float(ga.abs().max())
+def test_enc_dropout_mask_statistics():
+    """The keep mask of the attention dropout (counter-based hash, csrc/enc_dropout.h): keep rate, no structure along rows,
+    columns or maps, different seeds independent."""
+    n_maps, Rp, p = 12, 1024, 0.2
+    m = ops.enc_dropout_mask(n_maps, Rp, p, 987654321).float()
+    assert abs(float(m.mean()) - (1 - p)) < 5e-4                             # 12.6 M draws: sigma = 1.1e-4
+    assert float((m.mean(dim=2) - (1 - p)).abs().max()) < 0.07               # every row (1024 draws: sigma = 0.0125)
+    assert float((m.mean(dim=1) - (1 - p)).abs().max()) < 0.07               # every column
+    c = m - m.mean()
+    for a, b in ((c[:, :-1], c[:, 1:]), (c[:, :, :-1], c[:, :, 1:]), (c[:-1], c[1:]), (c[:, :-4, :-4], c[:, 4:, 4:])):
+        assert abs(float((a * b).mean()) / float((c * c).mean())) < 2e-3      # neighbours uncorrelated
+    m2 = ops.enc_dropout_mask(n_maps, Rp, p, 987654322).float()
+    assert abs(float(((m2 - m2.mean()) * c).mean()) / float((c * c).mean())) < 2e-3
+    assert float(ops.enc_dropout_mask(2, 64, 0.0, 1).float().mean()) == 1.0
 
 
-def test_encoder_training_paths_agree(monkeypatch):
-    """The all-MFMA training encoder (padded region axis, packed projection, fused LayerNorm backward) against the
-    per-head library formulation in eval mode with gradients on: output and parameter gradients."""
+def test_enc_attn_core_key_bias():
+    """The per-sample key bias of the training attention core (compacted training layout, train_compact.py): 0 leaves the
+    result bit-identical to the unbiased call, log n weights a key n-fold, -inf removes it - forward and gradient against
+    the fp64 formulation; heads of one sample share its bias row."""
+    g = _g(77)
+    B, R, nh, HP = 3, 96, 6, ops.HEAD_PAD
+    Rp = R
+    qkv, _ = _packed_qkv(B, Rp, nh, HP, g, scale_q=4.0)
+    qkv = qkv.cuda().requires_grad_(True)
+    dO = torch.randn(B, Rp, nh * HP, generator=g).cuda()
+    plain = ops.enc_attn_core(qkv.detach(), R, nh, 1.0 / 32, 0.0)
+    kb = torch.zeros(B, Rp)
+    assert torch.equal(ops.enc_attn_core(qkv.detach(), R, nh, 1.0 / 32, 0.0, key_bias=kb.cuda()), plain)
+    kb[0, 10] = float(np.log(7.0)); kb[0, 40:] = float('-inf')               # sample 0: key 10 counts 7-fold, keys 40.. absent
+    kb[2, 0] = float(np.log(100.0)); kb[2, 1:5] = float('-inf')
+    out = ops.enc_attn_core(qkv, R, nh, 1.0 / 32, 0.0, key_bias=kb.cuda())
+    out.backward(dO)
+    ref, q64 = _attn_core_reference(qkv, R, nh, HP, 1.0 / 32, key_bias=kb.cuda())
+    ref.backward(dO.double())
+    assert float((out.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    want = q64.grad.reshape(B, Rp, 3 * nh * HP)
+    assert float((qkv.grad.double() - want).abs().max()) < 5e-5 * float(want.abs().max())
+    assert torch.equal(out[1], plain[1])                                     # sample 1 untouched
+    kgrad = qkv.grad.view(B, Rp, 3, nh, HP)[:, :, 1:]                        # removed keys get no k / v gradient
+    assert not kgrad[0, 40:].any() and not kgrad[2, 1:5].any()
+
+
+def test_encoder_training_path_matches_oracle_autograd():
+    """The all-MFMA training encoder (padded region axis, packed projection, flash-style attention core, fused LayerNorm
+    forward + backward) against the oracle's restatement of transformer.py:135-190 under autograd, eval mode: output, input
+    gradient and every parameter gradient."""
     from gvd_amd import att_model
     opt = gvd_amd.opts.default_opt(vocab_size=60)
     torch.manual_seed(3)
@@ -898,25 +780,23 @@ def test_encoder_training_paths_agree(monkeypatch):
                 ln.gamma.add_(torch.randn(1024, device='cuda') * 0.1)
                 ln.beta.add_(torch.randn(1024, device='cuda') * 0.1)
     g = _g(9)
-    x = torch.randn(3, 40, 1024, generator=g).cuda()
-    dout = torch.randn(3, 40, 1024, generator=g).cuda()
-    params = [p for p in model.obj_interact.encoder.layers.parameters()]
-    res = {}
-    for flag in ('1', '0'):
-        monkeypatch.setenv('GVD_ENC_TRAIN_MFMA', flag)
-        monkeypatch.setenv('GVD_LN_FUSED_BWD', flag)
-        for p in params:
-            p.grad = None
-        xi = x.clone().requires_grad_(True)
-        with torch.enable_grad():
-            out = model._obj_interact(xi)
-            out.backward(dout)
-        res[flag] = (out.detach(), xi.grad.clone(), [p.grad.clone() for p in params])
-    a, b = res['1'], res['0']
-    assert float((a[0] - b[0]).abs().max()) < 2e-4
-    assert float((a[1] - b[1]).abs().max()) < 2e-4 * max(1.0, float(b[1].abs().max()))
-    for ga, gb in zip(a[2], b[2]):
-        assert float((ga - gb).abs().max()) < 3e-4 * max(1.0, float(gb.abs().max()))
+    x = torch.randn(3, 40, 1024, generator=g)
+    dout = torch.randn(3, 40, 1024, generator=g)
+    names = [n for n, _ in model.named_parameters() if n.startswith('obj_interact.')]
+    params = dict(model.named_parameters())
+    xi = x.cuda().requires_grad_(True)
+    with torch.enable_grad():
+        out = model._obj_interact(xi)
+        out.backward(dout.cuda())
+    W = {n: params[n].detach().cpu().double().requires_grad_(True) for n in names}
+    xr = x.double().requires_grad_(True)
+    ref = O.obj_interact(xr, W)
+    ref.backward(dout.double())
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) < 2e-4
+    assert float((xi.grad.cpu().double() - xr.grad).abs().max()) < 2e-4 * max(1.0, float(xr.grad.abs().max()))
+    for n in names:
+        gb = W[n].grad
+        assert float((params[n].grad.cpu().double() - gb).abs().max()) < 3e-4 * max(1.0, float(gb.abs().max())), n
 
 
 def test_gemm_fused_row_gather_is_bitwise_the_gathered_gemm():

@@ -1,6 +1,6 @@
-"""-m gpu: every non-default value of the GVD_* A/B knobs still reproduces the reference goldens.  Several knobs
-are read once per process, so each setting runs tools/knob_check.py in its own process; knobs that act on different
-components are grouped into one process."""
+"""-m gpu: every non-default value of the runtime knobs that select a code path still reproduces
+the reference goldens, and the persistent kernels' timeout path recomputes instead of failing.  The knobs are read once
+per process (or are process-wide state), so each setting runs tools/knob_check.py in its own process."""
 import os
 import subprocess
 import sys
@@ -11,17 +11,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SETTINGS = [
-    ('decode', dict(GVD_PERSISTENT='0', GVD_ATTN_NT='1', GVD_ATTN_CHUNK='32', GVD_GEMV_KS='2', GVD_GEMM_SMALL='0',
-                    GVD_FC7_ROWMAP='0', GVD_GRU_BARRIER='cg', GVD_FLASH_SKEW='0', GVD_COOP_LAUNCH='1')),
-    ('decode', dict(GVD_ATTN_NT='0', GVD_GEMV_KS='1', GVD_GEMM_VARIANT='1', GVD_GEMM_BIG='128', GVD_SIDE_FUSED='0', GVD_GRU_HU='16')),
-    ('decode', dict(GVD_COMPACT='0', GVD_POOL_EMBED_OWN='0', GVD_GEMM_VARIANT='0')),
-    ('decode', dict(GVD_COMPACT='0', GVD_ENC_FUSED='0', GVD_GEMM_VARIANT='2')),               # first flash kernels (16x16x4)
-    ('decode', dict(GVD_ENC_FUSED='0', GVD_FLASH_V16='0', GVD_FLASH_GLDS='1')),               # 32x32x2 flash kernel, LDS-DMA staging
-    ('decode', dict(GVD_ENC_FUSED='0', GVD_FLASH='0')),                                       # library attention chain
-    ('beam', dict(GVD_ATTN_GROUPED='0', GVD_BEAM_FUSED='0')),
-    ('train', dict(GVD_ENC_TRAIN_MFMA='0', GVD_LN_FUSED_BWD='0', GVD_P5_FUSED_TRAIN='0', GVD_GRU_TRAIN='0')),
-    ('train', dict(GVD_ENC_HEADS_MERGED='0', GVD_TRAIN_HEAD_PAD='192')),
-    ('train', dict(GVD_TRAIN_FUSED_ELEMENTWISE='0')),
+    # kernel-per-op decoder instead of the persistent one, library grid sync + cooperative launch for the bi-GRU
+    ('decode', dict(GVD_PERSISTENT='0', GVD_GRU_BARRIER='cg')),
+    ('decode', dict(GVD_COOP_LAUNCH='1')),
+    ('decode', dict(GVD_COMPACT='0')),                       # dense preamble (every masked proposal computed)
+    ('train', dict(GVD_TRAIN_COMPACT='1')),                  # compacted training layout
+    ('train', dict(GVD_GRU_BARRIER='cg')),
+    # forced grid-barrier timeouts (spin limit 1): forward / Trainer.step switch the persistent kernels off, recompute and
+    # still deliver the reference result (tools/knob_check.py asserts the warning and the switch)
+    ('timeout_decode', dict(GVD_SPIN_LIMIT='1')),
+    ('timeout_train', dict(GVD_SPIN_LIMIT='1')),
 ]
 
 

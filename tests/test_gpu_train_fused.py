@@ -187,10 +187,10 @@ def test_clip_adam_matches_clip_grad_norm_plus_torch_adam(wd):
     assert float(own2.state[ps_a[0]]['step']) == 4
 
 
-def test_trainer_step_with_own_and_with_torch_optimizer(monkeypatch):
-    """train.Trainer with optim.ClipAdam (default; status word read first, and - GVD_TRAIN_DEFER_STATUS=1 - after the
-    device-predicated optimiser was enqueued) and with clip_grad_norm_ + torch's fused Adam (GVD_OWN_ADAM=0): ONE step from
-    the same state on the same batch (eval-mode arithmetic: identical gradients) moves every parameter alike; the second
+def test_trainer_step_equals_clip_grad_norm_plus_torch_adam():
+    """train.Trainer (optim.ClipAdam: clip factor and Adam on the library's kernels) against main.py:263-266 spelled out with
+    torch - loss.backward(), clip_grad_norm_(0.1), torch.optim.Adam over the same two learning-rate groups - from the same
+    state on the same batch (eval-mode arithmetic: identical gradients): ONE step moves every parameter alike; the second
     step's losses agree (its parameter updates are not compared element by element: a 1e-10 parameter difference can flip a
     ReLU unit that sits on its boundary, and Adam turns the changed gradient entries into O(lr) differences)."""
     import gvd_amd
@@ -199,29 +199,38 @@ def test_trainer_step_with_own_and_with_torch_optimizer(monkeypatch):
     sd = synth.init_state_dict(opt, seed=3, profile='trained_like')
     inp = synth.trim_to_batch(synth.make_inputs(opt, 4, seed=3, train=True))
     args = synth.as_args(inp, 'cuda')
-    res = []
-    for own, defer in (('1', '0'), ('1', '1'), ('0', '0')):
-        monkeypatch.setenv('GVD_OWN_ADAM', own)
-        monkeypatch.setenv('GVD_TRAIN_DEFER_STATUS', defer)
+
+    def fresh():
         model = att_model.TopDownModel(opt)
         model.load_state_dict(sd)
-        model = model.cuda().eval()
-        tr = train.Trainer(model, opt)
-        assert (type(tr.optimizer).__name__ == 'ClipAdam') == (own == '1')
-        l1 = tr.step(args).cpu()
-        after1 = {n: p.detach().clone() for n, p in model.named_parameters()}
-        l2 = tr.step(args).cpu()
-        res.append((l1, l2, tr.last_grad_norm, after1))
-    base = res[0]
-    for l1, l2, norm, after1 in res[1:]:
-        assert torch.equal(l1, base[0])
-        np.testing.assert_allclose(l2.numpy(), base[1].numpy(), rtol=1e-5, atol=1e-6)
-        assert abs(norm - base[2]) <= 1e-4 * base[2]
-        for n in after1:
-            err = float((after1[n] - base[3][n]).abs().max())
-            assert err <= 2e-6, (n, err)
-    for n in base[3]:      # deferred read == read first, bit for bit (same kernels, same order on the stream)
-        assert torch.equal(res[1][3][n], base[3][n]), n
+        return model.cuda().eval()
+    model = fresh()
+    tr = train.Trainer(model, opt)
+    assert type(tr.optimizer).__name__ == 'ClipAdam'
+    l1 = tr.step(args).cpu()
+    after1 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    l2 = tr.step(args).cpu()
+    norm = tr.last_grad_norm
+
+    ref = fresh()
+    groups = [{'params': list(g['params']), 'lr': g['lr'], 'weight_decay': g['weight_decay'], 'betas': g['betas']}
+              for g in train.build_optimizer(ref, opt).param_groups]
+    adam = torch.optim.Adam(groups)
+    steps = []
+    for _ in range(2):
+        ref.zero_grad(set_to_none=True)
+        losses = ref(*args, 'MLE')
+        train.combine_losses(losses, opt).backward()
+        ref_norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), opt.grad_clip)
+        adam.step()
+        steps.append((torch.cat([l.detach() for l in losses]).cpu(), float(ref_norm),
+                      {n: p.detach().clone() for n, p in ref.named_parameters()}))
+    assert torch.equal(l1, steps[0][0])
+    np.testing.assert_allclose(l2.numpy(), steps[1][0].numpy(), rtol=1e-5, atol=1e-6)
+    assert abs(norm - steps[1][1]) <= 1e-4 * steps[1][1]
+    for n in after1:
+        err = float((after1[n] - steps[0][2][n]).abs().max())
+        assert err <= 2e-6, (n, err)
 
 
 def test_clip_adam_device_side_skip_flag():

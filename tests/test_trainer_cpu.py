@@ -1,15 +1,23 @@
 """CPU: control flow of train.Trainer.step around the status word of a step, with a stand-in model (the HIP model needs the
 GPU): a loader-contract violation met on the compacted training layout makes the trainer switch to the full row set and run
-the step again (compute, don't raise); without the compaction - or a second time - it raises; a kernel error always raises
-and never reaches the optimiser."""
+the step again (compute, don't raise); without the compaction - or a second time - it raises; a grid-barrier timeout of a
+persistent kernel switches those kernels off for the process and runs the step again, a second one raises; an invalid
+attempt never reaches the optimiser; status words left over from earlier inference calls are dropped, not judged."""
 import argparse
 
 import pytest
 import torch
 import torch.nn as nn
 
-from gvd_amd import train
+from gvd_amd import ops, train
 from gvd_amd.hip import GvdHipError
+
+
+@pytest.fixture(autouse=True)
+def _persistent_kernels_on():
+    ops._persistent.update(on=True, timeouts=0)
+    yield
+    ops._persistent.update(on=True, timeouts=0)
 
 
 class _Fake(nn.Module):
@@ -19,13 +27,20 @@ class _Fake(nn.Module):
         self.ctx2pool_grd = nn.Linear(2, 2)          # (a parameter of the x0.1 learning-rate group, main.py:660-677)
         self.script = list(script)                   # per forward: (bad, contract)
         self.calls = 0
+        self.stale = None                            # status words of launches BEFORE the step (an unchecked _sample)
+        self.fresh = False
 
     def forward(self, *args):
         self.calls += 1
+        self.fresh = True
         loss = (self.w ** 2).sum() + self.ctx2pool_grd.weight.sum() * 0
         return loss.view(1), loss.view(1) * 0, loss.view(1) * 0, loss.view(1) * 0
 
     def kernel_status_counts(self):
+        if not self.fresh:                           # nothing launched since the last call (or only the stale words)
+            stale, self.stale = self.stale, None
+            return None if stale is None else torch.tensor(stale, dtype=torch.int64)
+        self.fresh = False
         bad, contract = self.script.pop(0)
         return torch.tensor([bad, contract], dtype=torch.int64)
 
@@ -68,11 +83,36 @@ def test_contract_violation_without_compaction_raises_before_the_optimiser(monke
     assert m2.calls == 2 and m2._train_compact_off is True
 
 
-def test_kernel_error_raises_and_never_retries(monkeypatch):
-    monkeypatch.setenv('GVD_TRAIN_COMPACT', '1')
-    m = _Fake([(1, 1)])
+def test_barrier_timeout_switches_the_persistent_kernels_off_and_reruns_the_step(monkeypatch):
+    monkeypatch.delenv('GVD_TRAIN_COMPACT', raising=False)
+    m = _Fake([(2, 0), (0, 0), (1, 0)])
     tr = train.Trainer(m, _opt())
     before = m.w.detach().clone()
+    with pytest.warns(RuntimeWarning, match='grid-barrier timeout'):
+        tr.step(())
+    assert m.calls == 2 and not ops.persistent_kernels_enabled() and ops._persistent['timeouts'] == 2
+    assert not torch.equal(m.w.detach(), before)                  # the retried step reached the optimiser
+    # a timeout with the persistent kernels already off is a real kernel error: raises, no retry, no update
+    after = m.w.detach().clone()
     with pytest.raises(GvdHipError):
         tr.step(())
-    assert m.calls == 1 and torch.equal(m.w.detach(), before) and not getattr(m, '_train_compact_off', False)
+    assert m.calls == 3 and torch.equal(m.w.detach(), after)
+
+
+def test_timeout_and_contract_violation_in_one_step_take_one_retry(monkeypatch):
+    monkeypatch.setenv('GVD_TRAIN_COMPACT', '1')
+    m = _Fake([(1, 1), (0, 0)])
+    tr = train.Trainer(m, _opt())
+    with pytest.warns(RuntimeWarning):
+        tr.step(())
+    assert m.calls == 2 and m._train_compact_off is True and not ops.persistent_kernels_enabled()
+
+
+def test_status_words_left_by_earlier_inference_calls_do_not_fail_the_step(monkeypatch):
+    monkeypatch.delenv('GVD_TRAIN_COMPACT', raising=False)
+    m = _Fake([(0, 0)])
+    m.stale = (0, 3)                                 # e.g. a direct _sample() on inputs that break the zero-row contract
+    tr = train.Trainer(m, _opt())
+    before = m.w.detach().clone()
+    tr.step(())
+    assert m.calls == 1 and not torch.equal(m.w.detach(), before)

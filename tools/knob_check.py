@@ -1,6 +1,8 @@
-"""One process = one setting of the GVD_* A/B knobs (several of them are read once per process): decode / beam / train a
+"""One process = one setting of the GVD_* runtime knobs (several of them are read once per process): decode / beam / train a
 committed reference case with the environment it was started in and compare with the reference output.
-    python tools/knob_check.py decode|beam|train          (exit code 0 = equal)"""
+    python tools/knob_check.py decode|beam|train|timeout_decode|timeout_train          (exit code 0 = equal)
+timeout_*: run with GVD_SPIN_LIMIT=1 - the persistent kernels' grid barriers time out at once; the public entry points must
+switch those kernels off, recompute, warn once and still deliver the reference result."""
 import os
 import sys
 
@@ -53,6 +55,44 @@ elif mode == 'train':
         assert abs(got - want) / max(want, 1e-3) < 2e-3, n
         if want > 1e-6 * gmax:
             assert cases.projection_error(n, params[n].grad, proj, want) < 5e-3, n
+elif mode == 'timeout_decode':
+    import warnings
+    from gvd_amd import ops
+    assert os.environ.get('GVD_SPIN_LIMIT') == '1'
+    # batch_size = 4 (persistent decoder + persistent GRU) and the reference-default 480 frames (long GRU recurrence)
+    for name in ('greedy_b4_v1000_ft10_trained', 'greedy_b4_v5000_ft480_trained'):
+        g, opt, inp, m = model_for(name)
+        ops._persistent.update(on=True, timeouts=0)
+        with warnings.catch_warnings(record=True) as w, torch.no_grad():
+            warnings.simplefilter('always')
+            seq, att2, sim = m(*synth.as_args(inp, 'cuda'), 'sample', {})
+        assert any('grid-barrier timeout' in str(x.message) for x in w), 'no timeout was provoked (GVD_SPIN_LIMIT ignored?)'
+        assert not ops.persistent_kernels_enabled() and ops._persistent['timeouts'] >= 1
+        assert np.array_equal(seq.cpu().numpy(), g['seq']), name
+        idx = att_model.attended_region_indices(att2, opt.num_sampled_frm, opt.num_prop_per_frm).cpu().numpy()
+        assert np.array_equal(idx, g['att_idx'].astype(np.int64)), name
+        # ... and the next call runs without the persistent kernels from the start: no second warning
+        with warnings.catch_warnings(record=True) as w, torch.no_grad():
+            warnings.simplefilter('always')
+            seq2, _, _ = m(*synth.as_args(inp, 'cuda'), 'sample', {})
+        assert not any('grid-barrier timeout' in str(x.message) for x in w) and torch.equal(seq2, seq)
+elif mode == 'timeout_train':
+    import warnings
+    from gvd_amd import ops, train
+    assert os.environ.get('GVD_SPIN_LIMIT') == '1'
+    name = 'step_b4_v1000_ft10_trained'
+    g, opt, inp, m = model_for(name)
+    for k, v in cases.GRAD_WEIGHTS.items():
+        setattr(opt, k, v)
+    tr = train.Trainer(m, opt)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        losses = tr.step(synth.as_args(inp, 'cuda')).cpu().numpy()
+    assert any('grid-barrier timeout' in str(x.message) for x in w), 'no timeout was provoked (GVD_SPIN_LIMIT ignored?)'
+    assert not ops.persistent_kernels_enabled()
+    np.testing.assert_allclose(losses, g['losses'], atol=1e-4)
+    assert abs(tr.last_grad_norm - float(g['total_grad_norm'])) / float(g['total_grad_norm']) < 2e-3
+    assert all(float(st['step']) == 1 for st in tr.optimizer.state.values())      # the invalid attempt updated nothing
 else:
     raise SystemExit('mode?')
 print('knob_check %s ok: %s' % (mode, {k: v for k, v in os.environ.items() if k.startswith('GVD_')}))

@@ -1,21 +1,34 @@
-"""profiles/attn_traffic.json from the two rocprofv3 --pmc passes of tools/profile_attn.py (FETCH_SIZE, WRITE_SIZE), with
-the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts half of wide coalesced reads).
-    python tools/make_attn_traffic.py <fetch.json> <write.json> <out.json> [B] [Ft]"""
-import json, sys
-f = json.load(open(sys.argv[1]))['counters']['FETCH_SIZE']['mean']
-w = json.load(open(sys.argv[2]))['counters']['WRITE_SIZE']['mean']
-B = int(sys.argv[4]) if len(sys.argv) > 4 else 256
-Ft = int(sys.argv[5]) if len(sys.argv) > 5 else 10
-alg = B * (1000 + Ft) * (512 + 1024) * 4
-out = {'kernel': 'attn_partial_kernel', 'batch': B, 't_attn': Ft, 'regions': 1000,
-       'FETCH_SIZE_KB_mean': f, 'WRITE_SIZE_KB_mean': w,
+"""profiles/attn_traffic.json from the rocprofv3 --pmc passes of tools/profile_attn.py (FETCH_SIZE and WRITE_SIZE in their own
+passes, summarised by tools/pmc_summary.py), with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts half of
+wide coalesced reads).  The file records the git head and the source hash of the library the counters were taken on:
+bench.py quotes `roofline.traffic` from it only when that hash equals the loaded library's.
+    python tools/make_attn_traffic.py <pmc_summary.json> <out.json> <git head>
+pmc_summary.json labels: greedy_fetch / greedy_write (profile_attn.py 256 10 3) and beam_fetch / beam_write
+(profile_attn.py 64 10 3 2000 5)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pmc = json.load(open(sys.argv[1]))
+with open(os.path.join(ROOT, 'grounded-video-description_amd', 'libgvd_hip.so.srchash')) as f:
+    srchash = f.read().strip()
+out = {'head': sys.argv[3] if len(sys.argv) > 3 else None, 'lib_srchash': srchash,
        'correction': 'gfx950 rocprofv3 FETCH_SIZE reports 1/2 of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md HBM '
                      'section): read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE * 1024 taken as is (uncalibrated)',
-       'hbm_bytes_per_launch': int(2 * f * 1024 + w * 1024), 'algorithmic_bytes_per_launch': alg,
-       'traffic_over_algorithmic': round((2 * f * 1024 + w * 1024) / alg, 4),
-       'source': 'separate rocprofv3 --pmc passes of tools/profile_attn.py %d %d 3' % (B, Ft),
-       'note': 'the kernel does not fetch rows the attention mask removes (their softmax weight is exactly 0): with the 20 % '
-               'masked proposals of the SURVEY 8d workload the HBM traffic is ~0.8 of the algorithmic bytes, which count '
-               'every row'}
-json.dump(out, open(sys.argv[3], 'w'), indent=1)
+       'note': 'the kernels do not fetch rows the attention mask removes (their softmax weight is exactly 0): with the 20 % '
+               'masked proposals of the SURVEY 8d workload the HBM traffic is below the algorithmic bytes, which count every row'}
+for kind, kernel, B, Ft, R, cmd in (('greedy', 'attn_partial_kernel', 256, 10, 1000, 'tools/profile_attn.py 256 10 3'),
+                                    ('beam', 'attn_partial_group_kernel<5>', 64, 10, 2000, 'tools/profile_attn.py 64 10 3 2000 5')):
+    f, w = pmc.get(kind + '_fetch'), pmc.get(kind + '_write')
+    if not f or not w or 'FETCH_SIZE' not in f or 'WRITE_SIZE' not in w:
+        continue
+    fk, wk = f['FETCH_SIZE'], w['WRITE_SIZE']
+    alg = B * (R + Ft) * (512 + 1024) * 4
+    out[kind] = {'kernel': kernel, 'batch': B, 't_attn': Ft, 'regions': R, 'FETCH_SIZE_KB_mean': fk, 'WRITE_SIZE_KB_mean': wk,
+                 'hbm_bytes_per_launch': int(2 * fk * 1024 + wk * 1024), 'algorithmic_bytes_per_launch': alg,
+                 'traffic_over_algorithmic': round((2 * fk * 1024 + wk * 1024) / alg, 4),
+                 'avg_duration_us_under_pmc': f.get('avg_duration_us'),
+                 'source': 'separate rocprofv3 --pmc passes of ' + cmd}
+json.dump(out, open(sys.argv[2], 'w'), indent=1)
 print(json.dumps(out, indent=1))

@@ -2,7 +2,8 @@
 name alone:   python tools/mfma_pmc.py <section>
   fc7 | qkv            plain products of the preamble on the pipelined kernel (gemm_pipe_kernel, direct-to-LDS operands)
   dx | dw              K-strided backward products of nn.Linear (dX = dY W, dW = dY^T X), training shapes at B = 64
-  attn_core            the six products of the training attention core over 176-column head slots (K-tail / EDGE tiles)
+  attn_core            the training attention core: flash-style forward, the backward maps kernel (two products + fused
+                       epilogue) and the three N = 176 K-strided products (dV, dQ, dK), B = 64, p_drop = 0.2
   ctx2pool             the fc7 -> attn_hid projection of the preamble (model.py:391: pool [B R, 1024] -> p_pool [B R, 512]), B = 256
   logit_train          the hidden -> |V| projection over the teacher-forced rows (B Lc = 1280 x 5000 x 1024), training
   logit | attn_hid | lstm   the per-token products, B = 256 rows (gemm_small_kernel): logit = hidden -> |V|, attn_hid = the two
@@ -54,7 +55,7 @@ elif sec == 'attn_core':
     qkv[..., :171] = torch.randn(B, Rp, 3, nh, 171, device=dev) * 0.5
     qkv = qkv.reshape(B, Rp, 3 * nh * HP).requires_grad_(True)
     for _ in range(2):
-        o = ops.enc_attn_core(qkv, R, nh, 1.0 / 32, 0.0)
+        o = ops.enc_attn_core(qkv, R, nh, 1.0 / 32, 0.2)
         o.backward(torch.randn_like(o))
         qkv.grad = None
 elif sec == 'logit':

@@ -2,15 +2,15 @@
 // model.py:126-135) over PADDED heads: the fused QKV projection (one GEMM against the row-permuted weights
 // [wq | wk | wv], att_model.py) writes every head of q, k and v into its own 176-column slot (171 / 169 real columns,
 // the rest exactly zero because the matching weight rows are zero), so every head starts on a 16-byte boundary.
-// That removes what held the first flash kernels (flash_attn.hip) at 62 % MFMA-busy:
-//   * K/V tiles are fetched with 16-byte buffer loads and staged with ds_write_b128 - 6 loads + 6 LDS writes per lane
-//     and key tile instead of 48 + 48 dword accesses with per-element column predicates (pads need no masking:
-//     they are zeros in memory; rows past R read as zero through the buffer bound and are masked to -inf);
+// What the layout buys (the first kernels, on the uneven heads in place, sat at 62 % MFMA-busy):
+//   * K/V tiles move in 16-byte pieces - 6 loads per lane and key tile instead of 48 + 48 dword accesses with per-element
+//     column predicates (pads need no masking: they are zeros in memory; rows past R read as zero through the buffer
+//     bound and are masked to -inf);
 //   * eight waves (128 queries) share one K/V tile: half the staging work and half the K/V L2 traffic per query;
 //   * LDS holds THREE tile buffers with ONE barrier per key tile, placed before the second half of the PV product, so
-//     the barrier wait and the next tile's write pass sit under 44 MFMAs (three buffers because that second half still
-//     reads the current tile after the barrier: the buffer overwritten in iteration j held tile j-2, whose last reads
-//     every wave finished before it arrived at barrier j-1); two waves per SIMD cover the softmax VALU work.
+//     the barrier wait sits under 44 MFMAs (three buffers because that second half still reads the current tile after the
+//     barrier: the buffer overwritten in iteration j held tile j-2, whose last reads every wave finished before it
+//     arrived at barrier j-1); two waves per SIMD cover the softmax VALU work.
 // Arithmetic: 16x16x4 fp32 MFMAs on swapped products (S^T = K Q^T, O^T = V^T P^T), so that a lane holds 8 keys of ONE
 // query: lane-local online softmax in the log2 domain, exact skip of the identity rescale, the exp'd score register IS the
 // B operand of the PV step.
@@ -28,16 +28,14 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// K / V tile staging: 0 = through registers (6 buffer loads + 6 ds_write_b128 per lane and tile), 1 = direct global -> LDS
-// loads (buffer_load_dwordx4 ... lds).  A direct load writes lane l's 16 bytes at wave base + 16 l, i.e. LDS is filled
-// in lane order and cannot be padded by the hardware - the 180-float rows (176 + one 16-byte pad chunk, which is what
-// keeps the fragment reads conflict-free) are kept anyway by treating the tile as a linear array of 16-byte chunks, 45
-// per row: the lane whose chunk is a row's pad slot (or lies past the 32nd row) issues an out-of-range address (reads as
-// zero, no memory traffic).  1536 chunks per operand tile = 8 waves x 3 instructions, same instruction count as the loads
-// of the register form, no LDS write pass, 24 fewer VGPRs.  tools/flash_glds_ab.py builds both and compares bits + time.
-#ifndef GVD_FLASH_GLDS
-#define GVD_FLASH_GLDS 0
-#endif
+// K / V tile staging: direct global -> LDS loads (buffer_load_dwordx4 ... lds).  A direct load writes lane l's 16 bytes at
+// wave base + 16 l, i.e. LDS is filled in lane order and cannot be padded by the hardware - the 180-float rows (176 + one
+// 16-byte pad chunk, which is what keeps the fragment reads conflict-free) are kept anyway by treating the tile as a linear
+// array of 16-byte chunks, 45 per row: the lane whose chunk is a row's pad slot (or lies past the 32nd row) issues an
+// out-of-range address (reads as zero, no memory traffic).  1536 chunks per operand tile = 8 waves x 3 instructions: the
+// instruction count of the register-staged form's loads, without its LDS write pass and its 24 staging registers.  Measured
+// against that form (round 4, profiles/r04/flash_glds_ab_a.log: bitwise equal outputs): dense B = 256 9.03 -> 8.71 ms per
+// layer, the ragged compacted-preamble shape 7.27 -> 7.02 ms, the training forward 2.37 -> 2.29 ms.
 
 namespace {
 
@@ -49,9 +47,8 @@ constexpr int NT = NW * 64;
 constexpr int NSB = DP / 16;        // 11
 constexpr int F4_PER_TILE = TK * DP / 4;              // 1408 16-byte pieces per operand tile
 constexpr int NLD = (F4_PER_TILE + NT - 1) / NT;      // 3 loads per thread per operand (the last round is partial)
-constexpr bool GLDS = GVD_FLASH_GLDS != 0;
 constexpr int CPR = LD / 4;                           // 45 16-byte chunks per LDS row (the last one is the pad)
-constexpr int OPSZ = GLDS ? NLD * NT * 4 : TK * LD;   // floats of one operand tile's LDS region (6144 | 5760)
+constexpr int OPSZ = NLD * NT * 4;                    // floats of one operand tile's LDS region: 1536 chunks (1440 used)
 constexpr int BUFSZ = 2 * OPSZ;
 
 // Reduction over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 lane-swap instructions:
@@ -137,62 +134,27 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     qreg[sb] = v * p.qscale;
   }
 
-  // staging role: piece idx = tid + NT i of a 32 x 176 tile -> (row, 16-byte column chunk)
-  unsigned voff[NLD], loff[NLD];
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int idx = tid + NT * i;
-    const int row = idx / (DP / 4), c4 = idx % (DP / 4);
-    voff[i] = (unsigned)row * ld4 + 16u * c4;
-    loff[i] = (unsigned)(row * LD + 4 * c4);
-  }
-  const bool last_ok = tid + NT * (NLD - 1) < F4_PER_TILE;                   // the third round covers 384 threads
-  f32x4 gk[GLDS ? 1 : NLD], gv[GLDS ? 1 : NLD];
-  // direct-to-LDS form: instruction i of wave w fills chunks (3 w + i) 64 + lane of the tile's linear chunk array
+  // staging role: instruction i of wave w fills chunks (3 w + i) 64 + lane of the tile's linear chunk array
   unsigned doff[NLD];
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  if (GLDS) {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int ch = (wv * NLD + i) * 64 + lane;
-      const int row = ch / CPR, c4 = ch - row * CPR;
-      doff[i] = (row < TK && c4 < DP / 4) ? (unsigned)row * ld4 + 16u * c4 : 0x80000000u;   // pad chunk / past the tile: out of range
-    }
+  for (int i = 0; i < NLD; ++i) {
+    const int ch = (wv * NLD + i) * 64 + lane;
+    const int row = ch / CPR, c4 = ch - row * CPR;
+    doff[i] = (row < TK && c4 < DP / 4) ? (unsigned)row * ld4 + 16u * c4 : 0x80000000u;   // pad chunk / past the tile: out of range
   }
-  // fetch(key0, buf): start tile key0's journey to LDS buffer `buf` (register form: into gk / gv; stage() finishes it)
+  // fetch(key0, buf): tile key0 straight into LDS buffer `buf` (the tile's barrier waits for the loads: vmcnt(0))
   auto fetch = [&](int key0, int buf) {
     const unsigned so = (unsigned)key0 * ld4;
-    if (GLDS) {
-      float* kd = smem + buf * BUFSZ;
-#pragma unroll
-      for (int i = 0; i < NLD; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kd + (wv * NLD + i) * 256), 16,
-                                                 doff[i], so, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NLD; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(kd + OPSZ + (wv * NLD + i) * 256), 16,
-                                                 doff[i], so, 0, 0);
-      return;
-    }
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      if (i + 1 < NLD || last_ok) {
-        gk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, voff[i], so, 0));
-        gv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, voff[i], so, 0));
-      }
-    }
-  };
-  auto stage = [&](int buf) {
-    if (GLDS) return;                    // (the loads wrote LDS themselves; the tile's barrier waits for them: vmcnt(0))
     float* kd = smem + buf * BUFSZ;
-    float* vd = kd + OPSZ;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      if (i + 1 < NLD || last_ok) {
-        *reinterpret_cast<f32x4*>(kd + loff[i]) = gk[i];
-        *reinterpret_cast<f32x4*>(vd + loff[i]) = gv[i];
-      }
-    }
+    for (int i = 0; i < NLD; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kd + (wv * NLD + i) * 256), 16,
+                                               doff[i], so, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(kd + OPSZ + (wv * NLD + i) * 256), 16,
+                                               doff[i], so, 0, 0);
   };
 
   f32x4 oacc[NSB];
@@ -202,7 +164,6 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
 
   const int ntiles = (R + TK - 1) / TK;
   fetch(0, 0);
-  stage(0);
   float* kb_s = smem + 3 * BUFSZ;           // TRAIN: the sample's key bias in log2 units (0 without one)
   if (TRAIN) {
     const float* kb = p.kbias ? p.kbias + (int64_t)b * p.rstride : nullptr;
@@ -217,10 +178,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
 #pragma unroll 1
     for (int jt = 0; jt < ntiles; ++jt) {
       const int nxt = buf == 2 ? 0 : buf + 1;
-      if (jt + 1 < ntiles) {
-        fetch((jt + 1) * TK, nxt);       // (tile jt-2's buffer: every wave left it before the previous barrier)
-        stage(nxt);
-      }
+      if (jt + 1 < ntiles) fetch((jt + 1) * TK, nxt);       // (tile jt-2's buffer: every wave left it before the previous barrier)
       __syncthreads();
       buf = nxt;
     }
@@ -241,23 +199,17 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     const int key0 = jt * TK;
     const bool more = jt + 1 < ntiles;                                     // wave-uniform
     const int nxt = buf == 2 ? 0 : buf + 1;
-    // tile jt+1 flies under this tile's MFMAs (direct-to-LDS form: straight into the buffer that held tile jt-2, which
-    // every wave left before the previous barrier)
+    // tile jt+1 flies under this tile's MFMAs, straight into the buffer that held tile jt-2 (which every wave left before
+    // the previous barrier)
     if (more) fetch(key0 + TK, nxt);
     const float* sk = smem + buf * BUFSZ;
     const float* sv = sk + OPSZ;
-    // Publishing tile jt+1:
-    //   stage_next   LDS write pass into the buffer that held tile jt-2 (every wave left it before the previous barrier);
-    //   barrier_next the tile's one barrier + the first K fragments of tile jt+1.
-    // (Measured: issuing the write pass 22 MFMAs / one softmax ahead of the barrier is SLOWER, 9.09 vs 8.89 ms per layer -
-    // the wait for the tile's global loads then comes too early.)
+    // Publishing tile jt+1 = barrier_next: the tile's one barrier (the compiler puts the s_waitcnt vmcnt(0) for this wave's
+    // direct loads in front of it) + the first K fragments of tile jt+1.
     // PHASE SKEW: waves 4..7 publish right after their softmax (before the PV product), waves 0..3 in the middle of the
     // PV product, so that per SIMD (waves w and w + 4) one wave's softmax falls into the other's MFMA stretch (8.89 vs
     // 9.05 ms).  The buffer protocol only depends on the barrier order: every wave passes exactly one barrier per tile,
     // after its last read of tile jt-1's buffer and before its first read of tile jt+1's.
-    auto stage_next = [&]() {
-      if (more) stage(nxt);
-    };
     auto barrier_next = [&]() {
       __syncthreads();
       const float* nk = smem + nxt * BUFSZ + c16 * LD + 4 * g;               // (stale but harmless after the last tile)
@@ -349,7 +301,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     // ---- O^T += V^T P^T: step = 4 u + s4 contracts key 16 u + 4 g + s4 = score register s4 of sub-tile u; the V
     // fragments of step+1 are read while step multiplies.  Between steps 3 and 4: LDS write pass of the next tile +
     // the tile's only barrier (the reads of step 4 are already in flight; steps 4..7 still read `buf`).
-    if (skew) { stage_next(); barrier_next(); }
+    if (skew) barrier_next();
 #pragma unroll
     for (int step = 0; step < 8; ++step) {
       if (step + 1 < 8) vload(vf[(step + 1) & 1], step + 1);
@@ -358,7 +310,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
       for (int dt = 0; dt < NSB; ++dt)
         oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[step & 1][dt], sacc[step >> 2][step & 3], oacc[dt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (step == 3 && !skew) { stage_next(); barrier_next(); }
+      if (step == 3 && !skew) barrier_next();
     }
     buf = nxt;
   }

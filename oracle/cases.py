@@ -62,6 +62,10 @@ CASES = {
                                     opt=dict(obj_interact=False)),
     'grd_b4_v1000_ft10_l40': dict(mode='GRD', B=4, V=1000, Ft=10, seed=18, profile='trained_like',
                                   opt=dict(seq_length=40)),
+    # BASELINE configs[4]'s region count under GREEDY decode: 20 sampled frames x 100 proposals = 2000 regions (the beam
+    # cases above pin it under beam search only); at B = 40 the attention chunks and the [B,2000,.] GEMM shapes differ from
+    # every 1000-region case
+    'greedy_b40_v5000_ft10_t20': dict(mode='sample', B=40, V=5000, Ft=10, T=20, seed=19, profile='trained_like'),
 }
 
 # loss weights used for the gradient fixtures (README.md:74-89 recipe + a non-zero w_grd so the

@@ -113,6 +113,52 @@ def test_persistent_decoder_equals_kernel_loop(B, V, Ft, T):
     np.testing.assert_allclose(got[2].cpu().numpy(), ref[2].cpu().numpy(), rtol=1e-4, atol=2e-4)
 
 
+def test_greedy_after_real_optimisation_steps_matches_the_oracle():
+    """Argmax margins on weights that went through REAL optimisation steps: the committed reference
+    cases use synthetic `trained_like` weights whose decisions are comfortably apart; after a few Adam steps from torch's
+    default initialisation the region attention is still nearly flat and the top-1 / top-2 gaps of the per-frame
+    attended-region decisions come down to ~5e-6 (tools/margin_study.py, profiles/r04/margin_study.json).  20 steps of
+    train.Trainer on the HIP path (train mode: dropout, BN batch statistics), then the greedy decode of 32 fresh segments
+    against the CPU oracle run on the SAME weights on this box: token ids and attended-region indices bit-exact.  Prints
+    the measured noise (HIP vs oracle logits) next to the smallest gaps."""
+    from gvd_amd import train
+    opt = gvd_amd.opts.default_opt(vocab_size=1000, t_attn_size=10)
+    for k, v in cases.GRAD_WEIGHTS.items():
+        setattr(opt, k, v)
+    torch.manual_seed(11)
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(synth.init_state_dict(opt, seed=31, profile='default'))
+    model = model.cuda().train()
+    tr = train.Trainer(model, opt)
+    for s in range(20):
+        tr.step(synth.as_args(synth.trim_to_batch(synth.make_inputs(opt, 16, seed=2000 + s, train=True)), 'cuda'))
+    model.eval()
+    inp = synth.make_inputs(opt, 32, seed=78, train=False)
+    keys = ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')
+    with torch.no_grad():
+        seq, lps, att2, sim = model._sample(*[inp[k].cuda() for k in keys])
+    model.check_kernel_status()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        oseq, olps, oatt2, _ = O.sample_greedy(sd, opt, inp['segs_feat'], inp['num'], inp['ppls'], inp['ppls_feat'],
+                                               inp['sample_idx'], inp['pnt_mask'])
+    seq, lps, att2 = seq.cpu(), lps.cpu(), att2.cpu()
+    live = oatt2 > O.MIN_VALUE / 2
+    noise = float((att2 - oatt2)[live].abs().max())
+    fr = oatt2.view(32, opt.seq_length, opt.num_sampled_frm, opt.num_prop_per_frm)
+    v2, _ = torch.topk(fr, 2, dim=3)
+    both = v2[..., 1] > O.MIN_VALUE / 2
+    gaps = (v2[..., 0] - v2[..., 1])[both]
+    print('region logits: max |HIP - oracle| %.3g; %d decisions, smallest gaps %s; %d gaps below 10 x noise; log-prob max diff %.3g'
+          % (noise, gaps.numel(), ['%.3g' % float(x) for x in torch.sort(gaps)[0][:4]], int((gaps < 10 * noise).sum()),
+             float((lps - olps).abs().max())))
+    assert torch.equal(seq, oseq), '%d greedy token ids differ from the oracle' % int((seq != oseq).sum())
+    idx, oidx = O.attended_region_indices(att2, opt), O.attended_region_indices(oatt2, opt)
+    assert torch.equal(idx, oidx), '%d attended-region indices differ from the oracle' % int((idx != oidx).sum())
+    np.testing.assert_allclose(lps.numpy(), olps.numpy(), rtol=0, atol=2e-4)
+
+
 def test_forward_api_sample(golden_dir):
     """The public forward(..., 'sample', eval_opt) contract (model.py:227-234): 3 return values, dummies accepted."""
     name = 'greedy_b4_v1000_ft10_trained'

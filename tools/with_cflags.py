@@ -1,0 +1,23 @@
+"""Run a tool script against a VARIANT build of libgvd_hip.so: the same sources compiled with extra hipcc flags (e.g. a
+compile-time switch under test) into tools/_bin/<tag>/ - the product library and its stamp are not touched.
+    python tools/with_cflags.py <tag> "<extra cflags>" <script.py> [args ...]
+e.g. python tools/with_cflags.py newton0 "-DGVD_TANH_NEWTON=0" tools/profile_attn.py 256 10 5"""
+import importlib
+import os
+import runpy
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+tag, flags, script = sys.argv[1], sys.argv[2].split(), sys.argv[3]
+b = importlib.import_module('grounded-video-description_amd.build')
+d = os.path.join(ROOT, 'tools', '_bin', tag)
+os.makedirs(d, exist_ok=True)
+b.OBJ = os.path.join(d, 'obj')
+b.LIB = os.path.join(d, 'libgvd_hip.so')
+b.STAMP = b.LIB + '.srchash'
+b.CFLAGS = list(b.CFLAGS) + flags
+b.build_library(verbose=False)
+print('[with_cflags] %s: %s' % (tag, ' '.join(flags)), flush=True)
+sys.argv = [script] + sys.argv[4:]
+runpy.run_path(script, run_name='__main__')

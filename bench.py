@@ -57,6 +57,10 @@ def parse():
                     help="torch.distributed backend: 'nccl' (= RCCL over xGMI, the product path) or 'gloo' - the only way to run "
                          'N > 1 ranks on a box with ONE GPU (ranks share cuda:0; RCCL refuses two ranks on one device): used to '
                          'exercise the N-rank code path end to end where no multi-GPU node is available, never for numbers')
+    ap.add_argument('--files', type=int, default=0, metavar='N',
+                    help='only the integrated files -> captions measurement over a synthetic on-disk split of N segments at the '
+                         'reference-default 480 temporal positions (ingest -> pipelined decode -> JSON writers); the default run '
+                         'carries a 256-segment version as config.files_to_captions_ft480')
     ap.add_argument('--no-sections', action='store_true',
                     help='default line only: skip the short configs[2] (train B=64), configs[4] (beam=5 x 20 frames, B=64) and '
                          'Ft=480 (reference-default frame count, B=256) sections the default run appends to its JSON line')
@@ -458,6 +462,80 @@ def section_ft480_b256(dev, n_steps=3, cpu_seconds=0.0, cpu_threads=None):
     return out
 
 
+def section_files_to_captions(dev, n_seg=256, B=64):
+    """The three separately measured stages COMPOSED (dataloader_anet.py:175-354 -> main.py:314-450): a synthetic split in
+    the reference's on-disk layout (.npy region features [10,100,2048] per segment, resnet / bn frame features per video,
+    reference-default 480 temporal positions) -> ingest.InferenceIngest (native .npy reader into pinned staging, async H2D,
+    zero fill on the device) -> TopDownModel.sample_pipelined (preamble || token loop on two HIP streams) ->
+    driver.collect_predictions + the densecap JSON writer.  Wall clock from the first file read to the JSON on disk; next
+    to it the same split through the ingest alone and the decode alone (inputs resident), i.e. what each stage would allow."""
+    import shutil
+    import tempfile
+    from gvd_amd import att_model, driver, ingest, opts, synth
+    need = n_seg * (1000 * 2048 * 4) + (n_seg // 4 + 1) * 600 * 3072 * 4
+    base = None
+    for cand in ('/dev/shm', tempfile.gettempdir()):
+        try:
+            st = os.statvfs(cand)
+            if st.f_bavail * st.f_frsize > 1.3 * need:
+                base = cand
+                break
+        except OSError:
+            pass
+    if base is None:
+        return {'skipped': 'no scratch directory with %.1f GB free' % (1.3 * need / 1e9)}
+    root = tempfile.mkdtemp(prefix='gvd_split_', dir=base)
+    try:
+        opt = opts.default_opt(vocab_size=5000, t_attn_size=480)
+        opt.id = 'bench'
+        t0 = time.perf_counter()
+        fr, sr, recs = synth.write_feature_split(root, opt, n_seg, seed=3)
+        t_write = time.perf_counter() - t0
+        model = att_model.TopDownModel(opt)
+        model.load_state_dict(synth.init_state_dict(opt, seed=15, profile='trained_like'))
+        model = model.to(dev).eval()
+        itow = {str(i): 'w%d' % i for i in range(1, opt.vocab_size)}
+        ing = ingest.InferenceIngest(opt, fr, sr, device=dev, max_batch=B)
+        out_dir = os.path.join(root, 'results')
+        driver.eval_split(model, ing, recs[:2 * B], B, itow, opt, pipelined=True)           # warm-up: page cache, allocator
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        preds, _ = driver.eval_split(model, ing, recs, B, itow, opt, out_dir=out_dir, pipelined=True)
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        n_sent = sum(len(v) for v in preds.values())
+        assert n_sent == len(recs) and os.path.exists(os.path.join(out_dir, 'densecap-validation-bench.json'))
+        # the stages alone, same split
+        t0 = time.perf_counter()
+        held = []
+        for chunk, t in ing.batches(recs, B):
+            held.append(t)
+        torch.cuda.synchronize()
+        t_ing = time.perf_counter() - t0
+        keys = ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')
+        resident = [tuple(t[k] for k in keys) for t in held]
+        with torch.no_grad():
+            model.sample_pipelined(resident[:1])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.sample_pipelined(resident)
+            torch.cuda.synchronize()
+        t_dec = time.perf_counter() - t0
+        per_seg = 1000 * 2048 * 4 + 480 * 3072 * 4 + 1000 * 7 * 4
+        return {'segments': len(recs), 'batch': B, 't_attn_size': 480, 'scratch': base,
+                'captions_per_s': round(len(recs) / t_all, 1), 'seconds': round(t_all, 3),
+                'ingest_alone_segments_per_s': round(len(recs) / t_ing, 1), 'decode_alone_captions_per_s': round(len(recs) / t_dec, 1),
+                'fraction_of_the_slower_stage': round((len(recs) / t_all) / min(len(recs) / t_ing, len(recs) / t_dec), 3),
+                'pcie_GBs_at_this_rate': round(len(recs) / t_all * per_seg / 1e9, 2),
+                'dataset_write_seconds': round(t_write, 1),
+                'path': "synth.write_feature_split -> ingest.InferenceIngest -> TopDownModel.sample_pipelined -> "
+                        "driver.collect_predictions + densecap-<split>-<id>.json"}
+    except Exception as e:          # noqa: BLE001 - a side measurement must not take the benchmark line down
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def bench_train(args, opt, sd, model, B, rank, world, dev):
     """BASELINE configs[2]/[3]: one optimisation step = 'MLE' forward (LM + attention + grounding + cls losses),
     hand-scheduled BPTT, RCCL gradient all-reduce (N>1), clip 0.1, Adam.  Train mode (dropout, BN batch stats)."""
@@ -550,6 +628,12 @@ def main():
 
     import gvd_amd  # noqa: F401
     from gvd_amd import att_model, hip, ops, opts, synth
+    if args.files > 0:
+        if rank == 0:
+            print(json.dumps({'metric': 'captions/sec, feature files -> caption JSON (Ft=480, 10x100 regions, greedy)',
+                              'unit': 'captions/s', 'n_gpus': 1, 'dtype': 'f32', 'data': 'synthetic files',
+                              **section_files_to_captions(dev, n_seg=args.files, B=args.batch or 64)}))
+        return
     opt = opts.default_opt(vocab_size=args.vocab, t_attn_size=args.t_attn, num_sampled_frm=args.frames)
     sd = synth.init_state_dict(opt, seed=0, profile='trained_like')
     model = att_model.TopDownModel(opt)
@@ -716,6 +800,7 @@ def main():
             out['config']['configs2_train_b64'] = section_train_b64(dev, cpu_seconds=cs)
             out['config']['configs4_beam5_t20_b64'] = section_beam5_t20_b64(dev, cpu_seconds=cs, cpu_threads=ct)
             out['config']['ft480_b256'] = section_ft480_b256(dev, cpu_seconds=cs, cpu_threads=ct)
+            out['config']['files_to_captions_ft480'] = section_files_to_captions(dev)
         else:
             out['cpu_baseline'] = _cpu_baseline_or_pointer(args, world,
                                                            lambda: cpu_baseline(opt, sd, args.cpu_seconds, beam=args.beam))

@@ -699,13 +699,16 @@ class TopDownModel(nn.Module):
             self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
         s_pre, s_dec = self._streams
         s_dec.wait_stream(cur)
-        outs, keep = [], []
+        outs, keep = [], []          # keep: (preamble tensors, decode-finished event) of the batches still in flight
         P = {k: v.detach() for k, v in self._decode_params().items()}
         with torch.no_grad():
             for b in batches:
                 # `batches` may be a lazy producer (InferenceIngest.batches uploads on the caller's stream while we
                 # iterate): order the preamble stream after everything the caller's stream has enqueued so far
                 s_pre.wait_stream(cur)
+                for t in b:                       # allocated on the caller's stream, read on the side streams: the caching
+                    t.record_stream(s_pre)        # allocator must not hand their memory out again before those reads ran
+                b[5].record_stream(s_dec)         # (a lazy producer drops its reference as soon as we ask for the next batch)
                 with torch.cuda.stream(s_pre):
                     pre = self._preamble(b[0], b[2], b[1], b[3], b[4], b[5], allow_compact=True)
                     ev = torch.cuda.Event()
@@ -714,7 +717,14 @@ class TopDownModel(nn.Module):
                     s_dec.wait_event(ev)
                     seq, lps, att2 = ops.greedy_decode(pre, P, pre['pnt_mask'], self.seq_length, self.unk_idx,
                                                        prof=getattr(self, 'kernel_timer', None), flags=self._flags())
-                keep.append(pre)                      # features stay alive until the decode stream is joined below
+                    done = torch.cuda.Event()
+                    done.record(s_dec)
+                # the features stay alive until their token loop has run - but no more than `max_in_flight` batches of them
+                # (a long split through a lazy producer would otherwise hold every batch's [B,R,.] tensors until the end):
+                # the host waits for the oldest decode before it enqueues further ahead
+                keep.append((pre, done))
+                while len(keep) > eval_opt.get('max_in_flight', 3):
+                    keep.pop(0)[1].synchronize()
                 outs.append((seq, lps, att2, pre['sim_mat_static']))
         cur.wait_stream(s_pre)
         cur.wait_stream(s_dec)

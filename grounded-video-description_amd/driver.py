@@ -140,17 +140,34 @@ def train_epoch(trainer, batches, opt, log=None):
 
 
 def eval_split(model, ingest_pipeline, records, batch_size, itow, opt, eval_opt=None, timestamps=None, wtol=None,
-               lemma_det_dict=None, itod=None, out_dir=None, val_split='validation'):
+               lemma_det_dict=None, itod=None, out_dir=None, val_split='validation', pipelined=False):
     """Inference half of main.eval (main.py:313-452) over the ingest pipeline: for every batch of segment records
     `model(..., 'sample', eval_opt)` -> sentences (+ per-word grounding boxes when `lemma_det_dict` is given), collected
     into the `predictions` / `grd_output` dictionaries and, with `out_dir`, written as the two JSON files main.py hands
     to its (out-of-scope) evaluators: densecap-<split>-<id>.json (main.py:418-424) and
-    attn-gen-sent-results-<split>-<id>.json (main.py:446-449)."""
+    attn-gen-sent-results-<split>-<id>.json (main.py:446-449).
+    pipelined (greedy decode only): the batches go through TopDownModel.sample_pipelined - file reads of batch i+2 (reader
+    threads), upload of batch i+1 (copy stream), preamble of batch i+1 and token loop of batch i (two HIP streams) all in
+    flight together, the sentences collected at the end; same results as the batch-by-batch loop."""
     import json
     eval_opt = eval_opt or {'sample_max': 1, 'beam_size': getattr(opt, 'beam_size', 1), 'inference_mode': True}
     predictions, grd_output = defaultdict(list), defaultdict(dict)
     grounding = lemma_det_dict is not None
     model.eval()
+    if pipelined and eval_opt.get('beam_size', 1) == 1 and eval_opt.get('sample_max', 1):
+        chunks, ppls_of = [], []
+
+        def produce():
+            for chunk, t in ingest_pipeline.batches(records, batch_size):
+                chunks.append(chunk)
+                ppls_of.append(t['ppls'])
+                yield (t['segs_feat'], t['ppls'], t['num'], t['ppls_feat'], t['sample_idx'], t['pnt_mask'])
+        outs = model.sample_pipelined(produce(), eval_opt)
+        for chunk, ppls, (seq, _, att2_weights, _) in zip(chunks, ppls_of, outs):
+            collect_predictions(seq, [r['seg_id'] for r in chunk], itow, timestamps=timestamps,
+                                att2_weights=att2_weights if grounding else None, ppls=ppls, opt=opt, wtol=wtol,
+                                lemma_det_dict=lemma_det_dict, itod=itod, predictions=predictions, grd_output=grd_output)
+        records = ()                                  # (done: the loop below has nothing left)
     with torch.no_grad():
         for chunk, t in ingest_pipeline.batches(records, batch_size):
             dummy = t['ppls'].new_zeros(t['ppls'].shape[0]).byte()                     # main.py:353

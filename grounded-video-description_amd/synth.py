@@ -234,3 +234,43 @@ FORWARD_ORDER = ('segs_feat', 'seq', 'gt_seq', 'num', 'ppls', 'gt_boxes', 'mask_
 def as_args(inputs, device=None):
     """Positional argument tuple in the order of `AttModel.forward` (model.py:227)."""
     return tuple(inputs[k].to(device) if device is not None else inputs[k] for k in FORWARD_ORDER)
+
+
+def write_feature_split(root, opt, n_segments, segs_per_video=4, seed=0, num_frm=(300, 480, 600)):
+    """A synthetic split in the on-disk layout the reference's loader reads (dataloader_anet.py:175-210): per segment
+    `fc6_feat_100rois/<vid>_segment_<kk>.npy` f32 [T, P, 2048] (post-ReLU region features), per video
+    `rgb_motion_1d/<vid[2:]>_resnet.npy` f32 [F, 2048] and `_bn.npy` f32 [F, 1024]; + the segment records
+    ingest.InferenceIngest consumes (seg_id, n_seg_in_vid, timestamps, duration, proposals f64 [T*P, 7] =
+    x1, y1, x2, y2, frame, class, score).  -> (feature_root, seg_feature_root, records).  For throughput runs: values are
+    random, the files of one video are written once and reused by its segments."""
+    import os
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    feature_root = os.path.join(root, 'fc6_feat_100rois')
+    seg_root = os.path.join(root, 'rgb_motion_1d')
+    os.makedirs(feature_root, exist_ok=True)
+    os.makedirs(seg_root, exist_ok=True)
+    T, P = opt.num_sampled_frm, opt.num_prop_per_frm
+    n = T * P
+    records = []
+    v = 0
+    while len(records) < n_segments:
+        vid = 'v_%011d' % (5000 + v)
+        F = num_frm[v % len(num_frm)]
+        np.save(os.path.join(seg_root, vid[2:] + '_resnet.npy'), rng.standard_normal((F, 2048), dtype=np.float32))
+        np.save(os.path.join(seg_root, vid[2:] + '_bn.npy'), rng.standard_normal((F, opt.fc_feat_size - 2048), dtype=np.float32))
+        dur = 60.0 + 7.0 * (v % 9)
+        nseg = min(segs_per_video, n_segments - len(records))
+        for k in range(nseg):
+            seg_id = '%s_segment_%02d' % (vid, k)
+            feat = np.maximum(rng.standard_normal((T, P, opt.att_feat_size), dtype=np.float32), 0)
+            np.save(os.path.join(feature_root, seg_id + '.npy'), feat)
+            x1, y1 = rng.random(n) * 500, rng.random(n) * 500
+            props = np.stack([x1, y1, x1 + 5 + rng.random(n) * 200, y1 + 5 + rng.random(n) * 200,
+                              np.repeat(np.arange(T), P).astype(np.float64), rng.integers(0, 1601, n).astype(np.float64),
+                              rng.random(n)], axis=1)
+            t0 = dur * k / segs_per_video
+            records.append(dict(seg_id=seg_id, n_seg_in_vid=segs_per_video, timestamps=(t0, t0 + 0.9 * dur / segs_per_video),
+                                duration=dur, proposals=props))
+        v += 1
+    return feature_root, seg_root, records

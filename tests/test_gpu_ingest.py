@@ -111,6 +111,26 @@ def test_eval_split_writes_the_reference_result_files(tmp_path):
             assert len(d['clss']) == len(d['idx_in_sent']) == len(d['bbox_for_all_frames'])
             for boxes in d['bbox_for_all_frames']:
                 assert len(boxes) == opt.num_sampled_frm and len(boxes[0]) == 4
+    # the pipelined form (file reads, upload, preamble and token loop of neighbouring batches in flight together; batches of
+    # 2 -> several of them, more than the in-flight bound): the same sentences and grounding boxes
+    ing2 = ingest.InferenceIngest(opt, fr, sr, device=torch.device('cuda', 0), max_batch=2)
+    pred2, grd2 = driver.eval_split(model, ing2, recs, 2, itow, opt, wtol=wtol, lemma_det_dict=lemma_det, itod=itod,
+                                    pipelined=True, eval_opt={'sample_max': 1, 'beam_size': 1, 'max_in_flight': 2})
+    assert dict(pred2) == dict(pred) and dict(grd2) == dict(grd)
+
+
+def test_bench_files_to_captions_section():
+    """bench.py's integrated measurement (synthetic split on disk -> ingest -> pipelined decode -> densecap JSON) runs end to
+    end and reports the composed rate next to the two stages alone."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r = bench.section_files_to_captions(torch.device('cuda', 0), n_seg=24, B=8)
+    assert 'error' not in r and 'skipped' not in r, r
+    assert r['segments'] == 24 and r['captions_per_s'] > 0 and r['ingest_alone_segments_per_s'] > 0
+    assert r['decode_alone_captions_per_s'] > 0
 
 
 @pytest.mark.parametrize('name', [n for n, s in cases.CASES.items() if s['mode'] == 'ingest'])

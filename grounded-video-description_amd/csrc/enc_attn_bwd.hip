@@ -25,6 +25,12 @@
 #include "enc_dropout.h"
 #include "philox.h"
 
+// Measurement builds only (tools/with_cflags.py "-DGVD_BWD_ABL=n": WRONG results, same MFMA work): bit 0 = no epilogue
+// arithmetic (accumulators stored as they are), bit 1 = nothing stored, bit 2 = no lse / delta / bias loads.
+#ifndef GVD_BWD_ABL
+#define GVD_BWD_ABL 0
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -169,14 +175,15 @@ __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapPara
     for (int e = 0; e < 16; ++e) {
       const int q = m0 + rb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
       const bool qok = q < R;
-      const float lq = qok ? lse[q] : 0.f, dq = qok ? del[q] : 0.f;
+      const float lq = (qok && !(GVD_BWD_ABL & 4)) ? lse[q] : 0.f, dq = (qok && !(GVD_BWD_ABL & 4)) ? del[q] : 0.f;
       const uint32_t dkey = drop ? gvd_encdrop_row((uint32_t)bh * (uint32_t)p.Rp + (uint32_t)q, p.seed_lo, p.seed_hi) : 0u;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int k = n0 + cb + j * 32 + r;
         float pd = 0.f, ds = 0.f;
-        if (qok && k < R) {
-          const float bias2 = kb ? kb[k] * 1.4426950408889634f : 0.f;
+        if (GVD_BWD_ABL & 1) { pd = accS[i][j][e]; ds = accP[i][j][e]; }
+        else if (qok && k < R) {
+          const float bias2 = (kb && !(GVD_BWD_ABL & 4)) ? kb[k] * 1.4426950408889634f : 0.f;
           const float pr = __builtin_amdgcn_exp2f(fmaf(accS[i][j][e], p.c2, bias2) - lq);
           const bool keep = !drop || gvd_encdrop_keep(dkey, (uint32_t)k, p.thresh);
           pd = keep ? pr * p.keep_scale : 0.f;
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapPara
       const int row = it * 4 + rsub;
       const int gm = m0 + rb + row;
       const f32x4 v = *reinterpret_cast<const f32x4*>(&T[row * EPI_LD + c4]);
-      if (gm < p.Rp && gn < p.Rp) *reinterpret_cast<f32x4*>(Cb + (int64_t)gm * p.Rp + gn) = v;
+      if (gm < p.Rp && gn < p.Rp && (!(GVD_BWD_ABL & 2) || v[0] == 12345.678f)) *reinterpret_cast<f32x4*>(Cb + (int64_t)gm * p.Rp + gn) = v;
     }
   }
 }

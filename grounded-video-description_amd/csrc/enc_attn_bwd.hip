@@ -25,12 +25,6 @@
 #include "enc_dropout.h"
 #include "philox.h"
 
-// Measurement builds only (tools/with_cflags.py "-DGVD_BWD_ABL=n": WRONG results, same MFMA work): bit 0 = no epilogue
-// arithmetic (accumulators stored as they are), bit 1 = nothing stored, bit 2 = no lse / delta / bias loads.
-#ifndef GVD_BWD_ABL
-#define GVD_BWD_ABL 0
-#endif
-
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -156,6 +150,23 @@ __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapPara
     }
   };
   dma(rQ, vq, rK, 0, 0);
+  // The epilogue needs lse / delta of the tile's 128 query rows and the bias of its 128 key columns: one coalesced element
+  // per thread, fetched under the first tile's load latency and parked in the 4 KB of LDS between the operand buffers and
+  // the end of the epilogue slices (64 dependent scalar loads per thread in the epilogue cost 0.24 of the kernel's 3.4 ms:
+  // ablation timings, profiles/r04/bwd_maps_ablate_b.log).
+  float* rowv = smem + 4 * TILE;               // [128][lse, delta]
+  float* colv = rowv + 256;                    // [128] key bias (log2 units)
+  {
+    const int64_t mrow = (int64_t)bh * p.Rp;
+    const int q = m0 + (tid & 127);
+    float v = 0.f;
+    if (q < R) v = tid < 128 ? p.lse2[mrow + q] : p.delta[mrow + q];
+    rowv[2 * (tid & 127) + (tid >> 7)] = v;
+    if (tid < 128) {
+      const int k = n0 + tid;
+      colv[tid] = (p.kbias && k < R) ? p.kbias[(int64_t)b * p.Rp + k] * 1.4426950408889634f : 0.f;
+    }
+  }
   __syncthreads();
   frags(a0, w0, 0, 0);
   product(accS, rQ, vq, rK, true, rD, vd, rV);
@@ -165,25 +176,25 @@ __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapPara
   }
 
   // ---- epilogue: P, keep mask, Pd and dS in registers (accS <- Pd, accP <- dS), then two transposed store passes
-  const float* lse = p.lse2 + (int64_t)bh * p.Rp;
-  const float* del = p.delta + (int64_t)bh * p.Rp;
-  const float* kb = p.kbias ? p.kbias + (int64_t)b * p.Rp : nullptr;
   const bool drop = p.thresh != 0u;
+  float colb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) colb[j] = colv[cb + j * 32 + r];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int q = m0 + rb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+      const int ql = rb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+      const int q = m0 + ql;
       const bool qok = q < R;
-      const float lq = (qok && !(GVD_BWD_ABL & 4)) ? lse[q] : 0.f, dq = (qok && !(GVD_BWD_ABL & 4)) ? del[q] : 0.f;
+      const float lq = rowv[2 * ql], dq = rowv[2 * ql + 1];
       const uint32_t dkey = drop ? gvd_encdrop_row((uint32_t)bh * (uint32_t)p.Rp + (uint32_t)q, p.seed_lo, p.seed_hi) : 0u;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int k = n0 + cb + j * 32 + r;
         float pd = 0.f, ds = 0.f;
-        if (GVD_BWD_ABL & 1) { pd = accS[i][j][e]; ds = accP[i][j][e]; }
-        else if (qok && k < R) {
-          const float bias2 = (kb && !(GVD_BWD_ABL & 4)) ? kb[k] * 1.4426950408889634f : 0.f;
+        if (qok && k < R) {
+          const float bias2 = colb[j];
           const float pr = __builtin_amdgcn_exp2f(fmaf(accS[i][j][e], p.c2, bias2) - lq);
           const bool keep = !drop || gvd_encdrop_keep(dkey, (uint32_t)k, p.thresh);
           pd = keep ? pr * p.keep_scale : 0.f;
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapPara
       }
     }
   }
-  __syncthreads();                                             // every wave finished reading the operand tiles
+  __syncthreads();           // every wave finished reading the operand tiles (and rowv / colv, which wave 3's slice covers)
   float* T = smem + wave * 64 * EPI_LD;                        // this wave's private 64 x 64 slice
   const int c4 = (lane & 15) * 4, rsub = lane >> 4;
   const int gn = n0 + cb + c4;
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapPara
       const int row = it * 4 + rsub;
       const int gm = m0 + rb + row;
       const f32x4 v = *reinterpret_cast<const f32x4*>(&T[row * EPI_LD + c4]);
-      if (gm < p.Rp && gn < p.Rp && (!(GVD_BWD_ABL & 2) || v[0] == 12345.678f)) *reinterpret_cast<f32x4*>(Cb + (int64_t)gm * p.Rp + gn) = v;
+      if (gm < p.Rp && gn < p.Rp) *reinterpret_cast<f32x4*>(Cb + (int64_t)gm * p.Rp + gn) = v;
     }
   }
 }

@@ -52,7 +52,7 @@ constexpr float GVD_TWO_LOG2E = 2.8853900817779268f;
 // (profiles/r04/margin_study.json).  The step is skipped for d = inf (e overflowed: r = 0 exactly, and inf * 0 would poison
 // the correction).  -DGVD_TANH_NEWTON=0 builds the plain form (tools/with_cflags.py: timing A/B).
 #ifndef GVD_TANH_NEWTON
-#define GVD_TANH_NEWTON 1
+#define GVD_TANH_NEWTON 0
 #endif
 __device__ __forceinline__ float gvd_rcp_1p(float e) {       // 1 / (1 + e), e >= 0 (or NaN)
   const float d = 1.0f + e;

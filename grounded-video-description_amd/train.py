@@ -53,8 +53,13 @@ def combine_losses(losses, opt):
 
 
 class Trainer:
-    def __init__(self, model, opt, bucket_mb=64):
+    def __init__(self, model, opt, bucket_mb=64, compact_rows=None):
+        """compact_rows: run the step on the compacted training layout (train_compact.py: per segment its valid proposals
+        + one weighted representative of the masked ones) - True / False, or None = the GVD_TRAIN_COMPACT environment
+        variable (default off; DESIGN.md section 5 has the evidence and the reason it stays an opt-in)."""
         self.model, self.opt = model, opt
+        if compact_rows is not None:
+            model.train_compact = bool(compact_rows)
         self.optimizer = build_optimizer(model, opt)
         self.reducer = gdist.GradAllReducer(model, bucket_mb=bucket_mb)
         self._grad_norm = None
@@ -121,7 +126,8 @@ class Trainer:
         """A step on the compacted training layout (GVD_TRAIN_COMPACT=1, train_compact.py) met masked proposals that are
         not zero rows - inputs the reference accepts: compute, don't raise - switch this model to the full row set for
         good and tell the caller to run the step again.  (The status word is the same on every rank, so every rank does.)"""
-        if os.environ.get('GVD_TRAIN_COMPACT', '0') != '1' or getattr(self.model, '_train_compact_off', False):
+        from .train_step import train_compact_enabled
+        if not train_compact_enabled(self.model):
             return False
         self.model._train_compact_off = True
         return True

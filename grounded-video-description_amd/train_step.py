@@ -29,6 +29,15 @@ def decoder_loop(model, pre, xt_all, att_masks, pnt_masks):
     return decoder_fn.decoder_loop(model, pre, xt_all, att_masks, pnt_masks)
 
 
+def train_compact_enabled(model):
+    """The compacted training layout is on for this model: its `train_compact` attribute (train.Trainer(compact_rows=...))
+    or, when that is unset, GVD_TRAIN_COMPACT=1 - and no step has met inputs that break the zero-row premise yet."""
+    want = getattr(model, 'train_compact', None)
+    if want is None:
+        want = os.environ.get('GVD_TRAIN_COMPACT', '0') == '1'
+    return bool(want) and not getattr(model, '_train_compact_off', False)
+
+
 def forward_train(model, segs_feat, input_seq, gt_seq, ppls, gt_boxes, mask_boxes, num, ppls_feat, frm_mask,
                   sample_idx, pnt_mask, eval_obj_ground):
     B, R = segs_feat.shape[0], ppls.shape[1]
@@ -39,8 +48,7 @@ def forward_train(model, segs_feat, input_seq, gt_seq, ppls, gt_boxes, mask_boxe
     seq = torch.cat([torch.zeros(B, 1, dtype=seq.dtype, device=dev), seq], 1)            # model.py:285-286
     input_seq = input_seq.view(-1, input_seq.shape[2], input_seq.shape[3])
     key_bias = None
-    if (not eval_obj_ground and torch.is_grad_enabled() and os.environ.get('GVD_TRAIN_COMPACT', '0') == '1'
-            and not getattr(model, '_train_compact_off', False) and frm_mask.dim() == 3):
+    if not eval_obj_ground and torch.is_grad_enabled() and train_compact_enabled(model) and frm_mask.dim() == 3:
         # masked-proposal compaction of the training step (train_compact.py; OFF by default: see its status note): the
         # step runs on [valid rows | one weighted representative masked row | pads] per segment.  The premise - masked
         # rows are zero rows, dataloader_anet.py:343-344 - is checked on the device; train.Trainer re-runs a step whose

@@ -155,7 +155,15 @@ def test_greedy_after_real_optimisation_steps_matches_the_oracle():
              float((lps - olps).abs().max())))
     assert torch.equal(seq, oseq), '%d greedy token ids differ from the oracle' % int((seq != oseq).sum())
     idx, oidx = O.attended_region_indices(att2, opt), O.attended_region_indices(oatt2, opt)
-    assert torch.equal(idx, oidx), '%d attended-region indices differ from the oracle' % int((idx != oidx).sum())
+    # Two fp32 implementations that differ by `noise` cannot agree on an argmax whose two candidates are closer than that
+    # (here: gaps down to 1e-7 against 1e-6 of summation-order noise): a differing index is accepted ONLY where the oracle's
+    # own top-1 / top-2 gap of that frame is below 4 x the measured noise - a tie within the arithmetic - never elsewhere.
+    diff = idx != oidx
+    if bool(diff.any()):
+        gap_all = torch.where(both, v2[..., 0] - v2[..., 1], torch.full_like(v2[..., 0], float('inf')))
+        assert bool((gap_all[diff] < 4 * noise).all()), \
+            '%d attended-region indices differ from the oracle on decisions that are not ties' % int((gap_all[diff] >= 4 * noise).sum())
+        print('%d attended-region indices differ, all on gaps below 4 x noise' % int(diff.sum()))
     np.testing.assert_allclose(lps.numpy(), olps.numpy(), rtol=0, atol=2e-4)
 
 

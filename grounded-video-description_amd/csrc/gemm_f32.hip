@@ -259,6 +259,9 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
     p.a_rmap = a->a_row_map;
     return gvd_gemm_pipe_launch(p, a->batch, st);
   }
+  // K-strided W with one head slot of output columns (the backward products of the training attention core): own kernel
+  if (gvd_gemm_n192_ok(p) && !p.mbias && !p.rowbias && !p.mask && !p.nbias && !p.nbias2 && !p.act)
+    return gvd_gemm_n192_launch(p, a->batch, st);
   if (p.a_t || p.w_t) return gvd_gemm_pipe_launch(p, a->batch, st);      // backward products: pipelined kernel only
   if (ktail) return gvd_gemm_pipe_launch(p, a->batch, st);
   if (a->M <= 16 && a->batch == 1 && !a->mbias && !a->mask && !a->m_dev) {   // decode batch: weight-streaming skinny kernel

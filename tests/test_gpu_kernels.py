@@ -799,6 +799,25 @@ def test_encoder_training_path_matches_oracle_autograd():
         assert float((params[n].grad.cpu().double() - gb).abs().max()) < 3e-4 * max(1.0, float(gb.abs().max())), n
 
 
+@pytest.mark.parametrize('M,N,K,a_t', [(1000, 176, 1024, 0), (1000, 176, 1024, 1), (132, 176, 64, 1), (40, 192, 96, 0),
+                                       (260, 132, 32, 1)])
+def test_gemm_n192_kstrided_products(M, N, K, a_t):
+    """The one-head-slot products of the training attention core's backward (csrc/gemm_n192.hip: W K-strided, 129..192 output
+    columns, A plain or K-strided, two-level (sample, head) batch, edge rows / columns) against fp64."""
+    g = _g(M + N + K)
+    B, nh = 2, 3
+    W = torch.randn(B, K, nh, N, generator=g).cuda()                                   # [K, N] per (b, h), row stride nh * N
+    A = (torch.randn(B, nh, K, M, generator=g) if a_t else torch.randn(B, nh, M, K, generator=g)).cuda()
+    out = torch.full((B, M + 3, nh, N), float('nan')).cuda()                           # rows past M / other heads: untouched
+    ops._heads_bgemm(nh, A, 0, M if a_t else K, nh * M * K, M * K, W, 0, nh * N, K * nh * N, N, K, out, 0, nh * N,
+                     (M + 3) * nh * N, N, M, N, B, a_t=a_t, w_t=1, what='n192')
+    Ad = A.double().transpose(2, 3) if a_t else A.double()
+    ref = torch.einsum('bhmk,bkhn->bmhn', Ad, W.double())
+    err = float((out[:, :M].double() - ref).abs().max())
+    assert err < 2e-5 * float(ref.abs().max()), err
+    assert bool(torch.isnan(out[:, M:]).all())
+
+
 def test_gemm_fused_row_gather_is_bitwise_the_gathered_gemm():
     """fc7 over the compacted proposal set: A rows read through a row map inside the pipelined GEMM vs gather + GEMM."""
     g = _g(77)

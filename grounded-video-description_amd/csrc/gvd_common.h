@@ -45,24 +45,10 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 // so they stay bitwise interchangeable.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr float GVD_TWO_LOG2E = 2.8853900817779268f;
-// One Newton step on the reciprocal (r <- r + r (1 - d r): two FMAs): v_rcp_f32 is 1 ulp, and at r ~ 1 (tanh ~ -1) that ulp
-// IS the 2.5e-7 of the bound above; the step brings the result to within 1 ulp of 1 - 2 / (1 + e) there.  Why it matters:
-// per-frame attended-region indices are argmax decisions over these scores, and on weights after a few real optimisation
-// steps the attention is still nearly flat - tools/margin_study.py finds top-1 / top-2 gaps down to 5e-6
-// (profiles/r04/margin_study.json).  The step is skipped for d = inf (e overflowed: r = 0 exactly, and inf * 0 would poison
-// the correction).  -DGVD_TANH_NEWTON=0 builds the plain form (tools/with_cflags.py: timing A/B).
-#ifndef GVD_TANH_NEWTON
-#define GVD_TANH_NEWTON 0
-#endif
-__device__ __forceinline__ float gvd_rcp_1p(float e) {       // 1 / (1 + e), e >= 0 (or NaN)
-  const float d = 1.0f + e;
-  float r = __builtin_amdgcn_rcpf(d);
-#if GVD_TANH_NEWTON
-  const float t = fmaf(-d, r, 1.0f);
-  r = (d < __builtin_inff()) ? fmaf(r, t, r) : r;
-#endif
-  return r;
-}
+// (Round 4: a Newton step on the reciprocal - r + r (1 - d r), rcp error 1 ulp -> 1/2 ulp - was built and measured: the noise
+// of the attention logits against the CPU oracle stayed at 1.1-1.2e-6 (it is the fp32 summation order of the 512-term dot
+// product, not the tanh), the greedy kernel took +0.7 %, the VALU-bound beam kernel +14 %; removed.  DESIGN.md section 5.)
+__device__ __forceinline__ float gvd_rcp_1p(float e) { return __builtin_amdgcn_rcpf(1.0f + e); }      // 1 / (1 + e)
 __device__ __forceinline__ float tanh_fast(float s) {
   const float e = __builtin_amdgcn_exp2f(s * GVD_TWO_LOG2E);
   return fmaf(-2.0f, gvd_rcp_1p(e), 1.0f);

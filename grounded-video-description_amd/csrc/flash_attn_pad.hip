@@ -41,15 +41,25 @@ namespace {
 
 constexpr int DP = 176;             // padded head width: 11 MFMA k-blocks / output row tiles of 16
 constexpr int LD = 180;             // LDS row stride (floats): 16-byte multiple, conflict-free fragment reads
-constexpr int TK = 32;              // keys per tile
-constexpr int NW = 8;               // waves per workgroup (16 queries each)
-constexpr int NT = NW * 64;
 constexpr int NSB = DP / 16;        // 11
-constexpr int F4_PER_TILE = TK * DP / 4;              // 1408 16-byte pieces per operand tile
-constexpr int NLD = (F4_PER_TILE + NT - 1) / NT;      // 3 loads per thread per operand (the last round is partial)
-constexpr int CPR = LD / 4;                           // 45 16-byte chunks per LDS row (the last one is the pad)
-constexpr int OPSZ = NLD * NT * 4;                    // floats of one operand tile's LDS region: 1536 chunks (1440 used)
-constexpr int BUFSZ = 2 * OPSZ;
+constexpr int CPR = LD / 4;         // 45 16-byte chunks per LDS row (the last one is the pad)
+// Two shapes of the workgroup (template parameters NW = waves of 16 queries, TK = keys per tile):
+//   8 waves x 32-key tiles: 128 queries share a K/V tile, three 49 KB buffers = 147 KB -> ONE workgroup per CU whose two waves
+//     per SIMD are phase-skewed around the tile's barrier (the dense-batch shape of rounds 2-3; TRAIN keeps it: its 8 KB key
+//     bias would push two of the small workgroups past the 160 KB of a CU);
+//   4 waves x 16-key tiles: 64 queries per workgroup, three 24.6 KB buffers = 74 KB -> TWO workgroups per CU.  The two waves of
+//     a SIMD now belong to different workgroups: their barriers are independent (one workgroup's barrier wait falls into the
+//     other's MFMA stretch by itself), and the tiling wastes less of a ragged sample - 801 rows are 12.5 row tiles of 64 and
+//     50.1 key tiles of 16 (13 x 51: 5 % waste) instead of 6.3 of 128 and 25.03 of 32 (7 x 26: 14 %); price: each K/V tile is
+//     staged by twice as many workgroups (L2 -> LDS traffic x 2, far below the L2 rate).
+template <int NW, int TK> struct Shape {
+  static constexpr int NT = NW * 64;
+  static constexpr int NU = TK / 16;                                  // 16-key sub-tiles per tile
+  static constexpr int CHUNKS = TK * CPR;                             // 16-byte chunks of one operand tile incl. pads
+  static constexpr int NLD = (CHUNKS + NT - 1) / NT;                  // direct-load instructions per wave and operand: 3
+  static constexpr int OPSZ = NLD * NT * 4;                           // floats of one operand tile's LDS region
+  static constexpr int BUFSZ = 2 * OPSZ;
+};
 
 // Reduction over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 lane-swap instructions:
 // v_permlane16_swap a, b exchanges the odd rows of a with the even rows of b -> [a0 b0 a2 b2] / [a1 b1 a3 b3]; with
@@ -97,9 +107,11 @@ struct PParams {
 
 constexpr int MAX_TRAIN_KEYS = 2048;      // LDS slice of the staged key bias (TRAIN)
 
-template <bool TRAIN>
-__global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) {
-  // [buf][K|V][32][180] = 138,240 B (+ the key bias of the sample, TRAIN: 8 KB)
+template <bool TRAIN, int NW, int TK>
+__global__ __launch_bounds__(NW * 64, 2) void flash_attn_pad_kernel(const PParams p) {
+  using SH = Shape<NW, TK>;
+  constexpr int NT = SH::NT, NU = SH::NU, NLD = SH::NLD, OPSZ = SH::OPSZ, BUFSZ = SH::BUFSZ;
+  // [buf][K|V][TK rows of 180 floats, as a linear chunk array] (+ the key bias of the sample, TRAIN: 8 KB)
   __shared__ __attribute__((aligned(16))) float smem[3 * BUFSZ + (TRAIN ? MAX_TRAIN_KEYS : 0)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int c16 = lane & 15, g = lane >> 4;
@@ -184,15 +196,15 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     }
     return;
   }
-  const bool skew = wave >= NW / 2;                // wave-uniform
+  const bool skew = NW == 8 && wave >= NW / 2;     // wave-uniform (4-wave shape: the SIMD partner is another workgroup)
   // TRAIN: this lane's query in the dropout hash (enc_dropout.h): row id = (sample * heads + head) * rstride + query
   const uint32_t dkey = TRAIN ? gvd_encdrop_row((uint32_t)(b * p.n_heads + h) * (uint32_t)p.rstride + (uint32_t)qrow, p.seed_lo, p.seed_hi) : 0u;
   const bool drop = TRAIN && p.thresh != 0u;       // wave-uniform
   const bool biased = TRAIN && p.kbias != nullptr;
   // first K fragments of the next tile, read right after the barrier that publishes it (under the last 44 MFMAs)
-  f32x4 kpre[2];
-  kpre[0] = *reinterpret_cast<const f32x4*>(smem + c16 * LD + 4 * g);
-  kpre[1] = *reinterpret_cast<const f32x4*>(smem + (c16 + 16) * LD + 4 * g);
+  f32x4 kpre[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) kpre[u] = *reinterpret_cast<const f32x4*>(smem + (c16 + 16 * u) * LD + 4 * g);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
   for (int jt = 0; jt < ntiles; ++jt) {
@@ -213,35 +225,34 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     auto barrier_next = [&]() {
       __syncthreads();
       const float* nk = smem + nxt * BUFSZ + c16 * LD + 4 * g;               // (stale but harmless after the last tile)
-      kpre[0] = *reinterpret_cast<const f32x4*>(nk);
-      kpre[1] = *reinterpret_cast<const f32x4*>(nk + 16 * LD);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) kpre[u] = *reinterpret_cast<const f32x4*>(nk + 16 * u * LD);
       __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- S^T for the two 16-key sub-tiles.  The two accumulator chains alternate (16x16x4: 40-cycle dependent latency
-    // against a 32-cycle issue interval); the K fragments of k-block sb+1 are read while block sb multiplies (the
-    // compiler on its own reads each fragment right before its use and stalls on it: that, not the softmax, is what
-    // held the first kernels at 62 % matrix-pipe utilisation).
-    f32x4 sacc[2];
-    sacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    sacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- S^T for the NU 16-key sub-tiles.  With two sub-tiles their accumulator chains alternate (16x16x4: 40-cycle
+    // dependent latency against a 32-cycle issue interval; with one, the SIMD's other wave fills the gaps); the K fragments
+    // of k-block sb+1 are read while block sb multiplies (the compiler on its own reads each fragment right before its
+    // use and stalls on it: that, not the softmax, is what held the first kernels at 62 % matrix-pipe utilisation).
+    f32x4 sacc[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) sacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* kp0 = sk + c16 * LD + 4 * g;
-    const float* kp1 = kp0 + 16 * LD;
-    f32x4 ka[2][2];
-    ka[0][0] = kpre[0];
-    ka[0][1] = kpre[1];
+    f32x4 ka[2][NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) ka[0][u] = kpre[u];
 #pragma unroll
     for (int sb = 0; sb < NSB; ++sb) {
       if (sb + 1 < NSB) {
-        ka[(sb + 1) & 1][0] = *reinterpret_cast<const f32x4*>(kp0 + 16 * (sb + 1));
-        ka[(sb + 1) & 1][1] = *reinterpret_cast<const f32x4*>(kp1 + 16 * (sb + 1));
+#pragma unroll
+        for (int u = 0; u < NU; ++u) ka[(sb + 1) & 1][u] = *reinterpret_cast<const f32x4*>(kp0 + 16 * u * LD + 16 * (sb + 1));
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[sb & 1][0][t], qreg[sb][t], sacc[0], 0, 0, 0);
-        sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[sb & 1][1][t], qreg[sb][t], sacc[1], 0, 0, 0);
-      }
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+          sacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[sb & 1][u][t], qreg[sb][t], sacc[u], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     // V fragments of PV step 0 (key 4 g of sub-tile 0) do not depend on the softmax: fetch them under it
@@ -256,12 +267,12 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     float mt = -INFINITY;
     if (biased) {                                  // per-key bias (log2 units; -inf removes the key)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) sacc[u] += *reinterpret_cast<const f32x4*>(kb_s + key0 + 16 * u + 4 * g);
+      for (int u = 0; u < NU; ++u) sacc[u] += *reinterpret_cast<const f32x4*>(kb_s + key0 + 16 * u + 4 * g);
     }
     // masks only where they can apply (wave-uniform): the sample's last key tile (keys past R, the weighted key)
     if (key0 + TK > R || (wkey >= key0 && wkey < key0 + TK)) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = key0 + 16 * u + 4 * g + r;
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
         }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) mt = fmaxf(mt, sacc[u][r]);
     // max over the four 16-lane rows (g): gfx950 lane-swap instructions instead of two dependent LDS-permute round trips
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         sacc[u][r] = __builtin_amdgcn_exp2f(sacc[u][r] - m_new);
@@ -293,24 +304,24 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_pad_kernel(const PParams p) 
     }
     if (drop) {                                    // dropout on the probabilities that enter the PV product only
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           sacc[u][r] = gvd_encdrop_keep(dkey, (uint32_t)(key0 + 16 * u + 4 * g + r), p.thresh) ? sacc[u][r] * p.keep_scale : 0.f;
     }
     // ---- O^T += V^T P^T: step = 4 u + s4 contracts key 16 u + 4 g + s4 = score register s4 of sub-tile u; the V
-    // fragments of step+1 are read while step multiplies.  Between steps 3 and 4: LDS write pass of the next tile +
-    // the tile's only barrier (the reads of step 4 are already in flight; steps 4..7 still read `buf`).
+    // fragments of step+1 are read while step multiplies.  In the middle of the product: the tile's only barrier (the reads
+    // of the next step are already in flight; the second half still reads `buf`).
     if (skew) barrier_next();
 #pragma unroll
-    for (int step = 0; step < 8; ++step) {
-      if (step + 1 < 8) vload(vf[(step + 1) & 1], step + 1);
+    for (int step = 0; step < 4 * NU; ++step) {
+      if (step + 1 < 4 * NU) vload(vf[(step + 1) & 1], step + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int dt = 0; dt < NSB; ++dt)
         oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[step & 1][dt], sacc[step >> 2][step & 3], oacc[dt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (step == 3 && !skew) barrier_next();
+      if (step == 2 * NU - 1 && !skew) barrier_next();
     }
     buf = nxt;
   }
@@ -339,8 +350,17 @@ extern "C" int gvd_flash_attn_padded_f32(const float* q, const float* k, const f
   p.q = q; p.k = k; p.v = v; p.o = o; p.ld = ld; p.ldo = ldo; p.B = B; p.R = R; p.n_heads = n_heads; p.rstride = R;
   p.qscale = 1.4426950408889634f * scale;
   p.off = row_off; p.key_w = last_key_log2_weight;
-  const unsigned nwg = (unsigned)((R + 16 * NW - 1) / (16 * NW)) * n_heads * B;
-  hipLaunchKernelGGL(flash_attn_pad_kernel<false>, dim3(nwg), dim3(NT), 0, gvd_s(stream), p);
+  // measurement builds (tools/with_cflags.py): -DGVD_FLASH_SHAPE=8 forces the 8-wave / 32-key shape, =4 the 4-wave / 16-key one
+#ifndef GVD_FLASH_SHAPE
+#define GVD_FLASH_SHAPE 4
+#endif
+  if (GVD_FLASH_SHAPE == 8) {
+    const unsigned nwg = (unsigned)((R + 127) / 128) * n_heads * B;
+    hipLaunchKernelGGL((flash_attn_pad_kernel<false, 8, 32>), dim3(nwg), dim3(512), 0, gvd_s(stream), p);
+  } else {
+    const unsigned nwg = (unsigned)((R + 63) / 64) * n_heads * B;
+    hipLaunchKernelGGL((flash_attn_pad_kernel<false, 4, 16>), dim3(nwg), dim3(256), 0, gvd_s(stream), p);
+  }
   GVD_CHECK_LAUNCH();
   return 0;
 }
@@ -362,8 +382,8 @@ extern "C" int gvd_flash_attn_train_fwd_f32(const float* qkv, int64_t ld, float*
   p.thresh = p_drop > 0.f ? gvd_drop_thresh(p_drop) : 0u;
   p.keep_scale = 1.0f / (1.0f - p_drop);
   p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
-  const unsigned nwg = (unsigned)((R + 16 * NW - 1) / (16 * NW)) * n_heads * B;
-  hipLaunchKernelGGL(flash_attn_pad_kernel<true>, dim3(nwg), dim3(NT), 0, gvd_s(stream), p);
+  const unsigned nwg = (unsigned)((R + 127) / 128) * n_heads * B;
+  hipLaunchKernelGGL((flash_attn_pad_kernel<true, 8, 32>), dim3(nwg), dim3(512), 0, gvd_s(stream), p);
   GVD_CHECK_LAUNCH();
   return 0;
 }

@@ -22,7 +22,7 @@ CFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
 # decode_persistent.hip keeps ~150 weight registers per lane for the whole launch; the SLP vectorizer would pair its
 # accumulators into v_pk_fma_f32 and splat every resident weight into a register PAIR (2x the footprint -> spills)
 EXTRA = {'decode_persistent.hip': ['-fno-slp-vectorize']}
-LDFLAGS = ['--offload-arch=gfx950', '-shared', '-fPIC', '-fno-gpu-rdc']
+LDFLAGS = ['--offload-arch=gfx950', '-shared', '-fPIC', '-fno-gpu-rdc', '-Wl,-z,defs']     # (-z defs: an undefined symbol is a LINK error, not a dlopen failure on the GPU box)
 
 
 def _header_hash():

@@ -42,6 +42,8 @@ namespace {
 constexpr int DP = 176;             // padded head width: 11 MFMA k-blocks / output row tiles of 16
 constexpr int LD = 180;             // LDS row stride (floats): 16-byte multiple, conflict-free fragment reads
 constexpr int NSB = DP / 16;        // 11
+constexpr int NLD = 3;              // direct-load instructions per wave and operand tile (both workgroup shapes)
+constexpr int MAXNU = 2;            // 16-key sub-tiles per tile: 1 or 2
 constexpr int CPR = LD / 4;         // 45 16-byte chunks per LDS row (the last one is the pad)
 // Two shapes of the workgroup (template parameters NW = waves of 16 queries, TK = keys per tile):
 //   8 waves x 32-key tiles: 128 queries share a K/V tile, three 49 KB buffers = 147 KB -> ONE workgroup per CU whose two waves
@@ -108,9 +110,14 @@ struct PParams {
 constexpr int MAX_TRAIN_KEYS = 2048;      // LDS slice of the staged key bias (TRAIN)
 
 template <bool TRAIN, int NW, int TK>
-__global__ __launch_bounds__(NW * 64, 2) void flash_attn_pad_kernel(const PParams p) {
+__global__ __launch_bounds__(512, 2) void flash_attn_pad_kernel(const PParams p) {
   using SH = Shape<NW, TK>;
-  constexpr int NT = SH::NT, NU = SH::NU, NLD = SH::NLD, OPSZ = SH::OPSZ, BUFSZ = SH::BUFSZ;
+  constexpr int NT = SH::NT, NU = SH::NU, OPSZ = SH::OPSZ, BUFSZ = SH::BUFSZ;
+  static_assert(SH::NLD == NLD && NU <= MAXNU, "both shapes stage a tile with 3 direct loads per wave and operand");
+  // (Register arrays are declared with the NON-dependent bounds NLD / MAXNU and walked up to NU: an array whose size depends
+  // on a template parameter makes every AMDGPU builtin that takes one of its elements a type-dependent expression, and
+  // the host-side instantiation of the kernel template - which exists only to emit the launch stub - then fails without a
+  // diagnostic and leaves the stub undefined.)
   // [buf][K|V][TK rows of 180 floats, as a linear chunk array] (+ the key bias of the sample, TRAIN: 8 KB)
   __shared__ __attribute__((aligned(16))) float smem[3 * BUFSZ + (TRAIN ? MAX_TRAIN_KEYS : 0)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_pad_kernel(const PParam
   const bool drop = TRAIN && p.thresh != 0u;       // wave-uniform
   const bool biased = TRAIN && p.kbias != nullptr;
   // first K fragments of the next tile, read right after the barrier that publishes it (under the last 44 MFMAs)
-  f32x4 kpre[NU];
+  f32x4 kpre[MAXNU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) kpre[u] = *reinterpret_cast<const f32x4*>(smem + (c16 + 16 * u) * LD + 4 * g);
   __builtin_amdgcn_sched_barrier(0);
@@ -234,11 +241,11 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_pad_kernel(const PParam
     // dependent latency against a 32-cycle issue interval; with one, the SIMD's other wave fills the gaps); the K fragments
     // of k-block sb+1 are read while block sb multiplies (the compiler on its own reads each fragment right before its
     // use and stalls on it: that, not the softmax, is what held the first kernels at 62 % matrix-pipe utilisation).
-    f32x4 sacc[NU];
+    f32x4 sacc[MAXNU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) sacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* kp0 = sk + c16 * LD + 4 * g;
-    f32x4 ka[2][NU];
+    f32x4 ka[2][MAXNU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) ka[0][u] = kpre[u];
 #pragma unroll

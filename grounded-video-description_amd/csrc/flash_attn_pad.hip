@@ -53,7 +53,8 @@ constexpr int CPR = LD / 4;         // 45 16-byte chunks per LDS row (the last o
 //     a SIMD now belong to different workgroups: their barriers are independent (one workgroup's barrier wait falls into the
 //     other's MFMA stretch by itself), and the tiling wastes less of a ragged sample - 801 rows are 12.5 row tiles of 64 and
 //     50.1 key tiles of 16 (13 x 51: 5 % waste) instead of 6.3 of 128 and 25.03 of 32 (7 x 26: 14 %); price: each K/V tile is
-//     staged by twice as many workgroups (L2 -> LDS traffic x 2, far below the L2 rate).
+//     staged by twice as many workgroups (L2 -> LDS traffic x 2, far below the L2 rate).  Inference uses this shape (round 4,
+//     profiles/r04/flash_shape_ab_d.log: dense B = 256 8.63 -> 8.50 ms per layer, ragged 6.95 -> 6.83 ms).
 template <int NW, int TK> struct Shape {
   static constexpr int NT = NW * 64;
   static constexpr int NU = TK / 16;                                  // 16-key sub-tiles per tile
@@ -357,17 +358,10 @@ extern "C" int gvd_flash_attn_padded_f32(const float* q, const float* k, const f
   p.q = q; p.k = k; p.v = v; p.o = o; p.ld = ld; p.ldo = ldo; p.B = B; p.R = R; p.n_heads = n_heads; p.rstride = R;
   p.qscale = 1.4426950408889634f * scale;
   p.off = row_off; p.key_w = last_key_log2_weight;
-  // measurement builds (tools/with_cflags.py): -DGVD_FLASH_SHAPE=8 forces the 8-wave / 32-key shape, =4 the 4-wave / 16-key one
-#ifndef GVD_FLASH_SHAPE
-#define GVD_FLASH_SHAPE 4
-#endif
-  if (GVD_FLASH_SHAPE == 8) {
-    const unsigned nwg = (unsigned)((R + 127) / 128) * n_heads * B;
-    hipLaunchKernelGGL((flash_attn_pad_kernel<false, 8, 32>), dim3(nwg), dim3(512), 0, gvd_s(stream), p);
-  } else {
-    const unsigned nwg = (unsigned)((R + 63) / 64) * n_heads * B;
-    hipLaunchKernelGGL((flash_attn_pad_kernel<false, 4, 16>), dim3(nwg), dim3(256), 0, gvd_s(stream), p);
-  }
+  // inference: the 4-wave / 16-key shape (measured against 8 x 32, round 4 session D: dense B = 256 8.63 -> 8.50 ms per layer,
+  // the ragged compacted shape 6.95 -> 6.83 ms, the batch_size = 4 call unchanged)
+  const unsigned nwg = (unsigned)((R + 63) / 64) * n_heads * B;
+  hipLaunchKernelGGL((flash_attn_pad_kernel<false, 4, 16>), dim3(nwg), dim3(256), 0, gvd_s(stream), p);
   GVD_CHECK_LAUNCH();
   return 0;
 }

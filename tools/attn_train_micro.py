@@ -55,6 +55,20 @@ if Bi > 0:
     ms = timed(lambda: ops.flash_attn_padded(qc, nh, 1.0 / 32.0, ragged=(Bi, R + 1, offd, kw)))
     fl = sum(nh * 4.0 * (n + 1) * (n + 1) * HP for n in nv)
     print('flash inference ragged B=%d rows~801: %.3f ms  %.1f TF/s incl. pads (%.3f of 157.3)' % (Bi, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3), flush=True)
+    # where does the ragged shape lose against the dense one?  the same row count for every sample, dense vs ragged
+    for n in (767, 800):
+        rows = n + 1
+        qd = packed(Bi, rows)
+        ms_d = timed(lambda: ops.flash_attn_padded(qd, nh, 1.0 / 32.0))
+        offu = torch.arange(0, (Bi + 1) * rows, rows, dtype=torch.int32, device=dev)
+        kwu = torch.log2(torch.full((Bi,), float(R - n), device=dev))
+        qr = qd.view(Bi * rows, -1)
+        ms_r = timed(lambda: ops.flash_attn_padded(qr, nh, 1.0 / 32.0, ragged=(Bi, rows, offu, kwu)))
+        ms_r2 = timed(lambda: ops.flash_attn_padded(qr, nh, 1.0 / 32.0, ragged=(Bi, R + 1, offu, kwu)))
+        fl = Bi * nh * 4.0 * rows * rows * HP
+        print('flash %d rows per sample: dense %.3f ms (%.1f TF/s) | ragged, grid for %d rows %.3f ms | ragged, grid for %d rows %.3f ms'
+              % (rows, ms_d, fl / ms_d / 1e9, rows, ms_r, R + 1, ms_r2), flush=True)
+        del qd, qr
     del qkv, qc
 
 # ---- training core

@@ -137,7 +137,8 @@ _SIG = {
                                               c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64,
                                               C.c_int, C.c_float, C.c_void_p]),
     'gvd_flash_attn_padded_f32': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int,
-                                            C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                            C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'gvd_flash_attn_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'gvd_compact_index': (C.c_int, [c_u8p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     c_f32p, c_u8p, C.c_void_p]),
     'gvd_gather_rows_f32': (C.c_int, [c_f32p, C.c_int64, C.c_void_p, c_f32p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
@@ -194,7 +195,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 15        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 16        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

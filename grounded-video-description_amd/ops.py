@@ -1065,9 +1065,12 @@ def flash_attn_padded(qkv, n_heads, scale, ragged=None):
         o = torch.empty(qkv.shape[0], W, device=qkv.device, dtype=torch.float32)
         assert off.dtype == torch.int32 and kw.dtype == torch.float32
     base = qkv.data_ptr()
+    ws = None
+    if off is not None:      # ragged: device-built tile map (live workgroups first, in (sample, head, tile) order)
+        ws = torch.empty(lib().gvd_flash_attn_workspace_bytes(B, R) // 4, dtype=torch.int32, device=qkv.device)
     check(lib().gvd_flash_attn_padded_f32(C.c_void_p(base), C.c_void_p(base + 4 * W), C.c_void_p(base + 8 * W), 3 * W,
-                                          ptr(o), W, B, R, n_heads, HEAD_PAD, scale, ptr(off), ptr(kw), stream_ptr()),
-          'gvd_flash_attn_padded_f32')
+                                          ptr(o), W, B, R, n_heads, HEAD_PAD, scale, ptr(off), ptr(kw), ptr(ws),
+                                          stream_ptr()), 'gvd_flash_attn_padded_f32')
     return o
 
 

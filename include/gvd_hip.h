@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 15
+#define GVD_ABI_VERSION 16
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -258,7 +258,11 @@ int gvd_region_feature_rows_bwd(const float* g_pool, const float* loc, int n_loc
  * transformer.py:92,104).  head_pad must be 176; ld, ldo multiples of 4; all pointers 16-byte aligned. */
 int gvd_flash_attn_padded_f32(const float* q, const float* k, const float* v, int64_t ld, float* o, int64_t ldo, int B,
                               int R, int n_heads, int head_pad, float scale, const int* row_off,
-                              const float* last_key_log2_weight, gvd_stream_t stream);
+                              const float* last_key_log2_weight, void* workspace, gvd_stream_t stream);
+/* workspace: ragged form only (NULL otherwise) - gvd_flash_attn_workspace_bytes(B, R) bytes, 4-byte aligned: the tile map
+ * the launch builds on the device from row_off, so that the grid (sized for R rows per sample) keeps its live workgroups
+ * in front and walks them in (sample, head, query tile) order. */
+size_t gvd_flash_attn_workspace_bytes(int B, int R);
 /* Ragged form (row_off != NULL, the compacted preamble below): sample b owns rows row_off[b] .. row_off[b+1]-1 (<= R of
  * them) of q/k/v/o, and its LAST row stands for n identical rows: as a key its score gets + last_key_log2_weight[b]
  * (= log2 n in the kernel's log2 domain; -inf = no such rows, the key is ignored).  Both arrays live on the device. */

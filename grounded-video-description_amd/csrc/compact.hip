@@ -176,16 +176,37 @@ __global__ __launch_bounds__(256) void fc_feature_kernel(const float* __restrict
   const float* sb = segs + (int64_t)b * Ft * D;
   float v[FC_MAXC];
   float sum = 0.f;
+  // mean over the Ft frames, per column in frame order (the same sequential sums as before: same bits) - but with FOUR
+  // frames x all of the thread's columns (<= 64 loads) in flight before the first add: at the reference-default 480 frames x
+  // 3072 columns the loop with one dependent 4-byte load per add ran at 0.7 TB/s (2.1 ms per B = 256 call, 1.8 % of that step)
+#pragma unroll
+  for (int i = 0; i < FC_MAXC; ++i) v[i] = 0.f;
+  int t = 0;
+  for (; t + 4 <= Ft; t += 4) {
+    float x[FC_MAXC][4];
+#pragma unroll
+    for (int i = 0; i < FC_MAXC; ++i) {
+      const int c = tid + 256 * i;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[i][u] = c < D ? __builtin_nontemporal_load(sb + (int64_t)(t + u) * D + c) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < FC_MAXC; ++i)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[i] += x[i][u];
+  }
+  for (; t < Ft; ++t) {
+#pragma unroll
+    for (int i = 0; i < FC_MAXC; ++i) {
+      const int c = tid + 256 * i;
+      if (c < D) v[i] += sb[(int64_t)t * D + c];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < FC_MAXC; ++i) {
     const int c = tid + 256 * i;
-    float a = 0.f;
-    if (c < D) {
-      for (int t = 0; t < Ft; ++t) a += sb[(int64_t)t * D + c];
-      a = a / (float)Ft;
-    }
-    v[i] = a;
-    sum += a;
+    v[i] = c < D ? v[i] / (float)Ft : 0.f;
+    sum += v[i];
   }
   const float mean = block_sum_256(sum, s_red) / (float)D;
   float q = 0.f;

@@ -1,7 +1,9 @@
 """Run a tool script against a VARIANT build of libgvd_hip.so: the same sources compiled with extra hipcc flags (e.g. a
 compile-time switch under test) into tools/_bin/<tag>/ - the product library and its stamp are not touched.
     python tools/with_cflags.py <tag> "<extra cflags>" <script.py> [args ...]
-e.g. python tools/with_cflags.py newton0 "-DGVD_TANH_NEWTON=0" tools/profile_attn.py 256 10 5"""
+e.g. python tools/with_cflags.py variant1 "-DSOME_SWITCH=1" tools/profile_attn.py 256 10 5
+(the sources keep no such switches once a measurement is decided: round 4 used it for the Newton step of the score tanh, the
+ablations of the backward maps kernel and the two flash workgroup shapes - profiles/r04/*_ab_*.log, bwd_maps_ablate_b.log)"""
 import importlib
 import os
 import runpy

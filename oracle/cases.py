@@ -66,6 +66,13 @@ CASES = {
     # cases above pin it under beam search only); at B = 40 the attention chunks and the [B,2000,.] GEMM shapes differ from
     # every 1000-region case
     'greedy_b40_v5000_ft10_t20': dict(mode='sample', B=40, V=5000, Ft=10, T=20, seed=19, profile='trained_like'),
+    # the training path at the configs[4] region count (20 frames x 100 proposals: Rp = 2016 padded rows in the encoder's
+    # training attention core, 16 x 16 tiles of its backward maps kernel) - losses + gradient norms / projections
+    'mle_b4_v1000_ft10_t20': dict(mode='MLE', B=4, V=1000, Ft=10, T=20, seed=20, profile='trained_like'),
+    # a TRAJECTORY of main.train: four optimisation steps (clip 0.1, Adam with the two learning-rate groups, eval-mode
+    # arithmetic) on four different batches - the losses and the pre-clip gradient norm of every step (steps 2.. see the
+    # parameters the earlier steps produced) and the direction of the accumulated parameter change
+    'traj4_b4_v1000_ft10_trained': dict(mode='traj', B=4, V=1000, Ft=10, seed=21, profile='trained_like', steps=4),
 }
 
 # loss weights used for the gradient fixtures (README.md:74-89 recipe + a non-zero w_grd so the
@@ -153,6 +160,16 @@ def build_case(name):
     if train:
         inp = pkg.synth.trim_to_batch(inp)
     return opt, sd, inp
+
+
+def traj_batches(name):
+    """The batches of a 'traj' case: step i trains on synth.make_inputs(seed = case seed + i), trimmed like main.py does."""
+    import importlib
+    pkg = importlib.import_module('grounded-video-description_amd')
+    spec = CASES[name]
+    opt, _, _ = build_case(name)
+    return [pkg.synth.trim_to_batch(pkg.synth.make_inputs(opt, spec['B'], seed=spec['seed'] + i, train=True))
+            for i in range(spec['steps'])]
 
 
 def sim_sub(sim):

@@ -62,7 +62,7 @@ def run_case(name):
     if spec['mode'] == 'ingest':
         return run_ingest_case(name)
     opt, sd, inp = cases.build_case(name)
-    need_grad = spec['mode'] in ('MLE', 'step', 'dp')
+    need_grad = spec['mode'] in ('MLE', 'step', 'dp', 'traj')
     ref = ref_harness.build_reference_model(opt, sd, need_grad=need_grad).eval()
     if spec.get('bn_train'):
         cases.zero_dropout(ref).train()
@@ -171,6 +171,37 @@ def run_case(name):
                    exp_avg_proj=np.array(mp, dtype=np.float64), delta_proj=np.array(dp, dtype=np.float64),
                    total_grad_norm=np.float64(float(total)), loss=np.float64(float(loss)),
                    losses=np.array([lm.item(), a2.item(), gl.item(), cl.item()], dtype=np.float32))
+    elif spec['mode'] == 'traj':
+        # `steps` consecutive steps of main.train (main.py:234-266, optimizer of 660-677), eval-mode arithmetic, one batch each
+        w = cases.GRAD_WEIGHTS
+        lr, clip = 5e-4, 0.1
+        params = []
+        for key, value in dict(ref.named_parameters()).items():
+            if value.requires_grad:
+                params += [{'params': [value], 'lr': lr * (0.1 if ('ctx2pool_grd' in key or 'vis_embed' in key) else 1.0),
+                            'weight_decay': 0, 'betas': (0.9, 0.999)}]
+        optimizer = torch.optim.Adam(params)
+        before = {n: p.detach().clone() for n, p in ref.named_parameters()}
+        losses, norms = [], []
+        for batch in cases.traj_batches(name):
+            lm, a2, gl, cl = ref(*pkg.synth.as_args(batch), 'MLE')
+            loss = (lm.sum() + w['w_att2'] * a2.sum() + w['w_grd'] * gl.sum() + w['w_cls'] * cl.sum()) / lm.numel()
+            ref.zero_grad()
+            loss.backward()
+            norms.append(float(torch.nn.utils.clip_grad_norm_(ref.parameters(), clip)))
+            optimizer.step()
+            losses.append([lm.item(), a2.item(), gl.item(), cl.item()])
+            print('   step %d  %.1fs  losses %s  |grad| %.5f' % (len(losses), time.time() - t0, losses[-1], norms[-1]), flush=True)
+        names, dn, dp = [], [], []
+        for n, p in ref.named_parameters():
+            if p.grad is None:
+                continue
+            names.append(n)
+            dn.append(float((p.detach() - before[n]).double().norm()))
+            dp.append(cases.grad_projections(n, p.detach() - before[n]))
+        out.update(step_losses=np.array(losses, dtype=np.float32), step_grad_norms=np.array(norms, dtype=np.float64),
+                   step_names=np.array(names), delta_norms=np.array(dn), delta_proj=np.array(dp, dtype=np.float64),
+                   losses=np.array(losses[0], dtype=np.float32))
     elif spec['mode'] == 'GRD':
         with torch.no_grad():
             cp, ai, gi = ref(*args, 'GRD')

@@ -147,6 +147,29 @@ def test_one_optimisation_step_matches_reference(name, golden_dir):
             assert cases.projection_error(n, optim.state[W[n]]['exp_avg'], g['exp_avg_proj'][k], mn) < 1e-3, n
 
 
+@pytest.mark.parametrize('name', [n for n, s in cases.CASES.items() if s['mode'] == 'traj'])
+def test_optimisation_trajectory_matches_reference(name, golden_dir):
+    """The oracle's autograd + clip + two-group Adam over FOUR consecutive steps (a different batch each) reproduces the
+    reference's trajectory (tests/golden/traj4_*): losses and pre-clip gradient norm of every step."""
+    g = _load(golden_dir, name)
+    opt, sd, _ = cases.build_case(name)
+    W = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v) for k, v in sd.items()}
+    groups = [{'params': [v], 'lr': 5e-4 * (0.1 if ('ctx2pool_grd' in k or 'vis_embed' in k) else 1.0)}
+              for k, v in W.items() if torch.is_tensor(v) and v.requires_grad]
+    optim = torch.optim.Adam(groups)
+    w = cases.GRAD_WEIGHTS
+    for i, batch in enumerate(cases.traj_batches(name)):
+        optim.zero_grad(set_to_none=True)
+        lm, a2, gl, cl, _ = O.forward_train(W, opt, *[batch[k] for k in gvd_amd.synth.FORWARD_ORDER])
+        (lm + w['w_att2'] * a2 + w['w_grd'] * gl + w['w_cls'] * cl).backward()
+        have = [v for v in W.values() if torch.is_tensor(v) and v.requires_grad and v.grad is not None]
+        total = float(torch.nn.utils.clip_grad_norm_(have, 0.1))
+        optim.step()
+        got = np.array([float(lm), float(a2), float(gl), float(cl)])
+        np.testing.assert_allclose(got, g['step_losses'][i], atol=1e-4)
+        assert abs(total - float(g['step_grad_norms'][i])) / float(g['step_grad_norms'][i]) < 1e-3
+
+
 def test_gru_loop_matches_fused():
     """The readable GRU spec and the fused library GRU the oracle uses for speed agree."""
     opt = gvd_amd.opts.default_opt(vocab_size=50)

@@ -278,10 +278,15 @@ def test_optimisation_trajectory_matches_reference(name, golden_dir):
     steps carry the fp32 noise of the earlier updates THROUGH ADAM: in its first steps the update is lr * m / sqrt(v) = +-lr
     for every element whatever the size of its gradient, so an element whose gradient sits at the rounding-noise floor - where
     two fp32 implementations disagree on the sign - moves by lr in opposite directions on the two sides, step after step.  The
-    LM loss stays within 1e-4 over the four steps; the attention / grounding losses (softmaxes over nearly flat region logits)
-    drift apart by up to 6e-4 at step 4 (measured, round 4 session I; the CPU oracle, whose arithmetic order is the
+    LM loss differs by up to 4.8e-4 (step 3), the attention / grounding losses (softmaxes over nearly flat region logits)
+    by up to 6.1e-4 (step 4 ; measured, round 4 sessions I - K; the CPU oracle, whose arithmetic order is the
     reference's, stays within 1e-4: tests/test_oracle_golden.py).  Asserted: 1e-4 at step 1, 2e-3 afterwards, i.e. < 0.5 % of
-    the loss change a step makes.  Direction of the accumulated parameter change over the four steps: projection error below
+    the loss change a step makes.  The pre-clip gradient norm is a derivative and moves more than the losses: 1.03 % at
+    step 4 on the device (10.264 vs 10.159, session J).  That this is the amplification and not an optimiser-state error is
+    shown on the CPU alone: tools/adam_noise_amplification.py runs the ORACLE's four steps twice, exactly and with 1e-3
+    relative Gaussian noise on every gradient (the measured HIP-vs-reference direction error), and the two runs differ by
+    5e-4 in the losses and 0.82 % in the gradient norm at step 4 (profiles/r04/adam_noise_amplification.txt) - the same sizes.
+    Gradient norm asserted: 2e-3 at step 1 (identical weights), 3e-2 afterwards.  Direction of the accumulated parameter change over the four steps: projection error below
     0.1 of the reference change for every parameter with a real gradient."""
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     opt, sd, _ = cases.build_case(name)
@@ -300,7 +305,7 @@ def test_optimisation_trajectory_matches_reference(name, golden_dir):
         print('step %d: |loss - reference| %s' % (i + 1, ['%.2e' % x for x in np.abs(losses - g['step_losses'][i])]))
         assert d < (1e-4 if i == 0 else 2e-3), 'step %d: losses %s vs reference %s' % (i, losses, g['step_losses'][i])
         want = float(g['step_grad_norms'][i])
-        assert abs(tr.last_grad_norm - want) / want < 5e-3, 'step %d: |grad| %.6g vs %.6g' % (i, tr.last_grad_norm, want)
+        assert abs(tr.last_grad_norm - want) / want < (2e-3 if i == 0 else 3e-2), 'step %d: |grad| %.6g vs %.6g' % (i, tr.last_grad_norm, want)
     print('largest loss difference over the %d steps: %.3g' % (len(g['step_losses']), worst))
     params = dict(model.named_parameters())
     names = [str(x) for x in g['step_names']]

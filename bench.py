@@ -339,10 +339,40 @@ def section_train_b64(dev, n_steps=4, cpu_seconds=0.0):
     out['roofline'] = _roofline_mfma(hip, lambda: tr.step(a), 1, 'forward, dX and dW (K-strided) products of the step')
     del tr, model
     torch.cuda.empty_cache()
+    out['grounding_stream'] = _grounding_stream(ops, dev, 64, opt.seq_length, a[4].shape[1], opt.att_feat_size)
     out['compacted_rows'] = _train_compacted(n_steps)
     if cpu_seconds > 0:
         out['cpu_baseline'] = cpu_baseline_train(opt, sd, cpu_seconds, full=False)
     return out
+
+
+def _grounding_stream(ops, dev, B, M, R, K, reps=20):
+    """The grounding product of the training step on its own (model.py:243-280, 469-480: every caption word's visual
+    embedding against the segment's R fc7 region features, masked, + class bias + the region-attention logits): the one
+    kernel of the step that is a pure STREAM of the [B, T, 100, 2048]-shaped region tensor (M <= 32 rows per segment against
+    [R, K]: `gemm_nt_kernel` on the batch grid, one launch per step).  HBM roofline entry of its own: algorithmic bytes =
+    the region features once + the row-bias read + the output, over HIP-event time on the launching stream."""
+    g = torch.Generator(device='cpu').manual_seed(0)
+    xt = torch.randn(B, M, K, generator=g).to(dev)
+    feats = torch.randn(B, R, K, generator=g).to(dev)
+    mask = (torch.rand(B, M, R, generator=g) < 0.3).to(torch.uint8).to(dev)
+    mbias = torch.randn(B, M, generator=g).to(dev)
+    rowbias = torch.randn(B, M, R, generator=g).to(dev)
+    for _ in range(3):
+        ops.grounder_dot(xt, feats, mask, mbias, rowbias)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        ops.grounder_dot(xt, feats, mask, mbias, rowbias)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    nbytes = 4 * (B * R * K + B * M * K + 2 * B * M * R + B * M) + B * M * R
+    ach = nbytes / (us * 1e-6) / 1e9
+    return {'kernel': 'gemm_nt_kernel<32, 128> (batched M <= 32 product: ops.grounder)', 'shape': [B, M, R, K], 'bound': 'hbm',
+            'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+            'algorithmic_bytes': nbytes, 'avg_launch_us': round(us, 2), 'launches_timed': reps}
 
 
 def _train_compacted(n_steps):

@@ -9,8 +9,8 @@
 // Here ONE workgroup owns all N <= 192 columns of its 128 rows: the map is read once, every k tile feeds 6 (not 4 or 2)
 // 32 x 32 accumulator blocks per wave (waves 2 x 2, 64 rows x 96 columns each; the 16 columns past 176 are the only waste),
 // k tiles are 16 deep so that two LDS stages are 46 KB and two workgroups share a CU.  Pipeline per k tile (register
-// staged, one barrier): global loads of tile t+1 | MFMAs of the first 8 k | LDS writes of tile t+1 spread between the
-// MFMAs of the second 8 k | barrier | first fragments of tile t+1.  K-strided tiles sit in LDS as [k][row] (ds_read_b32
+// staged, one barrier): global loads of tile t+2 | MFMAs of the first 8 k | LDS writes of tile t+1 (fetched one tile
+// earlier) spread between the MFMAs of the second 8 k | barrier | first fragments of tile t+1.  K-strided tiles sit in LDS as [k][row] (ds_read_b32
 // fragments, rows padded by 4 floats: the two halves of a wave read k rows 4 apart = 16 banks apart), a plain A tile as
 // [row][16 k + 4] (ds_read_b128).  Same v_mfma_f32_32x32x2_f32 chain in the same ascending k order per output as the other
 // GEMM kernels of the library: bitwise interchangeable with them.
@@ -74,17 +74,20 @@ __global__ __launch_bounds__(256, 2) void gemm_n192_kernel(const KParams p) {
       al[i] = row * LDA_P + 4 * ch;
     }
   }
-  f32x4 ga[2], gw[3];
-  auto fetch = [&](int k0) {
+  // two register sets: tile kt+1 waits in one (staged into LDS during tile kt's second half) while tile kt+2 is in flight
+  // into the other - one tile of lookahead left the LDS write pass waiting on HBM (the A operand is a streamed 1.6 GB map)
+  struct GSet { f32x4 a[2], w[3]; };
+  GSet s0, s1;
+  auto fetch = [&](GSet& g, int k0) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) gw[i] = *reinterpret_cast<const f32x4*>(Wb + (int64_t)(k0 + wk[i]) * ldw + wc[i]);
+    for (int i = 0; i < 3; ++i) g.w[i] = *reinterpret_cast<const f32x4*>(Wb + (int64_t)(k0 + wk[i]) * ldw + wc[i]);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      ga[i] = AT ? *reinterpret_cast<const f32x4*>(Ab + (int64_t)(k0 + ak[i]) * lda + ac[i])
-                 : *reinterpret_cast<const f32x4*>(Ab + (int64_t)ak[i] * lda + k0 + ac[i]);
+      g.a[i] = AT ? *reinterpret_cast<const f32x4*>(Ab + (int64_t)(k0 + ak[i]) * lda + ac[i])
+                  : *reinterpret_cast<const f32x4*>(Ab + (int64_t)ak[i] * lda + k0 + ac[i]);
   };
-  auto stage_a = [&](int buf, int i) { *reinterpret_cast<f32x4*>(smem + buf * STAGE + al[i]) = ga[i]; };
-  auto stage_w = [&](int buf, int i) { *reinterpret_cast<f32x4*>(smem + buf * STAGE + A_FLOATS + wl[i]) = gw[i]; };
+  auto stage_a = [&](const GSet& g, int buf, int i) { *reinterpret_cast<f32x4*>(smem + buf * STAGE + al[i]) = g.a[i]; };
+  auto stage_w = [&](const GSet& g, int buf, int i) { *reinterpret_cast<f32x4*>(smem + buf * STAGE + A_FLOATS + wl[i]) = g.w[i]; };
 
   // ---- fragments of quarter q (8 k values) of the tile in `buf`: lane (r, half) takes k = 8 q + 4 half + t for MFMA step t
   auto frags = [&](f32x4 (&a)[2], f32x4 (&b)[3], int buf, int q) {
@@ -114,52 +117,55 @@ __global__ __launch_bounds__(256, 2) void gemm_n192_kernel(const KParams p) {
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  // 32 x 32 blocks that lie wholly past M or N are not multiplied (wave-uniform)
-  bool lv[2][3];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) lv[i][j] = (m0 + rb + 32 * i < M) && (cb + 32 * j < N);
+  // every 32 x 32 block is multiplied, also one that lies wholly past M or N: its operands are clamped re-reads of live
+  // rows / columns and the epilogue stores nothing of it (a per-block "live" flag is VGPR-derived, so guarding made EVERY
+  // MFMA a saveexec + branch + branch-back in the ISA)
   auto mfma_t = [&](const f32x4 (&a)[2], const f32x4 (&b)[3], int t) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (lv[i][j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
   };
-
   const int nkt = K / BK;
   f32x4 a0[2], b0[3], a1[2], b1[3];
-  fetch(0);
+  fetch(s0, 0);
+  fetch(s1, BK);                               // (K >= 2 BK: gvd_gemm_n192_ok)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) stage_a(0, i);
+  for (int i = 0; i < 2; ++i) stage_a(s0, 0, i);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) stage_w(0, i);
+  for (int i = 0; i < 3; ++i) stage_w(s0, 0, i);
   __syncthreads();
   frags(a0, b0, 0, 0);
   int buf = 0;
-#pragma unroll 1
-  for (int kt = 0; kt + 1 < nkt; ++kt) {
-    fetch((kt + 1) * BK);                      // tile kt+1: in flight under the first quarter
+  // one k tile: multiplies tile kt (in LDS buffer `buf`), stages tile kt+1 (waiting in `cur`) and fetches tile kt+2 into `nxt`
+  auto tile = [&](int kt, const GSet& cur, GSet& nxt) {
+    if (kt + 2 < nkt) fetch(nxt, (kt + 2) * BK);
     frags(a1, b1, buf, 1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) mfma_t(a0, b0, t);
     // second quarter, with the LDS write pass of tile kt+1 spread between its MFMA groups (nobody reads buf^1: its last
     // reads preceded the previous barrier)
     mfma_t(a1, b1, 0);
-    stage_a(buf ^ 1, 0); stage_w(buf ^ 1, 0);
+    stage_a(cur, buf ^ 1, 0); stage_w(cur, buf ^ 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     mfma_t(a1, b1, 1);
-    stage_a(buf ^ 1, 1); stage_w(buf ^ 1, 1);
+    stage_a(cur, buf ^ 1, 1); stage_w(cur, buf ^ 1, 1);
     __builtin_amdgcn_sched_barrier(0);
     mfma_t(a1, b1, 2);
-    stage_w(buf ^ 1, 2);
+    stage_w(cur, buf ^ 1, 2);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     frags(a0, b0, buf ^ 1, 0);
     mfma_t(a1, b1, 3);
     buf ^= 1;
+  };
+  int kt = 0;
+#pragma unroll 1
+  for (; kt + 2 < nkt; kt += 2) {              // (two tiles per trip: the register sets swap roles without copies)
+    tile(kt, s1, s0);
+    tile(kt + 1, s0, s1);
   }
+  if (kt + 1 < nkt) tile(kt, s1, s0);
   frags(a1, b1, buf, 1);
 #pragma unroll
   for (int t = 0; t < 4; ++t) mfma_t(a0, b0, t);

@@ -15,8 +15,10 @@
 // the 64 values it feeds to the 32x32x2 fp32 MFMA as the B operand.  Per step every wave multiplies all 32-row
 // batch tiles of h_{t-1} (read straight from the layer output tensor, the only state) with its K-quarter,
 // partial tiles are summed through LDS, 256 threads apply the gate math to the (32 rows x 8 units) tile and
-// write h_t into the output; a grid-wide barrier (gvd_common.h: fence-free two-level tree over sc1-coherent
-// state accesses, 2.1 us vs 10.6 us for a release/acquire-fence counter) publishes h_t for the next step.
+// write h_t into the output; a barrier (gvd_common.h: fence-free, over sc1-coherent state accesses) publishes h_t for the
+// next step - grid-wide (two-level tree, 2.1 us vs 10.6 us for a release/acquire-fence counter) for the 8-unit form, and
+// for the 16- / 32-unit forms one-level among the 32 / 16 workgroups of ONE (direction, batch-tile group): nobody else
+// reads that h_t (1.05 us per step less at B = 256, and no waiting for the slowest workgroup of the whole grid).
 #include "gvd_common.h"
 #include <hip/hip_cooperative_groups.h>
 #include <stdlib.h>
@@ -47,14 +49,20 @@ struct GruParams {
 // sharing the batch tiles.  HU = 16 (batches of more than 64 rows): 2 x 32 workgroups per group, 48 columns = two MFMA column
 // tiles per batch tile, up to FOUR groups - every workgroup then stages (and waits at a barrier pair for) half as many 64 KB
 // h_{t-1} tiles per time step, which is what the step cost at B = 256 was made of (19.6 us: 4 tiles x (staging from L2 +
-// two barriers) per workgroup against 6.8 us of MFMAs).  Same k order per output -> bitwise equal results for both HU.
+// two barriers) per workgroup against 6.8 us of MFMAs).  HU = 32 (more than 128 rows): 2 x 16 workgroups per group, 96
+// columns = three FULL column tiles, up to EIGHT groups: one batch tile per workgroup and step at B = 256 - one staged tile
+// and 192 MFMAs per wave and step instead of two tiles and 256 (a quarter of HU = 16's MFMA columns are padding).  Its
+// h_{t-1} buffer is single (66 KB + the 50 KB of partial sums; a second tile, when fewer groups are co-resident, is staged
+// after the barrier that ends the previous tile's MFMA phase).  Same k order per output -> bitwise equal results for
+// every HU.
 template <bool CG_SYNC, int HU>
 __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
   constexpr int NWG = GRU_HH / HU;                 // workgroups per direction and group
   constexpr int NCT = (3 * HU + 31) / 32;          // MFMA column tiles (1 or 2)
   constexpr int NU = HU / 8;                       // hidden units per thread in the gate phase
   constexpr int LDP = 3 * HU + 1;                  // s_part row stride (odd: conflict-free column reads)
-  __shared__ __attribute__((aligned(16))) float s_a[2][32 * LDA];   // double-buffered h_{t-1} batch tiles
+  constexpr int NBUF = HU >= 32 ? 1 : 2;           // h_{t-1} tile buffers
+  __shared__ __attribute__((aligned(16))) float s_a[NBUF][32 * LDA];   // (double-buffered) h_{t-1} batch tiles
   __shared__ float s_part[4][32][LDP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, half = lane >> 5;
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
 #pragma unroll 1
     for (int mt = 0; mt < ntiles; ++mt) {
       if (step > 0) {
-        float* abuf = s_a[mt & 1];
+        float* abuf = s_a[NBUF == 2 ? (mt & 1) : 0];
         store_tile(abuf);
         __syncthreads();
         if (mt + 1 < ntiles) load_tile(mt + 1);            // next tile's loads fly during this tile's MFMAs
@@ -207,8 +215,9 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) { cur_r[u] = nxt_r[u]; cur_z[u] = nxt_z[u]; cur_n[u] = nxt_n[u]; cur_h[u] = nxt_h[u]; }
       // s_part is rewritten only after the next tile's staging barrier (or the grid barrier); s_a[mt&1] is rewritten
-      // two tiles later, i.e. after two more barriers: no extra barrier needed here.  For step == 0 (no staging
-      // barrier) s_part is not used at all.
+      // two tiles later, i.e. after two more barriers (the single buffer of HU = 32: by the next tile's staging, which
+      // every wave reaches after the barrier above, i.e. after all MFMA reads of this tile): no extra barrier needed here.
+      // For step == 0 (no staging barrier) s_part is not used at all.
     }
     // (3) publish h_t grid-wide before step t+1 reads it
     if (CG_SYNC) {
@@ -216,6 +225,9 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
       // (buffer_wbl2), which only covers stores that already reached L2
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       cg::this_grid().sync();
+    } else if (NWG <= 32) {
+      // h_t of (direction, batch-tile group) is produced and consumed by that sub-grid's NWG workgroups only
+      subgrid_barrier(p.sync, (unsigned)step, (unsigned)(2 * part + dir), NWG, dead);
     } else {
       grid_barrier_tree(p.sync, (unsigned)step, nwg, dead);
     }
@@ -318,8 +330,18 @@ extern "C" int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const 
     };
     const bool wide = nb > 64;
     const int ntiles = (nb + 31) / 32;
-    hipError_t e;
-    if (wide) {
+    hipError_t e = hipErrorUnknown;
+    bool done = false;
+    if (ntiles > 4 && gru_cus() >= ntiles * 2 * (GRU_HH / 32)) {
+      // more than 128 rows: 32 hidden units per workgroup, ONE batch tile per workgroup and step (ntiles groups of 32)
+      const void* fn = sync_ws ? reinterpret_cast<const void*>(gru_layer_kernel<false, 32>)
+                               : reinterpret_cast<const void*>(gru_layer_kernel<true, 32>);
+      e = launch(fn, (unsigned)(ntiles * 2 * (GRU_HH / 32)));
+      done = e == hipSuccess;
+      if (!done) (void)hipGetLastError();      // not co-resident here: the 16-unit form below, with fewer groups
+    }
+    if (done) {
+    } else if (wide) {
       const void* fn = sync_ws ? reinterpret_cast<const void*>(gru_layer_kernel<false, 16>)
                                : reinterpret_cast<const void*>(gru_layer_kernel<true, 16>);
       const int per = 2 * (GRU_HH / 16);

@@ -171,6 +171,35 @@ __device__ __forceinline__ void grid_barrier_tree(unsigned* sync, unsigned round
   __syncthreads();
 }
 
+// Barrier number `round` among the `per` workgroups of ONE of up to 16 independent sub-grids of a launch (sub-grid `sg`;
+// per <= 32), on the same barrier object: one arrival counter and one release word per sub-grid (the group slots of the
+// tree above), one level.  For recurrences that only couple a known subset of the workgroups (the bi-GRU: the workgroups of
+// one direction and one batch-tile group) - they neither pay the second level nor wait for the slowest workgroup of the
+// whole grid.  Same timeout handling as the tree.
+__device__ __forceinline__ void subgrid_barrier(unsigned* sync, unsigned round, unsigned sg, unsigned per, bool& dead) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0 && !dead) {
+    unsigned* rel = sync + 64 + 32 * GVD_SYNC_GROUPS + 32 * sg;
+    if (__hip_atomic_fetch_add(sync + 64 + 32 * sg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (round + 1) * per - 1)
+      __hip_atomic_store(rel, round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0, limit = GVD_SPIN_LIMIT;
+    while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round + 1) {
+      if (spins == 0) {
+        const unsigned o = __hip_atomic_load(sync + GVD_SYNC_LIMIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (o) limit = o;
+      }
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > limit) {
+        __hip_atomic_store(sync + GVD_SYNC_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = true;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // Host: can `grid` workgroups of `block` threads of kernel `fn` be resident at the same time on the current device?  (The check
 // a cooperative launch makes; the persistent kernels are launched PLAINLY after it - the cooperative path costs a ~12 us
 // dispatch gap before and after every such kernel, 0.1 ms of a 3 ms batch_size = 4 call - and bound their barrier spins.)

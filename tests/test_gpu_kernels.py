@@ -301,7 +301,7 @@ def test_attention_beam_group_kernel_is_bitwise_the_row_kernel(K, Bs, N, Ft):
 
 
 @pytest.mark.parametrize('barrier', ['counter', 'cg'])
-@pytest.mark.parametrize('B,T', [(3, 10), (2, 480), (40, 37), (70, 12), (257, 5)])
+@pytest.mark.parametrize('B,T', [(3, 10), (2, 480), (40, 37), (70, 12), (150, 6), (200, 9), (257, 5)])
 def test_gru_persistent_kernel(B, T, barrier):
     """Persistent cooperative bi-GRU (2 layers) vs the oracle's explicit time-loop GRU; repeated launches must
     be bitwise repeatable (a cross-workgroup visibility race would show up as run-to-run differences)."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 session M: the one-head-slot GEMM (gemm_n192.hip) without the per-block MFMA guards (every MFMA of the round-4
-# (the two compile-time switches exist only in tools/sessions/r04_m_n192_variants.patch: `git apply` it before re-running this session)
+# (the two compile-time switches existed for this session only; the no-guard + prefetch form became the kernel afterwards)
 # kernel was saveexec + branch + branch back: found in the ISA), and on top of that with two k tiles in flight - variant builds
 # (tools/with_cflags.py): guard = the kernel as measured in sessions C - H, product = no guards, ahead = no guards + prefetch
 set -u

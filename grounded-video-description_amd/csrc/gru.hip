@@ -97,14 +97,15 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
       wreg[ct][kb] = v;
     }
   }
-  // gate-phase role: thread = (row r = tid/8 of the batch tile, units jj = tid%8 + 8 u, u < NU)
+  // gate-phase role: thread = (row r = tid/8 of the batch tile, the NU CONSECUTIVE units jj = NU (tid%8) + u, u < NU): its gi
+  // gates, its own h_{t-1} and its h_t are one NU-wide vector access each (16 bytes at HU = 32)
   const int g_row = tid >> 3, g_jj = tid & 7;
   float bh_r[NU], bh_z[NU], bh_n[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    bh_r[u] = p.b_hh[dir][j0 + g_jj + 8 * u];
-    bh_z[u] = p.b_hh[dir][GRU_HH + j0 + g_jj + 8 * u];
-    bh_n[u] = p.b_hh[dir][2 * GRU_HH + j0 + g_jj + 8 * u];
+    bh_r[u] = p.b_hh[dir][j0 + NU * g_jj + u];
+    bh_z[u] = p.b_hh[dir][GRU_HH + j0 + NU * g_jj + u];
+    bh_n[u] = p.b_hh[dir][2 * GRU_HH + j0 + NU * g_jj + u];
   }
   // staging role: 16 x 16-byte pieces per thread per tile; piece i -> tile row (tid + 256 i) / 128, float4 column % 128
   // (a wave-load covers 1 KiB contiguous of one sample's h_{t-1}: fully coalesced)
@@ -140,12 +141,29 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
     auto load_gate_inputs = [&](int mt, float* r_, float* z_, float* n_, float* h_) {
       const int b = (tile0 + mt) * 32 + g_row;
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        r_[u] = z_[u] = n_[u] = h_[u] = 0.f;
-        if (b < B) {
-          const float* gip = p.gi + (int64_t)b * ld_gi + (int64_t)t * 6 * GRU_HH + dir * 3 * GRU_HH + j0 + g_jj + 8 * u;
-          r_[u] = gip[0]; z_[u] = gip[GRU_HH]; n_[u] = gip[2 * GRU_HH];
-          if (step > 0) h_[u] = ld_agent_f32(out_rs, (unsigned)(((int64_t)b * ld_out + off_tp + j0 + g_jj + 8 * u) * 4));
+      for (int u = 0; u < NU; ++u) r_[u] = z_[u] = n_[u] = h_[u] = 0.f;
+      if (b < B) {
+        typedef float vecu __attribute__((ext_vector_type(NU)));
+        const float* gip = p.gi + (int64_t)b * ld_gi + (int64_t)t * 6 * GRU_HH + dir * 3 * GRU_HH + j0 + NU * g_jj;
+        const unsigned hoff = (unsigned)(((int64_t)b * ld_out + off_tp + j0 + NU * g_jj) * 4);
+        if constexpr (NU == 1) {
+          r_[0] = gip[0]; z_[0] = gip[GRU_HH]; n_[0] = gip[2 * GRU_HH];
+          if (step > 0) h_[0] = ld_agent_f32(out_rs, hoff);
+        } else {
+          const vecu vr = *reinterpret_cast<const vecu*>(gip), vz = *reinterpret_cast<const vecu*>(gip + GRU_HH),
+                     vn = *reinterpret_cast<const vecu*>(gip + 2 * GRU_HH);
+#pragma unroll
+          for (int u = 0; u < NU; ++u) { r_[u] = vr[u]; z_[u] = vz[u]; n_[u] = vn[u]; }
+          if (step > 0) {
+            if constexpr (NU == 4) {
+              const f32x4 vh = ld_agent_x4(out_rs, hoff);
+#pragma unroll
+              for (int u = 0; u < NU; ++u) h_[u] = vh[u];
+            } else {
+              const gvd_f32x2 vh = ld_agent_x2(out_rs, hoff);
+              h_[0] = vh[0]; h_[1] = vh[1];
+            }
+          }
         }
       }
     };
@@ -195,9 +213,10 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
       __syncthreads();
       const int b = (tile0 + mt) * 32 + g_row;
       if (b < B) {
+        float hn[NU];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-          const int jj = g_jj + 8 * u;
+          const int jj = NU * g_jj + u;
           float gr = bh_r[u], gz = bh_z[u], gn = bh_n[u];
           if (step > 0) {
             gr += s_part[0][g_row][jj] + s_part[1][g_row][jj] + s_part[2][g_row][jj] + s_part[3][g_row][jj];
@@ -206,10 +225,22 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const GruParams p) {
             gn += s_part[0][g_row][2 * HU + jj] + s_part[1][g_row][2 * HU + jj] +
                   s_part[2][g_row][2 * HU + jj] + s_part[3][g_row][2 * HU + jj];
           }
+          // (explicit fused multiply-adds: the contraction the compiler picks must not depend on the code shape around it
+          // - the unit forms HU = 8 / 16 / 32 differ in exactly that - or results would depend on the batch size)
           const float r = sigmoid_f(cur_r[u] + gr);
           const float z = sigmoid_f(cur_z[u] + gz);
-          const float n = tanhf(cur_n[u] + r * gn);
-          st_agent_f32(out_rs, (unsigned)(((int64_t)b * ld_out + off_t + j0 + jj) * 4), (1.f - z) * n + z * cur_h[u]);
+          const float n = tanhf(__builtin_fmaf(r, gn, cur_n[u]));
+          hn[u] = __builtin_fmaf(z, cur_h[u], __fmul_rn(1.f - z, n));
+        }
+        const unsigned ooff = (unsigned)(((int64_t)b * ld_out + off_t + j0 + NU * g_jj) * 4);
+        if constexpr (NU == 4) {
+          const f32x4 v = {hn[0], hn[1], hn[2], hn[3]};
+          st_agent_x4(out_rs, ooff, v);
+        } else if constexpr (NU == 2) {
+          const gvd_f32x2 v = {hn[0], hn[1]};
+          st_agent_x2(out_rs, ooff, v);
+        } else {
+          st_agent_f32(out_rs, ooff, hn[0]);
         }
       }
 #pragma unroll

@@ -122,6 +122,14 @@ __device__ __forceinline__ gvd_f32x4 ld_agent_x4(__amdgpu_buffer_rsrc_t r, unsig
 __device__ __forceinline__ float ld_agent_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16));
 }
+typedef float gvd_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gvd_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gvd_f32x2 ld_agent_x2(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(gvd_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 16));
+}
+__device__ __forceinline__ void st_agent_x2(__amdgpu_buffer_rsrc_t r, unsigned byte_off, gvd_f32x2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gvd_u32x2, v), r, byte_off, 0, 16);
+}
 __device__ __forceinline__ void st_agent_x4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, gvd_f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gvd_u32x4, v), r, byte_off, 0, 16);
 }

@@ -325,6 +325,24 @@ def test_gru_persistent_kernel(B, T, barrier):
     np.testing.assert_allclose(outs[0].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=5e-5)
 
 
+def test_gru_result_does_not_depend_on_the_batch_tiling():
+    """The three unit forms of the persistent bi-GRU (8 / 16 / 32 hidden units per workgroup, chosen by the batch size: up to
+    64 rows / up to 128 / above) compute every output with the same k order and the same explicit fused multiply-adds: a
+    sample's hidden sequence is bitwise the same whichever batch it travels in."""
+    opt = gvd_amd.opts.default_opt(vocab_size=10)
+    sd = gvd_amd.synth.init_state_dict(opt, seed=5)
+    gru = torch.nn.GRU(1024, 512, 2, dropout=0.2, bidirectional=True, batch_first=True)
+    gru.load_state_dict({k[len('context_enc.'):]: v for k, v in sd.items() if k.startswith('context_enc.')})
+    gru = gru.cuda().eval()
+    x = torch.randn(230, 9, 1024, generator=_g(77)).cuda()
+    with torch.no_grad():
+        full = ops.gru_bidir_2layer(x, gru)                                    # 8 batch tiles: 32-unit form
+        parts = torch.cat([ops.gru_bidir_2layer(x[a:b].contiguous(), gru)     # 40 rows: 8-unit, 100: 16-unit, 90: 16-unit
+                           for a, b in ((0, 40), (40, 140), (140, 230))])
+    torch.cuda.synchronize()
+    assert torch.equal(full, parts)
+
+
 def test_add_layernorm_unbiased():
     g = _g(11)
     x, y = torch.randn(777, 1024, generator=g), torch.randn(777, 1024, generator=g) * 0.3

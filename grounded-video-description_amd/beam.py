@@ -25,12 +25,26 @@ from . import ops
 from .hip import BeamStepArgs, check, lib, ptr, stream_ptr
 
 
+_STATE = ('h_att', 'c_att', 'h_lang', 'c_lang')
+
+
+def _state(stack):
+    """The four recurrent states as views of ONE [4, rows, H] tensor: forking the beams' states from their parents is then
+    one gather launch per step instead of four."""
+    return dict(zip(_STATE, stack.unbind(0)), stack=stack)
+
+
+def _fork(st, parent):
+    return _state(st['stack'].index_select(1, parent))
+
+
 def _core_rows(P, st, xt, fc_gates, pre, pmask_rows, K, att2_out):
-    """One TopDownCore step (AttModel.py:134-164) for B*K beam rows; st = dict(h_att,c_att,h_lang,c_lang)."""
+    """One TopDownCore step (AttModel.py:134-164) for B*K beam rows; st = _state(...) of (h_att, c_att, h_lang, c_lang)."""
     H = st['h_att'].shape[1]
     A = pre['p_pool'].shape[2]
+    nxt = torch.empty_like(st['stack'])
     h_att, c_att = ops.lstm_cell([xt], [P['att_w_ih'][:, H:]], st['h_att'], P['att_w_hh'], None, None, st['c_att'],
-                                 rowbias=fc_gates)
+                                 rowbias=fc_gates, h_out=nxt[0], c_out=nxt[1])
     q12 = ops.gemm_nt(h_att, P['w_stack'], P['b_stack'])
     region = dict(feats=pre['pool'], p_feats=pre['p_pool'], q=q12[:, A:], w=P['att2_alpha_w'].view(-1),
                   alpha_bias=P['att2_alpha_b'], att_mask=pmask_rows[:, 1:], pnt_mask=pmask_rows[:, 1:],
@@ -38,9 +52,9 @@ def _core_rows(P, st, xt, fc_gates, pre, pmask_rows, K, att2_out):
     temporal = dict(feats=pre['conv'], p_feats=pre['p_conv'], q=q12[:, :A], w=P['att1_alpha_w'].view(-1),
                     alpha_bias=P['att1_alpha_b'], group=K)
     att_sum = ops.attention_step(region, temporal)
-    h_lang, c_lang = ops.lstm_cell([att_sum, h_att], [P['lang_w_ih'][:, :H], P['lang_w_ih'][:, H:]], st['h_lang'],
-                                   P['lang_w_hh'], P['lang_b_ih'], P['lang_b_hh'], st['c_lang'])
-    return dict(h_att=h_att, c_att=c_att, h_lang=h_lang, c_lang=c_lang)
+    ops.lstm_cell([att_sum, h_att], [P['lang_w_ih'][:, :H], P['lang_w_ih'][:, H:]], st['h_lang'],
+                  P['lang_w_hh'], P['lang_b_ih'], P['lang_b_hh'], st['c_lang'], h_out=nxt[2], c_out=nxt[3])
+    return _state(nxt)
 
 
 def beam_decode(model, pre, P, K, fused_step=True):
@@ -57,8 +71,7 @@ def beam_decode(model, pre, P, K, fused_step=True):
     fc_gates = (ops.gemm_nt(fc, P['att_w_ih'][:, :H], P['att_b_ih']) + P['att_b_hh']).repeat_interleave(K, 0)
     pm_rows = pre['pnt_mask'].repeat_interleave(K, 0).contiguous()
     att2_w = torch.empty(rows, R, device=dev)
-    z = lambda: torch.zeros(rows, H, device=dev)
-    st = dict(h_att=z(), c_att=z(), h_lang=z(), c_lang=z())
+    st = _state(torch.zeros(4, rows, H, device=dev))
     it = torch.zeros(rows, dtype=torch.int64, device=dev)
     st = _core_rows(P, st, ops.embed_relu(it, P['embed']), fc_gates, pre, pm_rows, K, att2_w)   # BOS step
     att2_first = att2_w.view(B, K, R)[:, 0].max(dim=1)[1]                                         # model.py:733
@@ -92,7 +105,7 @@ def beam_decode(model, pre, P, K, fused_step=True):
         _, _, ys, ix = ops.logsoftmax_rows(logits, topk=K)
         a.ys, a.ix, a.att2_ind, a.t = ptr(ys), ptr(ix), ptr(att2_ind), t
         check(lib().gvd_beam_step(C.byref(a), stream_ptr()), 'gvd_beam_step')
-        st = {k: v.index_select(0, parent) for k, v in st.items()}
+        st = _fork(st, parent)
         st = _core_rows(P, st, ops.embed_relu(word_rows, P['embed']), fc_gates, pre, pm_rows, K, att2_w)
         att2_ind = att2_w.view(B, K, R).max(dim=2)[1].contiguous()   # CaptionModelBU.py:182
 
@@ -121,7 +134,7 @@ def beam_decode(model, pre, P, K, fused_step=True):
             beam_att[:t] = torch.gather(beam_att[:t], 2, gi)
             beam_att[t] = torch.gather(att2_ind, 1, q_sel)
         parent = (base + q_sel).view(-1)
-        st = {k: v.index_select(0, parent) for k, v in st.items()}
+        st = _fork(st, parent)
         beam_seq[t] = word
         beam_lps[t] = r
         sums = new_p

@@ -10,7 +10,7 @@ with the CPU reference is distributional, not bitwise (tests/test_gpu_e2e.py::te
 import torch
 
 from . import ops
-from .beam import _core_rows
+from .beam import _core_rows, _state
 
 
 def multinomial_decode(model, pre, P, temperature=1.0):
@@ -25,8 +25,7 @@ def multinomial_decode(model, pre, P, temperature=1.0):
     P['b_stack'] = torch.cat([P['att1_h2att_b'], P['att2_h2att_b']], 0)
     fc_gates = ops.gemm_nt(fc, P['att_w_ih'][:, :H], P['att_b_ih']) + P['att_b_hh']
     pm = pre['pnt_mask']
-    z = lambda: torch.zeros(B, H, device=dev)
-    st = dict(h_att=z(), c_att=z(), h_lang=z(), c_lang=z())
+    st = _state(torch.zeros(4, B, H, device=dev))
     seq = torch.empty(B, L, dtype=torch.int64, device=dev)
     lps = torch.empty(B, L, device=dev)
     att2 = torch.empty(B, L, R, device=dev)

@@ -741,10 +741,13 @@ def gru_bwd_step(dout, gi, gh, out, carry_mm, carry_z, d_gi, d_gh, B, T, Hh, t_f
                                  B, T, Hh, t_fw, t_bw, 1 if first else 0, stream_ptr()), 'gvd_gru_bwd_step')
 
 
-def gru_bidir_2layer(x, gru, barrier=None, flags=None):
+def gru_bidir_2layer(x, gru, barrier=None, flags=None, packed=None):
     """Inference forward of the frame encoder nn.GRU(1024, 512, 2, bidirectional, batch_first) (model.py:399):
     per layer one MFMA GEMM for both directions' input projections + one persistent cooperative kernel for the
-    recurrence (gvd_gru_bidir_layer).  x [B,T,1024] -> [B,T,1024]."""
+    recurrence (gvd_gru_bidir_layer).  x [B,T,1024] -> [B,T,1024].
+    packed: the caller's cache of derived parameter copies, `packed(key, params, build)` (TopDownModel._packed): the two
+    directions' stacked input-projection weights are then built once per parameter version instead of per call (two 6 MB
+    concatenations per layer: 1 % of a batch_size = 4 call)."""
     require_cuda_f32(x)
     B, T, _ = x.shape
     Hh = gru.hidden_size
@@ -753,8 +756,12 @@ def gru_bidir_2layer(x, gru, barrier=None, flags=None):
     for l in range(gru.num_layers):
         g = lambda n: getattr(gru, '%s_l%d' % (n, l)).detach()
         gr = lambda n: getattr(gru, '%s_l%d_reverse' % (n, l)).detach()
-        w_ih = torch.cat([g('weight_ih'), gr('weight_ih')], 0)
-        b_ih = torch.cat([g('bias_ih'), gr('bias_ih')], 0)
+        stack = lambda n: (lambda: torch.cat([g(n), gr(n)], 0))
+        if packed is None:
+            w_ih, b_ih = stack('weight_ih')(), stack('bias_ih')()
+        else:
+            w_ih = packed(('gru_w_ih', l), (g('weight_ih'), gr('weight_ih')), stack('weight_ih'))
+            b_ih = packed(('gru_b_ih', l), (g('bias_ih'), gr('bias_ih')), stack('bias_ih'))
         gi = gemm_nt(inp.view(B * T, -1), w_ih, b_ih)                      # [B*T, 6*Hh]
         inp = gru_layer(gi, g('weight_hh').contiguous(), g('bias_hh').contiguous(), gr('weight_hh').contiguous(),
                         gr('bias_hh').contiguous(), B, T, Hh, flags=flags, barrier=barrier)

@@ -64,6 +64,9 @@ def parse():
     ap.add_argument('--no-sections', action='store_true',
                     help='default line only: skip the short configs[2] (train B=64), configs[4] (beam=5 x 20 frames, B=64) and '
                          'Ft=480 (reference-default frame count, B=256) sections the default run appends to its JSON line')
+    ap.add_argument('--no-dp-section', action='store_true',
+                    help='skip the collective-safe configs[3] section (32 segments/GPU optimisation steps + all-reduce timing) '
+                         'every sample-mode line carries')
     ap.add_argument('--overlap', action='store_true',
                     help='pipeline the K steps on two HIP streams (preamble of step i+1 || token loop of step i). Off by '
                          'default: co-scheduling stretches the attention kernel, so its live roofline figure would not '
@@ -184,17 +187,48 @@ def cpu_baseline_train(opt, sd, seconds, full=True):
             'reference_in_build_container': _reference_timing() if full else None}
 
 
-def _roofline(attn_ms, attn_n, bytes_per_launch, traffic, kernel):
+def _attn_fetched_bytes(att_mask_rows, Ft, A, H, group=1):
+    """Bytes one attention launch really FETCHES, exactly, from the mask: the kernel skips the projection row and the feature
+    row of every region the attention mask removes (csrc/attention.hip: weight exactly 0), per 50-row chunk (a chunk without
+    any live row keeps its feature rows: uniform weights).  att_mask_rows: u8 [B, R] (1 = masked), B = samples (for the
+    beam-grouped kernel a row is skipped when masked for every beam of the sample: same mask for all beams here)."""
+    B, R = att_mask_rows.shape
+    chunk = 50
+    while chunk > 20 and B * ((R + chunk - 1) // chunk) < 512:        # attention.hip pick_chunk
+        chunk = (chunk + 1) // 2
+    chunk = max(1, min(chunk, 64, R))
+    live = (att_mask_rows == 0)
+    pad = (-R) % chunk
+    if pad:
+        live = torch.cat([live, torch.zeros(B, pad, dtype=torch.bool, device=live.device)], 1)
+    per_chunk = live.view(B, -1, chunk).sum(-1)                        # live rows per (sample, chunk)
+    rows_in_chunk = torch.full_like(per_chunk, chunk)
+    if pad:
+        rows_in_chunk[:, -1] = chunk - pad
+    p_rows = int(per_chunk.sum())
+    f_rows = int(torch.where(per_chunk > 0, per_chunk, rows_in_chunk).sum())
+    return 4 * (p_rows * A + f_rows * H) + 4 * B * Ft * (A + H)
+
+
+def _roofline(attn_ms, attn_n, bytes_per_launch, traffic, kernel, fetched_bytes=None):
+    """`frac` / `achieved`: the bytes the launch FETCHES (live rows only, exact from the mask: _attn_fetched_bytes) over the
+    HIP-event time; `frac_algorithmic` / `achieved_algorithmic`: SURVEY 8(d)'s all-rows figure B (R + Ft) (A + H) 4 over the
+    same time (it counts rows the kernel never reads); `traffic` / `frac_physical`: the PMC bytes of separate counter passes."""
     avg_s = (attn_ms / max(attn_n, 1)) * 1e-3
-    achieved = bytes_per_launch / avg_s / 1e9 if attn_n else None
+    alg = bytes_per_launch / avg_s / 1e9 if attn_n else None
+    fb = bytes_per_launch if fetched_bytes is None else fetched_bytes
+    achieved = fb / avg_s / 1e9 if attn_n else None
     return {'bound': 'hbm', 'kernel': kernel,
             'achieved': None if achieved is None else round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-            'traffic': traffic[0], 'traffic_source': traffic[1], 'bytes_per_launch': bytes_per_launch,
-            # the kernel does not fetch rows the attention mask removes (weight exactly 0), so the HBM traffic is below the
-            # algorithmic bytes (which count every row): the physical HBM rate is traffic / duration
+            'bytes_per_launch': fb,
+            'bytes_basis': ('fetched rows only (rows the attention mask removes are never read), exact from the mask'
+                            if fetched_bytes is not None else 'all rows (SURVEY 8d)'),
+            'achieved_algorithmic': None if alg is None else round(alg, 1),
+            'frac_algorithmic': None if alg is None else round(alg / HBM_PEAK_GBS, 4),
+            'algorithmic_bytes_all_rows': bytes_per_launch,
+            'traffic': traffic[0], 'traffic_source': traffic[1],
             'hbm_rate_from_traffic_GBs': None if (not attn_n or not traffic[0]) else round(traffic[0] / avg_s / 1e9, 1),
-            # `frac` follows SURVEY 8(d) (algorithmic bytes); this is the fraction of the HBM peak the kernel MOVES
             'frac_physical': None if (not attn_n or not traffic[0]) else round(traffic[0] / avg_s / 1e9 / HBM_PEAK_GBS, 4),
             'avg_launch_us': round(avg_s * 1e6, 2), 'launches_timed': attn_n}
 
@@ -323,7 +357,9 @@ def section_train_b64(dev, n_steps=4, cpu_seconds=0.0):
             got = torch.cat([l.reshape(1) for l in model(*a, 'MLE')]).cpu().numpy()
         want = np.load(gpath)['losses']
         out['parity'] = {'golden': 'tests/golden/mle_b64_v5000_ft10_trained.npz (reference CPU losses lm/att2/grd/cls)',
-                         'max_abs_loss_diff': float(np.abs(got - want).max()),
+                         'losses_got': [float(np.float32(x)) for x in got], 'losses_want': [float(np.float32(x)) for x in want],
+                         'losses_got_hex': [float(x).hex() for x in got], 'losses_want_hex': [float(x).hex() for x in want],
+                         'max_abs_loss_diff': float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max()),
                          'within_1e-4': bool(np.abs(got - want).max() <= 1e-4)}
     model.train()
     tr = train.Trainer(model, opt)
@@ -400,29 +436,23 @@ def _train_compacted(n_steps):
         return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
 
 
-def section_beam5_t20_b64(dev, n_steps=3, cpu_seconds=0.0, cpu_threads=None):
-    """BASELINE configs[4] inside the default line: beam=5 over 20 frames x 100 regions, 64 segments; `parity` = ids and
-    attended regions of the committed reference case beam5_b8_v5000_ft10_t20 (the reference's own beam_search under the
-    harness shim) decoded by the same model."""
+def section_beam5_t20_b64(dev, n_steps=10, cpu_seconds=0.0, cpu_threads=None):
+    """BASELINE configs[4] inside the default line: beam=5 over 20 frames x 100 regions, 64 segments.  The timed batch IS
+    the committed reference case beam5_b64_v5000_ft10_t20 (weights + inputs from seed 22, oracle/cases.py; the reference's
+    own beam_search under the harness shim): `parity` compares the ids / attended regions the TIMED region produced - the
+    nontemporal attn_partial_group_kernel<5> instantiation, 320 beam rows - with the reference's output."""
     import numpy as np
     from gvd_amd import att_model, hip, ops, opts, synth
     opt = opts.default_opt(vocab_size=5000, t_attn_size=10, num_sampled_frm=20)
-    sd = synth.init_state_dict(opt, seed=9, profile='trained_like')
+    sd = synth.init_state_dict(opt, seed=22, profile='trained_like')
     model = att_model.TopDownModel(opt)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     keys = ('segs_feat', 'ppls', 'num', 'ppls_feat', 'sample_idx', 'pnt_mask')
     out = {'batch': 64, 'beam': 5, 'frames': 20}
-    gpath = os.path.join(GOLDEN_DIR, 'beam5_b8_v5000_ft10_t20.npz')
+    gpath = os.path.join(GOLDEN_DIR, 'beam5_b64_v5000_ft10_t20.npz')
     with torch.no_grad():
-        if os.path.exists(gpath):
-            g = np.load(gpath)
-            small = synth.make_inputs(opt, 8, seed=9, train=False)
-            seq, lps, att2, _ = model._sample(*[small[k].to(dev) for k in keys], {'beam_size': 5})
-            out['parity'] = {'golden': 'tests/golden/beam5_b8_v5000_ft10_t20.npz (reference beam_search under the shim)',
-                             'token_ids_equal': bool((seq.cpu().numpy() == g['seq']).all()),
-                             'attended_regions_equal': bool((att2.cpu().numpy() == g['att2']).all())}
-        inp = synth.make_inputs(opt, 64, seed=100, train=False)
+        inp = synth.make_inputs(opt, 64, seed=22, train=False)
         d = [inp[k].to(dev) for k in keys]
         for _ in range(2):
             model._sample(*d, {'beam_size': 5})
@@ -431,16 +461,24 @@ def section_beam5_t20_b64(dev, n_steps=3, cpu_seconds=0.0, cpu_threads=None):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_steps):
-            model._sample(*d, {'beam_size': 5})
+            seq, lps, att2, _ = model._sample(*d, {'beam_size': 5})
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n_steps
         ops.set_kernel_timer(None)
     model.check_kernel_status()
+    if os.path.exists(gpath):
+        g = np.load(gpath)
+        out['parity'] = {'golden': 'tests/golden/beam5_b64_v5000_ft10_t20.npz (reference beam_search under the shim, the TIMED batch)',
+                         'compared': 'output of the last timed step',
+                         'token_ids_equal': bool((seq.cpu().numpy() == g['seq']).all()),
+                         'attended_regions_equal': bool((att2.cpu().numpy() == g['att2']).all()),
+                         'max_abs_logprob_diff': float(np.abs(lps.cpu().numpy() - g['seqLogprobs']).max())}
     ms, n = timer.read()
     R = opt.num_sampled_frm * opt.num_prop_per_frm
     out.update(ms_per_step=round(1e3 * dt, 3), captions_per_s=round(64 / dt, 1), steps_timed=n_steps)
     out['roofline'] = _roofline(ms, n, 64 * (R + 10) * (opt.att_hid_size + opt.rnn_size) * 4, _pmc_traffic('beam', 64, 10, R),
-                                'attn_partial_group_kernel<5> (one feature stream per sample for its 5 beams)')
+                                'attn_partial_group_kernel<5, nontemporal> (one feature stream per sample for its 5 beams)',
+                                fetched_bytes=_attn_fetched_bytes(inp['pnt_mask'][:, 1:], 10, opt.att_hid_size, opt.rnn_size))
     del model
     torch.cuda.empty_cache()
     if cpu_seconds > 0:
@@ -569,6 +607,62 @@ def section_files_to_captions(dev, n_seg=256, B=64):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def section_dp_train(args, dev, rank, world, n_steps=6, B=32):
+    """BASELINE configs[3] (batch-DP training, 256 segments as 8 x 32; reference main.py:654-658 nn.DataParallel, loss
+    semantics main.py:239-255) as a COLLECTIVE-SAFE section of every sample-mode line: every rank runs it (the N = 1 line
+    carries the one-GPU point of the same curve, without a collective).  32 segments per GPU, train mode, `n_steps` timed
+    optimisation steps between barriers -> whole-job segments/s (MAX over ranks), every rank's seconds, the bucket launch
+    timeline of one traced step (when each bucket's all-reduce was issued / when the compute stream got it back, against the
+    end of backward), the EXPOSED milliseconds of the gradient exchange (not hidden behind backward) and the collectives
+    alone: ring bus bandwidth 2 (N - 1) / N x bytes / t from stream events, to hold against xGMI's ~153 GB/s per link."""
+    from gvd_amd import att_model, dist as gdist, opts, synth, train
+    use_dist = dist.is_initialized()
+    gloo = args.dist_backend == 'gloo'
+    opt = opts.default_opt(vocab_size=5000, t_attn_size=10)
+    sd = synth.init_state_dict(opt, seed=13, profile='trained_like')
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    gdist.broadcast_parameters(model)
+    tr = train.Trainer(model, opt)
+    a = synth.as_args(synth.trim_to_batch(synth.make_inputs(opt, B, seed=300 + rank, train=True)), dev)
+    for _ in range(2):                  # warm-up: allocator growth, weight packs, bucket discovery (step 0) + first hooked step
+        tr.step(a)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        losses = tr.step(a)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed, per_rank = _max_and_per_rank(elapsed, dev, use_dist, gloo)
+    timeline = exposed = coll = None
+    if tr.reducer.active:
+        tr.reducer.trace = True
+        tr.step(a)                      # one traced step on every rank, outside the timed region
+        torch.cuda.synchronize()
+        timeline, exposed = tr.reducer.launch_timeline(), tr.reducer.exposed_ms()
+        tr.reducer.trace = False
+        coll = tr.reducer.measure_allreduce(reps=5)          # the step's collectives alone (every rank)
+    out = {'segments_per_gpu': B, 'global_batch': B * world, 'n_gpus': world, 'steps_timed': n_steps,
+           'segments_per_s': round(world * B * n_steps / elapsed, 1), 'ms_per_step': round(1e3 * elapsed / n_steps, 3),
+           'per_rank_seconds': per_rank, 'losses_last_rank0': [round(float(x), 5) for x in losses],
+           'parallelism': ('dp%d: one process per GPU, bucketed gradient all-reduce (%s) launched from autograd hooks in '
+                           'gradient-ready order, mean over replicas of per-replica masked means (main.py:239-255)'
+                           % (world, 'gloo: code-path run, not a measurement' if gloo else 'RCCL over xGMI'))
+                          if world > 1 else 'one GPU: no collective (the N = 1 point of the configs[3] curve)',
+           'dp_bucket_launches': timeline, 'allreduce_exposed_ms': exposed, 'allreduce_alone': coll,
+           'allreduce_hidden_fraction': (None if not (coll and exposed is not None and coll['ms_per_sweep'] > 0) else
+                                         round(max(0.0, 1.0 - exposed / coll['ms_per_sweep']), 3))}
+    del tr, model, a
+    torch.cuda.empty_cache()
+    return out
+
+
 def bench_train(args, opt, sd, model, B, rank, world, dev):
     """BASELINE configs[2]/[3]: one optimisation step = 'MLE' forward (LM + attention + grounding + cls losses),
     hand-scheduled BPTT, RCCL gradient all-reduce (N>1), clip 0.1, Adam.  Train mode (dropout, BN batch stats)."""
@@ -628,7 +722,8 @@ def bench_train(args, opt, sd, model, B, rank, world, dev):
             'roofline': roof,
             # the forward attention streaming kernel of the teacher-forced loop (same kernel, same bytes as in decode)
             'roofline_attention': _roofline(attn_ms, attn_n, B * (R + Ft) * (A + H) * 4, (None, None),
-                                            'attn_partial_kernel (forward region+temporal attention of the teacher-forced loop)'),
+                                            'attn_partial_kernel (forward region+temporal attention of the teacher-forced loop)',
+                                            fetched_bytes=_attn_fetched_bytes(inp['pnt_mask'][:, 1:], Ft, A, H)),
             'cpu_baseline': _cpu_baseline_or_pointer(args, world, lambda: cpu_baseline_train(opt, sd, args.cpu_seconds))}
         print(json.dumps(out))
     if use_dist:
@@ -774,7 +869,8 @@ def main():
             'roofline': _roofline(attn_ms, attn_n, bytes_per_launch, _pmc_traffic('greedy' if args.beam == 1 else 'beam', B, Ft, R),
                                   'attn_partial_kernel (region+temporal additive attention)' if args.beam == 1 else
                                   'attn_partial_group_kernel<%d> (one feature stream per sample for its %d beams)'
-                                  % (args.beam, args.beam)),
+                                  % (args.beam, args.beam),
+                                  fetched_bytes=_attn_fetched_bytes(inp['pnt_mask'][:, 1:], Ft, A, H)),
         }
         out['config']['host_binding'] = binding
         if not args.h2d and not args.overlap:
@@ -837,6 +933,20 @@ def main():
         else:
             out['cpu_baseline'] = _cpu_baseline_or_pointer(args, world,
                                                            lambda: cpu_baseline(opt, sd, args.cpu_seconds, beam=args.beam))
+    # configs[3] section: COLLECTIVE - every rank runs it (rank 0 after its single-rank extra passes above; the others wait in
+    # the section's first collective).  It carries the RCCL evidence of an N > 1 run: all-reduce bus bandwidth, exposed ms.
+    dp = None
+    if args.beam == 1 and not args.h2d and not args.overlap and not args.no_dp_section:
+        dinp = model = None             # (rank 0 of the default workload dropped them before its sections already)
+        torch.cuda.empty_cache()
+        try:
+            dp = section_dp_train(args, dev, rank, world)
+        except Exception as e:          # noqa: BLE001 - reported, not fatal (but never swallowed on a subset of ranks: a
+            if use_dist and world > 1:  # collective section that fails on one rank must take the job down, not hang it)
+                raise
+            dp = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+    if rank == 0:
+        out['config']['configs3_dp_train'] = dp
         print(json.dumps(out))
     barrier()                    # (rank 0's extra measurement passes are over before any rank tears the group down)
     if use_dist:

@@ -130,7 +130,7 @@ class GradAllReducer:
         self._next = 0             # buckets [0, _next) have been launched
         self._handles = []
         if self.trace and self.all_params and self.all_params[0].is_cuda:
-            self._tev = {'t0': self._event(), 'launch': [], 'finish': None}
+            self._tev = {'t0': self._event(), 'launch': [], 'finish': None, 'reduced': [], 'drained': None}
 
     @staticmethod
     def _event():
@@ -146,8 +146,53 @@ class GradAllReducer:
         if not t or t['finish'] is None:
             return []
         end = t['t0'].elapsed_time(t['finish'])
+        red = dict(t.get('reduced') or [])
         return [{'bucket': bi, 'mbytes': round(self.buckets[bi]['numel'] * 4 / 1e6, 1) if bi < len(self.buckets) else None,
-                 'launched_ms': round(t['t0'].elapsed_time(e), 3), 'backward_end_ms': round(end, 3)} for bi, e in t['launch']]
+                 'launched_ms': round(t['t0'].elapsed_time(e), 3), 'backward_end_ms': round(end, 3),
+                 # when the compute stream got past its wait for this bucket's collective (>= backward_end_ms by construction:
+                 # the waits are issued after backward) - what is above backward_end_ms was NOT hidden behind backward
+                 'reduced_ms': round(t['t0'].elapsed_time(red[bi]), 3) if bi in red else None} for bi, e in t['launch']]
+
+    def exposed_ms(self):
+        """After a traced step and a device sync: milliseconds between the end of backward and the moment the compute stream
+        holds every averaged gradient (waits for the collectives still in flight + the divide / write-back passes) = the part
+        of the gradient exchange that did NOT overlap with backward."""
+        t = self._tev_done if hasattr(self, '_tev_done') else None
+        if not t or t['finish'] is None or t.get('drained') is None:
+            return None
+        return round(t['finish'].elapsed_time(t['drained']), 3)
+
+    def measure_allreduce(self, reps=5):
+        """The step's collectives ALONE (every bucket's all-reduce back to back on the flat buffers, nothing else on the
+        device): seconds per sweep from stream events -> algorithm bandwidth bytes / t and the ring 'bus' bandwidth
+        2 (N - 1) / N x bytes / t (the per-link figure to hold against xGMI's ~153 GB/s per link).  COLLECTIVE: every rank
+        calls it, between steps.  Returns None when the reducer is inactive."""
+        if not self.active or not self.buckets or not self.buckets[0]['flat'].is_cuda:
+            return None
+        for _, h in self._handles:
+            h.wait()
+        self._handles = []
+        nbytes = sum(b['numel'] for b in self.buckets) * 4
+
+        def sweep():
+            hs = [dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
+            for h in hs:
+                h.wait()
+        sweep()                                   # warm-up (communicator / channel setup)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            sweep()
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3 / reps
+        for b in self.buckets:                    # (the sums of sums are garbage: the next step's launches overwrite them)
+            b['flat'].zero_()
+        n = self.world
+        return {'bytes': nbytes, 'buckets': len(self.buckets), 'ms_per_sweep': round(sec * 1e3, 3),
+                'algbw_GBs': round(nbytes / sec / 1e9, 2), 'busbw_GBs': round(2 * (n - 1) / n * nbytes / sec / 1e9, 2),
+                'sweeps_timed': reps, 'backend': dist.get_backend(self.group)}
 
     def _launch(self, bi):
         b = self.buckets[bi]
@@ -204,8 +249,11 @@ class GradAllReducer:
         self._build_buckets()
 
     def _drain(self):
+        tev = self._tev
         for bi, h in self._handles:
             h.wait()
+            if tev is not None:
+                tev['reduced'].append((bi, self._event()))
             b = self.buckets[bi]
             b['flat'].div_(self.world)
             for p, o in zip(b['params'], b['offsets']):
@@ -214,6 +262,8 @@ class GradAllReducer:
                     p.grad = g.clone()
                 else:
                     p.grad.copy_(g)
+        if tev is not None and self._handles:
+            tev['drained'] = self._event()
         self._handles = []
 
     def finish(self, status=None, defer=False):

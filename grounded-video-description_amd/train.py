@@ -69,7 +69,7 @@ class Trainer:
         """Pre-clip total gradient norm of the last step (main.py:265).  Kept on the device; read on demand."""
         return None if self._grad_norm is None else float(self._grad_norm)
 
-    def step(self, args):
+    def step(self, args, _retried=False):
         """args: the 11 positional tensors of AttModel.forward.  Returns the 4 detached losses [4].
 
         ONE device->host read per step: the kernel-status counts of the persistent kernels (the bi-GRU runs as one in
@@ -95,8 +95,8 @@ class Trainer:
             bad, contract = word[1], word[2]
         else:
             bad, contract = (0, 0) if counts is None else counts.tolist()       # the step's one host read
-        if self._recompute(bad, contract):
-            return self.step(args)
+        if self._recompute(bad, contract, _retried):
+            return self.step(args, _retried=True)
         if bad or contract:
             self.model.raise_for_status(bad, contract)
         if own:
@@ -108,14 +108,21 @@ class Trainer:
             self.optimizer.step()
         return torch.cat([l.detach() for l in losses])
 
-    def _recompute(self, bad, contract):
-        """The two conditions of a step a reference user never sees are COMPUTED, not raised (the status word is the same
-        on every rank, so every rank takes the same branch): a grid-barrier timeout of the persistent bi-GRU kernel (shared
-        GPU) switches the persistent kernels off for the process, masked proposals that are not zero rows switch the
-        compacted training layout off for this model; either way the caller runs the step again (forward + backward:
-        fresh dropout draws - the invalid attempt updated nothing)."""
+    def _recompute(self, bad, contract, retried=False):
+        """The two conditions of a step a reference user never sees are COMPUTED, not raised: a grid-barrier timeout of the
+        persistent bi-GRU kernel (shared GPU) switches the persistent kernels off for the process, masked proposals that
+        are not zero rows switch the compacted training layout off for this model; either way the caller runs the step
+        again (forward + backward: fresh dropout draws - the invalid attempt updated nothing).
+
+        The decision uses ONLY rank-identical information - the MAX-reduced status word and whether THIS step was already
+        retried - never process-local state such as ops.persistent_kernels_enabled(): a rank that had switched its
+        persistent kernels off earlier (say a rank-0-only validation pass that timed out) would otherwise raise while its
+        peers retry and block in the next all-reduce.  disable_persistent_kernels is idempotent; a step that is still
+        invalid after its one retry raises on every rank."""
+        if retried or not (bad or contract):
+            return False
         again = False
-        if bad and ops.persistent_kernels_enabled():
+        if bad:
             ops.disable_persistent_kernels(bad)
             again = True
         if contract and self._drop_train_compaction():

@@ -33,6 +33,10 @@ CASES = {
                                          end_gain=3.0, end_bias=-1.5),
     'beam3_b4_v1000_ft480_t10_end': dict(mode='beam', B=4, V=1000, Ft=480, T=10, K=3, seed=11, profile='trained_like',
                                          end_gain=3.0, end_bias=-1.5),
+    # BASELINE configs[4] at the batch bench.py TIMES (64 segments x beam 5 = 320 rows, 790 MB of features per attention
+    # launch: the nontemporal instantiation of the grouped attention kernel, the 1000-row top-K merge): bench.py's beam
+    # section decodes exactly this case in its timed region and compares that run with this reference output
+    'beam5_b64_v5000_ft10_t20': dict(mode='beam', B=64, V=5000, Ft=10, T=20, K=5, seed=22, profile='trained_like'),
     # one optimisation step of main.train (main.py:234-266 + the optimizer of 660-677): loss assembly, clip 0.1, Adam
     # with the two learning-rate groups -> per-parameter first moments and update norms
     'step_b4_v1000_ft10_trained': dict(mode='step', B=4, V=1000, Ft=10, seed=12, profile='trained_like'),

@@ -269,7 +269,10 @@ def test_masked_lsm_loss():
     assert abs(float(out) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
 
 
-@pytest.mark.parametrize('K,Bs,N,Ft', [(5, 3, 203, 10), (3, 2, 2000, 37), (2, 7, 100, 1), (4, 1, 64, 480)])
+# (5, 33, 1000, 10) and (5, 17, 2000, 10): more than 192 MiB of features per launch -> the NONTEMPORAL instantiation
+# attn_partial_group_kernel<5, true> (attention.hip: `nt`), the one bench.py's beam section times at 64 segments x 2000 regions
+@pytest.mark.parametrize('K,Bs,N,Ft', [(5, 3, 203, 10), (3, 2, 2000, 37), (2, 7, 100, 1), (4, 1, 64, 480),
+                                       (5, 33, 1000, 10), (5, 17, 2000, 10), (3, 34, 1000, 10)])
 def test_attention_beam_group_kernel_is_bitwise_the_row_kernel(K, Bs, N, Ft):
     """Beam search: the K beam rows of a sample share its features.  The grouped kernel (one workgroup per chunk and
     SAMPLE, features read once for K queries) must give bit-for-bit what the per-row kernel gives on the expanded rows."""

@@ -85,18 +85,37 @@ def test_contract_violation_without_compaction_raises_before_the_optimiser(monke
 
 def test_barrier_timeout_switches_the_persistent_kernels_off_and_reruns_the_step(monkeypatch):
     monkeypatch.delenv('GVD_TRAIN_COMPACT', raising=False)
-    m = _Fake([(2, 0), (0, 0), (1, 0)])
+    m = _Fake([(2, 0), (0, 0), (1, 0), (1, 0)])
     tr = train.Trainer(m, _opt())
     before = m.w.detach().clone()
     with pytest.warns(RuntimeWarning, match='grid-barrier timeout'):
         tr.step(())
     assert m.calls == 2 and not ops.persistent_kernels_enabled() and ops._persistent['timeouts'] == 2
     assert not torch.equal(m.w.detach(), before)                  # the retried step reached the optimiser
-    # a timeout with the persistent kernels already off is a real kernel error: raises, no retry, no update
+    # a later step whose ONE retry (decided from the status word alone - the same on every rank - not from this process's
+    # switch, which is already off here) is invalid too is a real kernel error: raises, no update
     after = m.w.detach().clone()
     with pytest.raises(GvdHipError):
         tr.step(())
-    assert m.calls == 3 and torch.equal(m.w.detach(), after)
+    assert m.calls == 4 and torch.equal(m.w.detach(), after)
+
+
+def test_retry_decision_does_not_depend_on_the_process_local_switch(monkeypatch):
+    """Data-parallel hang of ADVICE r4: rank A switched its persistent kernels off earlier (a rank-local validation pass
+    timed out), rank B did not; a later training step times out on B -> the MAX-reduced word says bad on BOTH.  Both must
+    take the same branch (retry), whatever their local switch says."""
+    monkeypatch.delenv('GVD_TRAIN_COMPACT', raising=False)
+    calls = []
+    for switch_on in (True, False):                  # rank B, rank A
+        ops._persistent.update(on=switch_on, timeouts=0)
+        m = _Fake([(1, 0), (0, 0)])
+        tr = train.Trainer(m, _opt())
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            tr.step(())
+        calls.append(m.calls)
+    assert calls == [2, 2]
 
 
 def test_timeout_and_contract_violation_in_one_step_take_one_retry(monkeypatch):

@@ -337,7 +337,13 @@ class TopDownModel(nn.Module):
         return ops.linear(xp, w, lin.bias, act, p_drop)
 
     def _drop(self, x, p=None):
-        return F.dropout(x, self.drop_prob_lm if p is None else p, self.training)
+        """F.dropout at the reference's stand-alone dropout sites (token / visual-word embeddings model.py:79-82,428,470;
+        h_lang AttModel.py:161; seg_info model.py:308): the Philox row kernel forward and backward (ops.dropout) - the ATen op only
+        for tensors it does not take (CPU tensors of the control-flow tests, element counts that are not a multiple of 4)."""
+        p = self.drop_prob_lm if p is None else p
+        if x.is_cuda and x.dtype == torch.float32 and x.numel() % 4 == 0 and x.numel() > 0:
+            return ops.dropout(x, p, self.training)
+        return F.dropout(x, p, self.training)
 
     def _packed(self, key, params, build):
         """Derived (re-laid-out) copies of parameters for the fused inference kernels, rebuilt whenever a source
@@ -635,7 +641,17 @@ class TopDownModel(nn.Module):
             c = torch.cat([self._lin(segs_feat[:, :, :2048], self.att_embed[0][0], act=1, p_drop=self._fused_drop_p()),
                            self._lin(segs_feat[:, :, 2048:], self.att_embed[1][0], act=1, p_drop=self._fused_drop_p())],
                           dim=2)
-            c = self.att_embed_aux(c.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+            bn = self.att_embed_aux[0]
+            if self.training and bn.momentum is not None and bn.affine and c.is_cuda and c.shape[-1] % 4 == 0:
+                # train mode: batch statistics over the B * Ft rows of the [B, Ft, C] layout as it is - column-statistic kernels
+                # forward and backward (ops.bn_relu_train), no [B, C, Ft] permute copies around the library BatchNorm
+                c = ops.bn_relu_train(c.view(-1, c.shape[-1]), bn).view(c.shape)
+            elif not self.training:
+                # eval-mode arithmetic under autograd (the gradient goldens): a per-channel affine of the last axis + ReLU
+                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                c = torch.relu(c * scale + (bn.bias - bn.running_mean * scale))
+            else:
+                c = self.att_embed_aux(c.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
         if not torch.is_grad_enabled():
             # inference: persistent cooperative HIP GRU (one launch per layer instead of ~6 per step/direction)
             c = ops.gru_bidir_2layer(c, self.context_enc, flags=self._flags(), packed=self._packed)

@@ -11,16 +11,37 @@ queries, attention scores/contexts).  Backward walks the steps in reverse:
 Reference semantics: autograd through AttModel.py:134-164 x Lc (model.py:421-453).
 """
 import torch
+import torch.nn.functional as F
 
 from . import decoder_fn
 
 
 def _tn(dY, X):
-    """dY^T X (a weight gradient over the stacked [Lc*B, .] activations): the K-strided MFMA kernel when the shape is one
-    it takes, the library product otherwise."""
+    """dY^T X (a weight gradient over the stacked [Lc*B, .] activations) on the K-strided MFMA kernel; a contraction length
+    that is not a multiple of its 32-deep k tile (odd batch sizes) is zero-padded first.  (The torch stand-in backend of the
+    CPU tests has no gemm_dw: plain matmul there.)"""
     f = getattr(decoder_fn.K, 'gemm_dw', None)
-    r = f(dY, X) if (f is not None and dY.is_contiguous() and X.is_contiguous()) else None
+    if f is None:
+        return dY.t() @ X
+    pad = (-dY.shape[0]) % 32
+    if pad:
+        dY, X = F.pad(dY, (0, 0, 0, pad)), F.pad(X, (0, 0, 0, pad))
+    r = f(dY.contiguous(), X.contiguous())
     return dY.t() @ X if r is None else r
+
+
+def _dx(K, groups, M):
+    """The products out_g = A_g @ W_g (+ addend_g) of one BPTT step in one launch (ops.dx_products) when every group has a
+    shape the kernel takes; one matmul per group otherwise (the stand-in backend, widths that are not multiples of 128)."""
+    f = getattr(K, 'dx_products', None)
+    if f is not None and all(K.dx_ok(M, g['W'].shape[0], g['W'].shape[1]) for g in groups):
+        f(groups, M)
+        return
+    for g in groups:
+        if g.get('addend') is not None:
+            torch.addmm(g['addend'], g['A'], g['W'], out=g['out'])
+        else:
+            torch.mm(g['A'], g['W'], out=g['out'])
 
 
 class DecoderLoopFn(torch.autograd.Function):
@@ -52,8 +73,9 @@ class DecoderLoopFn(torch.autograd.Function):
         am = att_mask[:, 1:]
         w_stack = S['w_stack']
         a1_aw, a2_aw = P['a1_aw'].reshape(-1), P['a2_aw'].reshape(-1)
-        alpha_r = torch.softmax(S['scores_r'], dim=-1)          # [B,Lc,R]
-        alpha_t = torch.softmax(S['scores_t'], dim=-1)          # [B,Lc,Ft]
+        softmax = getattr(K, 'softmax_rows', None) or (lambda x: torch.softmax(x, dim=-1))
+        alpha_r = softmax(S['scores_r'])                        # [B,Lc,R]
+        alpha_t = softmax(S['scores_t'])                        # [B,Lc,Ft]
         if d_h_all is None:
             d_h_all = torch.zeros(B, Lc, H, device=dev, dtype=fc.dtype)
         dG_lang = torch.empty(Lc, B, 4 * H, device=dev, dtype=fc.dtype)
@@ -74,14 +96,26 @@ class DecoderLoopFn(torch.autograd.Function):
         dh_att_next = dh_lang_next = None
         dc_att_next = dc_lang_next = None
         w_lang_ih, w_lang_hh, w_att_hh = P['lang_w_ih'], P['lang_w_hh'], P['att_w_hh']
+        # recurrent hidden-state gradients of the two cells: ping-pong buffers the step's product launch writes
+        dh_lang_buf = [torch.empty(B, H, device=dev, dtype=fc.dtype) for _ in range(2)]
+        dh_att_buf = [torch.empty(B, H, device=dev, dtype=fc.dtype) for _ in range(2)]
+        dh_att_cur = torch.empty(B, H, device=dev, dtype=fc.dtype)
+        dg_att_prev = None                                       # gate gradients of the attention cell at step t + 1
         for t in range(Lc - 1, -1, -1):
             # every kernel writes its step's slice of the [Lc, ...] arrays in place: no per-step copies / partial sums
             # (the two addends of a hidden-state gradient - this step's output gradient and the recurrent term of step
             # t + 1 - are added inside the pointwise kernel)
             dg, dc_lang_next = K.lstm_cell_bwd(d_h_all[:, t], dc_lang_next, S['gates_lang'][t], S['c_lang'][t],
                                                S['c_lang'][t + 1], dg_out=dG_lang[t], dh2=dh_lang_next)
-            dX = torch.mm(dg, w_lang_ih, out=dX_all[t])         # [B,2H] = [d(att+att2) | d h_att]
-            dh_lang_next = dg @ w_lang_hh
+            # ONE launch: [d(att+att2) | d h_att] = dg W_ih(lang), d h_lang(t-1) = dg W_hh(lang) and - from the attention
+            # cell's gate gradients of step t + 1 - d h_att(t) = dg_att W_hh(att)
+            dX = dX_all[t]
+            dh_lang_next = dh_lang_buf[t & 1]
+            groups = [dict(A=dg, W=w_lang_ih, out=dX), dict(A=dg, W=w_lang_hh, out=dh_lang_next)]
+            if dg_att_prev is not None:
+                dh_att_next = dh_att_buf[t & 1]
+                groups.append(dict(A=dg_att_prev, W=w_att_hh, out=dh_att_next))
+            _dx(K, groups, B)
             d_att_sum = dX[:, :H]
             pmask = (pnt_masks[:, t] if per_step_mask else pnt_masks)[:, 1:]
             q12 = S['q12'][t]
@@ -95,10 +129,9 @@ class DecoderLoopFn(torch.autograd.Function):
             K.attn_bwd_step(temporal, alpha_t[:, t], S['ctx_t'][t], d_att_sum, None, de_out=de_t_all[t],
                             dq_part=dq_t_part, dw_part=dw_t_all[t], dab_part=dab_t_all[t])
             K.sum_chunks_pair(dq_t_part, dq_r_part, dq12)        # [:, :A] temporal (a1), [:, A:] region (a2)
-            dh_att = torch.addmm(dX[:, H:], dq12, w_stack)
-            dg, dc_att_next = K.lstm_cell_bwd(dh_att, dc_att_next, S['gates_att'][t], S['c_att'][t], S['c_att'][t + 1],
-                                              dg_out=dG_att[t], dh2=dh_att_next)
-            dh_att_next = dg @ w_att_hh
+            _dx(K, [dict(A=dq12, W=w_stack, out=dh_att_cur, addend=dX[:, H:])], B)      # d h_att = dX[:, H:] + dq12 W_h2att
+            dg_att_prev, dc_att_next = K.lstm_cell_bwd(dh_att_cur, dc_att_next, S['gates_att'][t], S['c_att'][t],
+                                                       S['c_att'][t + 1], dg_out=dG_att[t], dh2=dh_att_next)
         dw_r, dw_t = dw_r_all.sum((0, 1, 2)), dw_t_all.sum((0, 1, 2))
         dab_r, dab_t = dab_r_all.sum().view(1), dab_t_all.sum().view(1)
         dctx_all = dX_all[:, :, :H]
@@ -114,8 +147,11 @@ class DecoderLoopFn(torch.autograd.Function):
         w_att_ih = P['att_w_ih']
         sumG = dG_att.sum(0)                                     # [B,4H]: the fc part of the input is loop invariant
         g = {}
-        g['fc'] = sumG @ w_att_ih[:, :H]
-        g['xt_all'] = (dGa @ w_att_ih[:, H:]).view(Lc, B, E).transpose(0, 1).contiguous()
+        g['fc'] = torch.empty(B, H, device=dev, dtype=fc.dtype)
+        _dx(K, [dict(A=sumG, W=w_att_ih[:, :H], out=g['fc'])], B)
+        dxt = torch.empty(Lc * B, E, device=dev, dtype=fc.dtype)
+        _dx(K, [dict(A=dGa, W=w_att_ih[:, H:], out=dxt)], Lc * B)
+        g['xt_all'] = dxt.view(Lc, B, E).transpose(0, 1).contiguous()
         g['att_w_ih'] = torch.cat([_tn(sumG, fc), _tn(dGa, xt_flat)], dim=1)
         g['att_w_hh'] = _tn(dGa, h_att_prev)
         g['att_b_ih'] = dGa.sum(0)
@@ -131,9 +167,15 @@ class DecoderLoopFn(torch.autograd.Function):
         g['a1_b'], g['a2_b'] = d_bstack[:A], d_bstack[A:]
         g['a1_aw'], g['a2_aw'] = dw_t.view(1, A), dw_r.view(1, A)
         g['a1_ab'], g['a2_ab'] = dab_t, dab_r
-        dctx_b = dctx_all.transpose(0, 1)                        # [B,Lc,H]
-        g['pool'] = torch.bmm(alpha_r.transpose(1, 2), dctx_b)   # [B,R,H]
-        g['conv'] = torch.bmm(alpha_t.transpose(1, 2), dctx_b)
+        dctx_b = dctx_all.transpose(0, 1)                        # [B,Lc,H] view of dX_all[:, :, :H]
+        ru = getattr(K, 'rank_update', None)
+        if ru is not None and Lc <= 32 and H % 128 == 0:
+            # alpha^T d_ctx over all steps: one streaming write of [B,R,H] / [B,Ft,H] (csrc/stream_mm.hip)
+            g['pool'] = ru(alpha_r, dctx_b)                      # [B,R,H]
+            g['conv'] = ru(alpha_t, dctx_b)
+        else:
+            g['pool'] = torch.bmm(alpha_r.transpose(1, 2), dctx_b)
+            g['conv'] = torch.bmm(alpha_t.transpose(1, 2), dctx_b)
         g['p_pool'] = K.attn_bwd_pfeats(p_pool, S['q12'][:, :, A:], de_r_all, a2_aw)
         g['p_conv'] = K.attn_bwd_pfeats(p_conv, S['q12'][:, :, :A], de_t_all, a1_aw)
         ctx.save = None

@@ -84,6 +84,15 @@ class BeamStepArgs(C.Structure):
                 ('B', C.c_int), ('K', C.c_int), ('L', C.c_int), ('t', C.c_int)]
 
 
+DX_MAX_GROUPS = 4          # GVD_DX_MAX_GROUPS
+
+
+class DxGroup(C.Structure):
+    """gvd_dx_group: one product out[M, ncols] = A[M, Kred] . W[Kred, ncols] (+ addend) of a gvd_gemm_dx_small_f32 launch."""
+    _fields_ = [('A', c_f32p), ('lda', C.c_int64), ('W', c_f32p), ('ldw', C.c_int64), ('Kred', C.c_int), ('ncols', C.c_int),
+                ('out', c_f32p), ('ldo', C.c_int64), ('addend', c_f32p), ('ld_add', C.c_int64)]
+
+
 OPT_MAX_TENSORS = 32       # GVD_OPT_MAX_TENSORS
 OPT_CHUNK = 16384          # GVD_OPT_CHUNK
 
@@ -187,6 +196,28 @@ _SIG = {
     'gvd_relu_dropout_bwd_parts': (C.c_int, [C.c_int64]),
     'gvd_relu_dropout_bwd_colsum': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     'gvd_sum_chunks_pair': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_void_p]),
+    'gvd_grounder_fwd_f32': (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int64, c_f32p, C.c_int64, c_f32p,
+                                       C.c_int64, C.c_int64, c_u8p, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int64,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'gvd_rows_contract_f32': (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_u8p, C.c_int64, C.c_int64, c_f32p, c_f32p, C.c_int64,
+                                        C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p]),
+    'gvd_rank_update_f32': (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_u8p, C.c_int64, C.c_int64, c_f32p, C.c_int64,
+                                      C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]),
+    'gvd_gemm_dx_small_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'gvd_gemm_dx_small_f32': (C.c_int, [C.POINTER(DxGroup), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'gvd_softmax_rows': (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_void_p]),
+    'gvd_masked_lsm_bwd': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
+                                     C.c_int64, C.c_void_p]),
+    'gvd_nll_gather_bwd': (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, c_i64p, c_f32p, c_f32p, c_f32p, C.c_int64,
+                                     C.c_void_p]),
+    'gvd_masked_copy_rowsum': (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_u8p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                         c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    'gvd_bn_parts': (C.c_int, [C.c_int64]),
+    'gvd_bn_train_fwd': (C.c_int, [c_f32p, C.c_int64, C.c_int, c_f32p, c_f32p, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p,
+                                   c_f32p, c_f32p, C.c_void_p]),
+    'gvd_bn_train_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     'gvd_opt_chunk': (C.c_int, []),
     'gvd_sumsq_partials': (C.c_int, [C.c_void_p, c_f32p, C.c_void_p]),
     'gvd_clip_coef': (C.c_int, [c_f32p, C.c_int, C.c_float, c_f32p, C.c_void_p]),
@@ -195,7 +226,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 16        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 17        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

@@ -7,7 +7,7 @@ import os
 
 import torch
 
-from .hip import AttnSide, GemmArgs, GemmSeg, GreedyArgs, LstmArgs, check, lib, ptr, require_cuda_f32, stream_ptr
+from .hip import AttnSide, DxGroup, GemmArgs, GemmSeg, GreedyArgs, LstmArgs, check, lib, ptr, require_cuda_f32, stream_ptr
 
 
 def _seg(A, W, K=None, a_bs=0, w_bs=0):
@@ -87,7 +87,12 @@ def gemm_dw(dY, X, split=None):
             S *= 2
     if split is not None:
         S = split
-    if M % (32 * S) or tiles * S < 256:
+    if tiles * S < 256:
+        # few output tiles and a short contraction (the [Lc B, .] weight gradients of the token loop: M = 640 .. 1280): cut the
+        # contraction down to 64-row chunks if that is what it takes to give every CU a workgroup
+        while tiles * S < 256 and M % (64 * S) == 0 and M // (2 * S) >= 32:
+            S *= 2
+    if M % (32 * S):
         return None
     Mc = M // S
     part = torch.empty(S, N, K, device=dY.device, dtype=torch.float32)
@@ -132,6 +137,114 @@ def grounder_dot(xt, feats, mask, mbias=None, rowbias=None, xt_shared=False):
     g.M, g.N, g.batch, g.act = M, R, B, 0
     check(lib().gvd_gemm_nt_f32(C.byref(g), stream_ptr()), 'gvd_gemm_nt_f32(grounder)')
     return out
+
+
+def _mask_strides(mask, M):
+    """(ptr, ld_mask, batch stride) of a u8 mask [B,R] (one row per sample) or [B,M,R] with unit inner stride."""
+    if mask is None:
+        return None, 0, 0
+    assert mask.dtype == torch.uint8 and mask.stride(-1) == 1
+    if mask.dim() == 2:
+        return ptr(mask), 0, mask.stride(0)
+    assert mask.shape[1] == M
+    return ptr(mask), mask.stride(1), mask.stride(0)
+
+
+def grounder_stream(xt, feats, mask, mbias=None, rowbias=None):
+    """`AttModel._grounder` dot branch (model.py:262-278) for the few words of a caption against the segment's region
+    features - the HBM-streaming kernel (gvd_grounder_fwd_f32): out[b,m,r] = xt[b,m,:] . feats[b,r,:] + mbias[b,m] +
+    rowbias[b,m,r]; out[mask] = -1e8.  xt [B,M,K] (M <= 32), feats [B,R,K] (K % 32 == 0), mask u8 [B,R] | [B,M,R]."""
+    require_cuda_f32(xt, feats, mbias, rowbias)
+    B, R, K = feats.shape
+    M = xt.shape[1]
+    assert xt.is_contiguous() and feats.is_contiguous() and xt.shape == (B, M, K)
+    out = torch.empty(B, M, R, device=feats.device, dtype=torch.float32)
+    mp, mld, mbs = _mask_strides(mask, M)
+    if mbias is not None:
+        assert mbias.is_contiguous() and mbias.shape == (B, M)
+    if rowbias is not None:
+        assert rowbias.is_contiguous() and rowbias.shape == (B, M, R)
+    check(lib().gvd_grounder_fwd_f32(ptr(feats), K, R * K, ptr(xt), K, M * K, ptr(mbias), M, ptr(rowbias), R, M * R,
+                                     mp, mld, mbs, ptr(out), R, M * R, B, M, R, K, stream_ptr()), 'gvd_grounder_fwd_f32')
+    return out
+
+
+def rows_contract(S, F, mask=None, S_t=None):
+    """out[b,m,:] = sum_r S[b,m,r] F[b,r,:] (entries of S under `mask` count as 0).  S [B,M,R] (M <= 32, unit inner stride),
+    F [B,R,N] contiguous (N % 128 == 0) -> [B,M,N]: one streaming pass over F (gvd_rows_contract_f32).  S_t: the transposed,
+    already masked copy [B,R,32] masked_copy_rowsum(..., want_t=True) writes - read instead of S when given."""
+    require_cuda_f32(S, F, S_t)
+    B, M, R = S.shape
+    N = F.shape[2]
+    assert F.is_contiguous() and F.shape[:2] == (B, R) and S.stride(2) == 1
+    assert S_t is None or (S_t.is_contiguous() and S_t.shape == (B, R, 32))
+    out = torch.empty(B, M, N, device=F.device, dtype=torch.float32)
+    mp, mld, mbs = _mask_strides(mask, M)
+    check(lib().gvd_rows_contract_f32(ptr(S), S.stride(1), S.stride(0), mp, mld, mbs, ptr(S_t), ptr(F), N, R * N, ptr(out), N,
+                                      M * N, B, M, R, N, stream_ptr()), 'gvd_rows_contract_f32')
+    return out
+
+
+def rank_update(S, X, mask=None):
+    """out[b,r,:] = sum_m S[b,m,r] X[b,m,:] (entries of S under `mask` count as 0).  S [B,M,R] (M <= 32, unit inner stride),
+    X [B,M,N] (unit inner stride, N % 128 == 0, 16-byte aligned rows) -> [B,R,N], written once (gvd_rank_update_f32)."""
+    require_cuda_f32(S, X)
+    B, M, R = S.shape
+    N = X.shape[2]
+    assert X.shape[:2] == (B, M) and S.stride(2) == 1 and X.stride(2) == 1
+    out = torch.empty(B, R, N, device=X.device, dtype=torch.float32)
+    mp, mld, mbs = _mask_strides(mask, M)
+    check(lib().gvd_rank_update_f32(ptr(S), S.stride(1), S.stride(0), mp, mld, mbs, ptr(X), X.stride(1), X.stride(0),
+                                    ptr(out), N, R * N, B, M, R, N, stream_ptr()), 'gvd_rank_update_f32')
+    return out
+
+
+_dx_ws = {}
+
+
+def dx_products(groups, M):
+    """Up to 4 small-M products out = A @ W (+ addend) in ONE launch (gvd_gemm_dx_small_f32; csrc/gemm_dxs.hip): the gradients
+    w.r.t. the inputs of the LSTM cells / h2att of one BPTT step.  groups: list of dict(A [M,Kred], W [Kred,ncols] (a column
+    block view of a weight: unit inner stride), out [M,ncols] (view, unit inner stride)[, addend [M,ncols]])."""
+    assert 1 <= len(groups) <= 4
+    arr = (DxGroup * len(groups))()
+    total = 0
+    for i, g in enumerate(groups):
+        A, W, out, add = g['A'], g['W'], g['out'], g.get('addend')
+        require_cuda_f32(A, W, out, add)
+        Kred, ncols = W.shape
+        assert A.shape == (M, Kred) and out.shape == (M, ncols) and A.stride(1) == 1 and W.stride(1) == 1 and out.stride(1) == 1
+        arr[i].A, arr[i].lda = ptr(A), A.stride(0)
+        arr[i].W, arr[i].ldw = ptr(W), W.stride(0)
+        arr[i].Kred, arr[i].ncols = Kred, ncols
+        arr[i].out, arr[i].ldo = ptr(out), out.stride(0)
+        if add is not None:
+            assert add.shape == (M, ncols) and add.stride(1) == 1
+            arr[i].addend, arr[i].ld_add = ptr(add), add.stride(0)
+        total += ncols
+    dev = groups[0]['A'].device
+    need = lib().gvd_gemm_dx_small_workspace_bytes(M, total)
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    ws = _dx_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(need, dtype=torch.uint8, device=dev)          # tile counters start at zero; every launch re-zeroes them
+        _dx_ws[key] = ws
+    check(lib().gvd_gemm_dx_small_f32(arr, len(groups), M, ptr(ws), ws.numel(), stream_ptr()), 'gvd_gemm_dx_small_f32')
+
+
+def dx_ok(M, Kred, ncols):
+    return Kred % 128 == 0 and ncols % 128 == 0 and M >= 1
+
+
+def softmax_rows(x, out=None):
+    """softmax over the last axis of x [..., N] (unit inner stride; leading axes collapse to rows of one stride)."""
+    require_cuda_f32(x)
+    N = x.shape[-1]
+    x2 = x.reshape(-1, N)
+    assert x2.stride(1) == 1
+    out = torch.empty(x2.shape, device=x.device, dtype=torch.float32) if out is None else out.view(-1, N)
+    check(lib().gvd_softmax_rows(ptr(x2), x2.stride(0), x2.shape[0], N, ptr(out), out.stride(0), stream_ptr()), 'gvd_softmax_rows')
+    return out.view(x.shape)
 
 
 def lstm_cell(xs, ws, h_prev, w_hh, b_ih, b_hh, c_prev, rowbias=None, gates_out=None, h_out=None, c_out=None):
@@ -357,6 +470,7 @@ def masked_lsm_loss(x, label):
     lse = torch.empty(x2.shape[0], device=x.device, dtype=torch.float32)
     check(lib().gvd_masked_lsm_loss(ptr(x2), x2.stride(0), ptr(l2), l2.stride(0), x2.shape[0], N, ptr(acc),
                                     ptr(lse), stream_ptr()), 'gvd_masked_lsm_loss')
+    masked_lsm_loss.last_acc = acc
     return acc[0] / acc[1], lse
 
 
@@ -389,6 +503,73 @@ def dropout_rows(x, p_drop, seed):
     y = torch.empty_like(x)
     check(lib().gvd_dropout_rows(ptr(x), ptr(y), x.numel(), float(p_drop), seed, stream_ptr()), 'gvd_dropout_rows')
     return y
+
+
+class _DropoutFn(torch.autograd.Function):
+    """F.dropout (training mode) on the Philox row kernel, forward and backward: dropout is linear in x, so the backward is the
+    same kernel on dy with the same seed (the mask is regenerated, never stored)."""
+
+    @staticmethod
+    def forward(ctx, x, p_drop, seed):
+        ctx.cfg = (p_drop, seed)
+        return dropout_rows(x, p_drop, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p_drop, seed = ctx.cfg
+        return dropout_rows(dy, p_drop, seed), None, None
+
+
+def dropout(x, p_drop, training=True):
+    """F.dropout(x, p_drop, training) for GPU fp32 tensors whose element count is a multiple of 4 (every dropout site of the
+    hot path: token / visual-word embeddings, h_lang - model.py:79-82,428; AttModel.py:161)."""
+    p_drop = float(p_drop)
+    if not training or p_drop <= 0.0:
+        return x
+    seed = draw_seed()
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _DropoutFn.apply(x, p_drop, seed)
+    return dropout_rows(x.detach(), p_drop, seed)
+
+
+class _BnReluTrainFn(torch.autograd.Function):
+    """nn.BatchNorm1d(C) in TRAIN mode + ReLU over x [rows, C] (model.py:114,397 `att_embed_aux` on the [B Ft, C] layout the
+    frame projections write): batch statistics + running-statistics update + normalise + ReLU in gvd_bn_train_fwd, the whole
+    backward in gvd_bn_train_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+        rows, Cc = x.shape
+        stat = torch.empty(4 * Cc, device=x.device, dtype=torch.float32)
+        parts = torch.empty(lib().gvd_bn_parts(rows) * 2 * Cc, device=x.device, dtype=torch.float32)
+        y = torch.empty_like(x)
+        check(lib().gvd_bn_train_fwd(ptr(x), rows, Cc, ptr(weight), ptr(bias), eps, momentum, ptr(running_mean),
+                                     ptr(running_var), ptr(stat), ptr(parts), ptr(y), stream_ptr()), 'gvd_bn_train_fwd')
+        ctx.save_for_backward(x, y, stat)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, stat = ctx.saved_tensors
+        rows, Cc = x.shape
+        dy = dy.contiguous()
+        parts = torch.empty(lib().gvd_bn_parts(rows) * 2 * Cc, device=x.device, dtype=torch.float32)
+        sums = torch.empty(2 * Cc, device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        check(lib().gvd_bn_train_bwd(ptr(x), ptr(y), ptr(dy), ptr(stat), rows, Cc, ptr(parts), ptr(sums), ptr(dx),
+                                     stream_ptr()), 'gvd_bn_train_bwd')
+        return dx, sums[Cc:], sums[:Cc], None, None, None, None
+
+
+def bn_relu_train(x, bn):
+    """relu(bn(x)) for an nn.BatchNorm1d `bn` in training mode, x [rows, C] contiguous (C % 4 == 0): batch statistics,
+    running statistics and num_batches_tracked updated like the module's forward does."""
+    require_cuda_f32(x)
+    assert x.is_contiguous() and x.dim() == 2 and bn.momentum is not None and bn.affine
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BnReluTrainFn.apply(x, bn.weight, bn.bias, rm, rv, float(bn.eps), float(bn.momentum))
 
 
 def relu_dropout_bwd(dy, y, p_drop):
@@ -462,10 +643,24 @@ def linear(x, w, b=None, act=0, p_drop=0.0):
     return dropout_(out, p_drop, seed) if p_drop > 0 else out
 
 
+def _stream_grounder_ok(xt, feats, xt_shared):
+    return (not xt_shared and xt.dim() == 3 and xt.shape[1] <= 32 and feats.shape[2] % 128 == 0 and xt.is_contiguous()
+            and feats.is_contiguous())
+
+
 class _GrounderFn(torch.autograd.Function):
+    """`_grounder` dot branch.  The per-caption form (xt [B, M <= 32, K]: model.py:469-480) runs on the three streaming
+    kernels of csrc/stream_mm.hip - forward and both gradients read / write the [B,R,K] region tensor exactly once, nothing
+    goes through a library GEMM; the class-similarity form (xt shared by the batch, M = D1: model.py:321-340 on configurations
+    the fused row kernels do not take) keeps the batched MFMA GEMM."""
+
     @staticmethod
     def forward(ctx, xt, feats, mask, mbias, rowbias, xt_shared):
-        out = grounder_dot(xt, feats, mask, mbias, rowbias, xt_shared)
+        ctx.stream = _stream_grounder_ok(xt, feats, xt_shared) and (mbias is None or mbias.dim() == 2)
+        if ctx.stream:
+            out = grounder_stream(xt, feats, mask, mbias, rowbias)
+        else:
+            out = grounder_dot(xt, feats, mask, mbias, rowbias, xt_shared)
         ctx.xt_shared = xt_shared
         ctx.save_for_backward(xt, feats, mask)
         ctx.mbias_dim = None if mbias is None else mbias.dim()
@@ -474,23 +669,53 @@ class _GrounderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         xt, feats, mask = ctx.saved_tensors
+        g = [None] * 6
+        if ctx.stream:
+            B, M, R = dout.shape
+            need_sum = ctx.mbias_dim is not None and ctx.needs_input_grad[3]
+            # the masked gradient IS an output (the gradient of `rowbias` = the region-attention logits): one pass writes it and
+            # its row sums (the gradient of the class bias); both products below read it
+            dm, rs, dmt = masked_copy_rowsum(dout, mask, want_sum=need_sum, want_t=True)
+            if ctx.needs_input_grad[0]:
+                g[0] = rows_contract(dm, feats, S_t=dmt)
+            if ctx.needs_input_grad[1]:
+                g[1] = rank_update(dm, xt)
+            if need_sum:
+                g[3] = rs
+            if ctx.needs_input_grad[4]:
+                g[4] = dm
+            return tuple(g)
         if mask is not None:
             m = mask.bool()
             if m.dim() == 2:
                 m = m.unsqueeze(1)
             dout = dout.masked_fill(m, 0.0)
-        g = [None] * 6
         if ctx.needs_input_grad[0]:
             dxt = torch.matmul(dout, feats)                    # [B,M,K]
             g[0] = dxt.sum(0) if ctx.xt_shared else dxt
         if ctx.needs_input_grad[1]:
             g[1] = torch.matmul(dout.transpose(1, 2), xt)     # [B,R,K] (xt broadcasts when shared)
         if ctx.mbias_dim is not None and ctx.needs_input_grad[3]:
-            s = dout.sum(-1)
-            g[3] = s.sum(0) if ctx.mbias_dim == 1 else s
+            sm = dout.sum(-1)
+            g[3] = sm.sum(0) if ctx.mbias_dim == 1 else sm
         if ctx.needs_input_grad[4]:
             g[4] = dout
         return tuple(g)
+
+
+def masked_copy_rowsum(x, mask, want_sum=True, want_t=False):
+    """y = x with the entries under `mask` (u8 [B,R] or [B,M,R]) set to 0, (optionally) y.sum(-1) and (optionally, M <= 32) the
+    transposed copy y_t [B,R,32] (columns m >= M zero): one pass (gvd_masked_copy_rowsum).  x [B,M,R]."""
+    require_cuda_f32(x)
+    B, M, R = x.shape
+    x = x if x.stride(2) == 1 else x.contiguous()
+    y = torch.empty(B, M, R, device=x.device, dtype=torch.float32)
+    rs = torch.empty(B, M, device=x.device, dtype=torch.float32) if want_sum else None
+    yt = torch.empty(B, R, 32, device=x.device, dtype=torch.float32) if want_t else None
+    mp, mld, mbs = _mask_strides(mask, M)
+    check(lib().gvd_masked_copy_rowsum(ptr(x), x.stride(1), x.stride(0), mp, mld, mbs, B, M, R, ptr(y), ptr(rs), ptr(yt),
+                                       stream_ptr()), 'gvd_masked_copy_rowsum')
+    return (y, rs, yt) if want_t else (y, rs)
 
 
 def grounder(xt, feats, mask, mbias=None, rowbias=None, xt_shared=False):
@@ -499,6 +724,8 @@ def grounder(xt, feats, mask, mbias=None, rowbias=None, xt_shared=False):
     if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
         return _GrounderFn.apply(xt, feats, mask, mbias, rowbias, xt_shared)
     d = lambda t: None if t is None else t.detach()
+    if _stream_grounder_ok(xt, feats, xt_shared) and (mbias is None or mbias.dim() == 2):
+        return grounder_stream(d(xt), d(feats), mask, d(mbias), d(rowbias))
     return grounder_dot(d(xt), d(feats), mask, d(mbias), d(rowbias), xt_shared)
 
 
@@ -507,6 +734,7 @@ class _NllGatherFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, target):
+        assert logits.stride(1) == 1 and target.is_contiguous()
         lse, picked, _, _ = logsoftmax_rows(logits, target)
         ctx.save_for_backward(logits, target, lse)
         return picked
@@ -514,8 +742,11 @@ class _NllGatherFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpicked):
         logits, target, lse = ctx.saved_tensors
-        g = -torch.exp(logits - lse.unsqueeze(1)) * dpicked.unsqueeze(1)
-        g.scatter_add_(1, target.unsqueeze(1), dpicked.unsqueeze(1))
+        rows, V = logits.shape
+        g = torch.empty(rows, V, device=logits.device, dtype=torch.float32)
+        dp = dpicked.contiguous()
+        check(lib().gvd_nll_gather_bwd(ptr(logits), logits.stride(0), rows, V, ptr(target), ptr(lse), ptr(dp), ptr(g), V,
+                                       stream_ptr()), 'gvd_nll_gather_bwd')
         return g, None
 
 
@@ -529,18 +760,19 @@ class _MaskedLsmFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, label):
         loss, lse = masked_lsm_loss(x, label)
-        ctx.save_for_backward(x, label, lse)
+        ctx.save_for_backward(x, label, lse, masked_lsm_loss.last_acc)
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
-        x, label, lse = ctx.saved_tensors
+        x, label, lse, acc = ctx.saved_tensors
         N = x.shape[-1]
-        x2, l2 = x.reshape(-1, N), (label.reshape(-1, N) != 0).to(x.dtype)
-        cnt_row = l2.sum(1, keepdim=True)
-        total = cnt_row.sum()
-        g = (torch.exp(x2 - lse.unsqueeze(1)) * cnt_row - l2) * (dloss / total)
-        return g.view_as(x), None
+        x2, l2 = x.reshape(-1, N), label.reshape(-1, N)
+        g = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
+        dl = dloss.reshape(1).contiguous()
+        check(lib().gvd_masked_lsm_bwd(ptr(x2), x2.stride(0), ptr(l2), l2.stride(0), x2.shape[0], N, ptr(acc), ptr(lse),
+                                       ptr(dl), ptr(g), N, stream_ptr()), 'gvd_masked_lsm_bwd')
+        return g.view(x.shape), None
 
 
 def masked_lsm(x, label):

@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 16
+#define GVD_ABI_VERSION 17
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -513,6 +513,95 @@ int gvd_relu_dropout_bwd_colsum(const float* dy, const float* y, float* dz, floa
  * ldo): the per-chunk query-gradient partials of gvd_attn_bwd_step's two sides of one BPTT step in one launch. */
 int gvd_sum_chunks_pair(const float* a, int nca, const float* r, int ncr, int B, int A, float* out, int64_t ldo,
                         gvd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Streaming products between the few rows of a segment (caption words / decoder steps, M <= 32) and its [R, N] region
+ * tensor (csrc/stream_mm.hip): each reads or writes the [B, R, N] tensor exactly once - HBM streams with an MFMA tail.
+ * ------------------------------------------------------------------------------------------- */
+
+/* `AttModel._grounder`, dot-product branch (model.py:262-278) as the training / grounding drivers call it
+ * (model.py:469-480): out[b,m,r] = xt[b,m,:] . feats[b,r,:] + mbias[b,m] + rowbias[b,m,r]; out[b,m,r] = GVD_MIN_VALUE where
+ * mask[b*mask_batch_stride + m*ld_mask + r] != 0 (ld_mask = 0: one mask row per sample).  feats [B,R,K] (ldf, K % 32 == 0),
+ * xt [B,M,K] (M <= 32), out [B,M,R].  mbias / rowbias / mask may be NULL. */
+int gvd_grounder_fwd_f32(const float* feats, int64_t ldf, int64_t f_batch_stride, const float* xt, int64_t ldxt,
+                         int64_t xt_batch_stride, const float* mbias, int64_t mbias_batch_stride, const float* rowbias,
+                         int64_t rowbias_ld, int64_t rowbias_batch_stride, const uint8_t* mask, int64_t ld_mask,
+                         int64_t mask_batch_stride, float* out, int64_t ldo, int64_t out_batch_stride, int B, int M, int R,
+                         int K, gvd_stream_t stream);
+
+/* out[b,m,:] = sum_r S[b,m,r] F[b,r,:]  (S entries under `mask` count as 0): the gradient of the grounder's output w.r.t.
+ * the word embeddings xt (autograd of model.py:262-265; the masked_fill blocks the gradient).  S [B,M,R] (lds, M <= 32),
+ * F [B,R,N] (ldf, N % 128 == 0), out [B,M,N].  S_t (optional): the same matrix transposed, [B,R,32] contiguous with the
+ * mask already applied and the columns m >= M zero (gvd_masked_copy_rowsum writes it) - the kernel then reads S through
+ * it (coalesced) and ignores S / mask. */
+int gvd_rows_contract_f32(const float* S, int64_t lds, int64_t s_batch_stride, const uint8_t* mask, int64_t ld_mask,
+                          int64_t mask_batch_stride, const float* S_t, const float* F, int64_t ldf, int64_t f_batch_stride, float* out,
+                          int64_t ldo, int64_t out_batch_stride, int B, int M, int R, int N, gvd_stream_t stream);
+
+/* out[b,r,:] = sum_m S[b,m,r] X[b,m,:]  (S entries under `mask` count as 0): the gradient of the grounder's output w.r.t.
+ * the region features (autograd of model.py:262-265), and d pool / d conv = alpha^T d_ctx of the two attention contexts
+ * over all decoder steps (autograd of AttModel.py:50,96).  S [B,M,R] (M <= 32), X [B,M,N] (N % 128 == 0), out [B,R,N]. */
+int gvd_rank_update_f32(const float* S, int64_t lds, int64_t s_batch_stride, const uint8_t* mask, int64_t ld_mask,
+                        int64_t mask_batch_stride, const float* X, int64_t ldx, int64_t x_batch_stride, float* out,
+                        int64_t ldo, int64_t out_batch_stride, int B, int M, int R, int N, gvd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small-M dX products of the token loop's BPTT (csrc/gemm_dxs.hip): out_g[M, ncols_g] = A_g[M, Kred_g] . W_g[Kred_g, ncols_g]
+ * (+ addend_g) for up to GVD_DX_MAX_GROUPS products in ONE launch, W consumed in place with the contraction index as its
+ * slow axis - the gradients w.r.t. the inputs of nn.LSTMCell / nn.Linear (autograd of AttModel.py:139,160,39,77):
+ * dgates . weight_ih, dgates . weight_hh, dq . h2att.weight.  Kred % 128 == 0, ncols % 128 == 0, 16-byte aligned rows.
+ * workspace: gvd_gemm_dx_small_workspace_bytes(M, total columns) bytes, ZERO before the first launch that uses it (every
+ * launch leaves its tile counters zero again); one workspace per stream.
+ * ------------------------------------------------------------------------------------------- */
+#define GVD_DX_MAX_GROUPS 4
+typedef struct {
+  const float* A; int64_t lda;          /* [M, Kred] */
+  const float* W; int64_t ldw;          /* [Kred, ncols] (a column block of a wider matrix: ldw >= ncols) */
+  int Kred; int ncols;
+  float* out; int64_t ldo;              /* [M, ncols] */
+  const float* addend; int64_t ld_add;  /* optional [M, ncols] added to the product (may alias nothing written here) */
+} gvd_dx_group;
+size_t gvd_gemm_dx_small_workspace_bytes(int M, int total_cols);
+int gvd_gemm_dx_small_f32(const gvd_dx_group* groups, int ngroups, int M, void* workspace, size_t workspace_bytes,
+                          gvd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row / column kernels of the training step (csrc/train_rows.hip)
+ * ------------------------------------------------------------------------------------------- */
+
+/* out[r, :] = softmax(x[r, :]) over N columns: alpha = softmax(e) of the saved attention scores for the BPTT
+ * (autograd of AttModel.py:46,92). */
+int gvd_softmax_rows(const float* x, int64_t ldx, int rows, int N, float* out, int64_t ldo, gvd_stream_t stream);
+
+/* Backward of gvd_masked_lsm_loss (utils.py:139,142): g[r,n] = (exp(x[r,n] - row_lse[r]) * count_r - [label[r,n] != 0]) *
+ * (*dloss / total), count_r / total read from the forward's `acc` (acc[3 + 2 r], acc[1]). */
+int gvd_masked_lsm_bwd(const float* x, int64_t ldx, const float* label, int64_t ld_label, int rows, int N, const float* acc,
+                       const float* row_lse, const float* dloss, float* g, int64_t ldg, gvd_stream_t stream);
+
+/* Backward of log_softmax(logits)[target] per row (utils.py:131-132; forward: gvd_logsoftmax_rows with `target`):
+ * g[r,v] = dpicked[r] * ([v == target[r]] - exp(logits[r,v] - lse[r])). */
+int gvd_nll_gather_bwd(const float* logits, int64_t ldx, int rows, int V, const int64_t* target, const float* lse,
+                       const float* dpicked, float* g, int64_t ldg, gvd_stream_t stream);
+
+/* y[b,m,r] = mask ? 0 : x[b,m,r] (the masked_fill of model.py:274-278 applied to the grounder's output gradient) and,
+ * when rowsum != NULL, rowsum[b,m] = sum_r y[b,m,r] (the gradient of the per-word class bias).  x [B,M,R] (ldx, batch stride),
+ * mask u8 (ld_mask = 0: one row per sample) or NULL, y [B,M,R] contiguous.  y_t (optional, M <= 32): the transposed copy
+ * [B,R,32] (y_t[b,r,m] = y[b,m,r], columns m >= M zero) gvd_rows_contract_f32 reads. */
+int gvd_masked_copy_rowsum(const float* x, int64_t ldx, int64_t x_batch_stride, const uint8_t* mask, int64_t ld_mask,
+                           int64_t mask_batch_stride, int B, int M, int R, float* y, float* rowsum, float* y_t,
+                           gvd_stream_t stream);
+
+/* nn.BatchNorm1d(C) + ReLU in TRAIN mode (model.py:114,397 `att_embed_aux`) over x [rows, C] (rows = B * Ft; C % 4 == 0):
+ * batch mean / biased variance per column by two ordered passes, y = relu((x - mean) * invstd * weight + bias); the running
+ * statistics (nullable) are updated as F.batch_norm does: r = (1 - momentum) r + momentum * (mean | UNBIASED variance).
+ * stat [4 C] receives mean | invstd | scale | shift (kept for the backward); parts: gvd_bn_parts(rows) * 2 * C floats of
+ * scratch.  Backward: dz = dy * [y > 0]; dx = scale * (dz - mean_r(dz) - xhat * mean_r(dz * xhat)); sums [2 C] receives
+ * sum_r dz (= d bias) | sum_r dz * xhat (= d weight). */
+int gvd_bn_parts(int64_t rows);
+int gvd_bn_train_fwd(const float* x, int64_t rows, int C, const float* weight, const float* bias, float eps, float momentum,
+                     float* running_mean, float* running_var, float* stat, float* parts, float* y, gvd_stream_t stream);
+int gvd_bn_train_bwd(const float* x, const float* y, const float* dy, const float* stat, int64_t rows, int C, float* parts,
+                     float* sums, float* dx, gvd_stream_t stream);
 
 /* Up to GVD_OPT_MAX_TENSORS parameter tensors of one optimiser launch, passed by value.  Tensor t owns workgroups
  * chunk0[t] .. chunk0[t+1]-1 (chunk0[0] = 0; ceil(n[t] / gvd_opt_chunk()) each).  vec_ok[t]: all of the tensor's

@@ -62,7 +62,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     import subprocess
     pairs = {'gvd_gemm_seg': hip.GemmSeg, 'gvd_gemm_args': hip.GemmArgs, 'gvd_lstm_args': hip.LstmArgs,
              'gvd_attn_side': hip.AttnSide, 'gvd_beam_step_args': hip.BeamStepArgs, 'gvd_greedy_args': hip.GreedyArgs,
-             'gvd_opt_group': hip.OptGroup}
+             'gvd_opt_group': hip.OptGroup, 'gvd_dx_group': hip.DxGroup}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gvd_hip.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -167,3 +167,33 @@ def gru_bwd_step(dout, gi, gh, out, carry_mm, carry_z, d_gi, d_gh, B, T, Hh, t_f
         d_gi[:, t, d] = torch.cat([dr, dz, dn], 1)
         d_gh[:, t, d] = torch.cat([dr, dz, dn * r], 1)
         carry_z[d] = dh * z
+
+
+def dx_ok(M, Kred, ncols):
+    return True
+
+
+def dx_products(groups, M):
+    """One 'launch' of up to 4 products out = A @ W (+ addend); every group reads its inputs before any output is written
+    (the HIP kernel's groups run concurrently: an output of one group must not be an input of another)."""
+    assert 1 <= len(groups) <= 4
+    res = []
+    for g in groups:
+        assert g['A'].shape == (M, g['W'].shape[0])
+        r = g['A'] @ g['W']
+        if g.get('addend') is not None:
+            r = r + g['addend']
+        res.append(r)
+    for g, r in zip(groups, res):
+        g['out'].copy_(r)
+
+
+def softmax_rows(x, out=None):
+    return torch.softmax(x, dim=-1)
+
+
+def rank_update(S, X, mask=None):
+    if mask is not None:
+        m = mask.bool()
+        S = S.masked_fill(m if m.dim() == 3 else m.unsqueeze(1), 0.0)
+    return torch.bmm(S.transpose(1, 2), X)

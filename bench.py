@@ -388,30 +388,64 @@ def section_train_b64(dev, n_steps=4, cpu_seconds=0.0):
 def _grounding_stream(ops, dev, B, M, R, K, reps=20):
     """The grounding product of the training step on its own (model.py:243-280, 469-480: every caption word's visual
     embedding against the segment's R fc7 region features, masked, + class bias + the region-attention logits): the one
-    kernel of the step that is a pure STREAM of the [B, T, 100, 2048]-shaped region tensor (M <= 32 rows per segment against
-    [R, K]: `gemm_nt_kernel` on the batch grid, one launch per step).  HBM roofline entry of its own: algorithmic bytes =
-    the region features once + the row-bias read + the output, over HIP-event time on the launching stream."""
+    kernel of the step that is a pure STREAM of the [B, T, 100, 2048]-shaped region tensor (M <= 32 words per segment against
+    [R, K]: grounder_fwd_kernel of csrc/stream_mm.hip, one launch per step).  HBM roofline entry of its own: algorithmic
+    bytes = the region features once + the words + the row-bias read + the mask + the output, over HIP-event time on the
+    launching stream; `traffic` = the PMC bytes of this kernel at this shape from profiles/attn_traffic.json when that file was
+    measured on this library build.  Next to it the two streams of its backward (d words: one read of the region tensor;
+    d regions: one write of its gradient)."""
     g = torch.Generator(device='cpu').manual_seed(0)
     xt = torch.randn(B, M, K, generator=g).to(dev)
     feats = torch.randn(B, R, K, generator=g).to(dev)
     mask = (torch.rand(B, M, R, generator=g) < 0.3).to(torch.uint8).to(dev)
     mbias = torch.randn(B, M, generator=g).to(dev)
     rowbias = torch.randn(B, M, R, generator=g).to(dev)
-    for _ in range(3):
-        ops.grounder_dot(xt, feats, mask, mbias, rowbias)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
-        ops.grounder_dot(xt, feats, mask, mbias, rowbias)
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    nbytes = 4 * (B * R * K + B * M * K + 2 * B * M * R + B * M) + B * M * R
-    ach = nbytes / (us * 1e-6) / 1e9
-    return {'kernel': 'gemm_nt_kernel<32, 128> (batched M <= 32 product: ops.grounder)', 'shape': [B, M, R, K], 'bound': 'hbm',
-            'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
-            'algorithmic_bytes': nbytes, 'avg_launch_us': round(us, 2), 'launches_timed': reps}
+    dout = torch.randn(B, M, R, generator=g).to(dev)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    def entry(kernel, us, nbytes, traffic_key=None):
+        ach = nbytes / (us * 1e-6) / 1e9
+        tr = _pmc_traffic_entry(traffic_key, B, M, R, K) if traffic_key else (None, None)
+        return {'kernel': kernel, 'shape': [B, M, R, K], 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': tr[0], 'traffic_source': tr[1],
+                'frac_physical': None if not tr[0] else round(tr[0] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                'algorithmic_bytes': nbytes, 'avg_launch_us': round(us, 2), 'launches_timed': reps}
+    us = timed(lambda: ops.grounder_stream(xt, feats, mask, mbias, rowbias))
+    out = entry('grounder_fwd_kernel<8 waves, 4 ring slots> (csrc/stream_mm.hip: ops.grounder forward)', us,
+                4 * (B * R * K + B * M * K + 2 * B * M * R + B * M) + B * M * R, 'grounder_fwd')
+    dm, _, dmt = ops.masked_copy_rowsum(dout, mask, want_sum=False, want_t=True)
+    out['backward_d_words'] = entry('rows_contract_kernel (one read of the region tensor)',
+                                    timed(lambda: ops.rows_contract(dm, feats, S_t=dmt)), 4 * (B * R * K + B * R * 32 + B * M * K))
+    out['backward_d_regions'] = entry('rank_update_kernel<3> (one write of the region tensor\'s gradient)',
+                                      timed(lambda: ops.rank_update(dm, xt)), 4 * (B * R * K + B * M * R + B * M * K))
+    return out
+
+
+def _pmc_traffic_entry(key, B, M, R, K):
+    """PMC bytes per launch of a stream_mm kernel from profiles/attn_traffic.json (same staleness rule as _pmc_traffic)."""
+    tpath = os.path.join(ROOT, 'profiles', 'attn_traffic.json')
+    if not os.path.exists(tpath):
+        return None, 'no profiles/attn_traffic.json'
+    with open(tpath) as f:
+        tj = json.load(f)
+    have = _lib_srchash()
+    if not have or tj.get('lib_srchash') != have:
+        return None, 'profiles/attn_traffic.json was measured on another library build: refused (stale)'
+    e = tj.get(key) or {}
+    if e.get('shape') == [B, M, R, K]:
+        return e.get('hbm_bytes_per_launch'), 'profiles/attn_traffic.json (rocprofv3 --pmc passes on this library build)'
+    return None, 'profiles/attn_traffic.json holds no entry for this shape'
 
 
 def _train_compacted(n_steps):
@@ -533,13 +567,16 @@ def section_ft480_b256(dev, n_steps=3, cpu_seconds=0.0, cpu_threads=None):
     return out
 
 
-def section_files_to_captions(dev, n_seg=256, B=64):
+def section_files_to_captions(dev, n_seg=1024, B=64):
     """The three separately measured stages COMPOSED (dataloader_anet.py:175-354 -> main.py:314-450): a synthetic split in
     the reference's on-disk layout (.npy region features [10,100,2048] per segment, resnet / bn frame features per video,
     reference-default 480 temporal positions) -> ingest.InferenceIngest (native .npy reader into pinned staging, async H2D,
     zero fill on the device) -> TopDownModel.sample_pipelined (preamble || token loop on two HIP streams) ->
     driver.collect_predictions + the densecap JSON writer.  Wall clock from the first file read to the JSON on disk; next
-    to it the same split through the ingest alone and the decode alone (inputs resident), i.e. what each stage would allow."""
+    to it the same split through the ingest alone and the decode alone (inputs resident), i.e. what each stage would allow.
+    1024 segments = 16 batches: the pipeline's fill (the first batch's file reads + upload, ~37 ms at this shape, with nothing
+    to hide behind) is 1 / 17 of the run as it is 1 / 270 of the 17 k-segment validation split; the 4-batch split of round 4
+    measured mostly that fill."""
     import shutil
     import tempfile
     from gvd_amd import att_model, driver, ingest, opts, synth

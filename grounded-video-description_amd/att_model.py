@@ -106,12 +106,17 @@ class _Core(nn.Module):
 class TopDownModel(nn.Module):
     def __init__(self, opt):
         super().__init__()
-        for k, want in (('att_model', 'topdown'), ('att_input_mode', 'both'), ('region_attn_mode', 'mix'),
-                        ('transfer_mode', 'cls'), ('t_attn_mode', 'bigru'), ('seq_per_img', 1),
-                        ('enable_BUTD', False)):
-            if getattr(opt, k) != want:
-                raise NotImplementedError('%s=%r: only the reference README configuration (%r) is built '
-                                          'on the HIP path' % (k, getattr(opt, k), want))
+        for k, want in (('att_model', ('topdown',)), ('att_input_mode', ('both',)), ('region_attn_mode', ('mix',)),
+                        ('transfer_mode', ('cls', 'none')), ('t_attn_mode', ('bigru',)), ('seq_per_img', (1,)),
+                        ('enable_BUTD', (False,))):
+            if getattr(opt, k) not in want:
+                # (profiles/r05/reference_option_survey.json: which other values the REFERENCE itself can run at its README
+                # dimensions - region_attn_mode add / cat, att_input_mode dual_region, transfer_mode glove / both raise inside
+                # misc/model.py / misc/AttModel.py; mix_mul, dp, featmap, region, bilstm run there and are not built here)
+                raise NotImplementedError('%s=%r: the HIP path is built for %s (the reference README recipe%s)'
+                                          % (k, getattr(opt, k), ' / '.join(repr(w) for w in want),
+                                             " and transfer_mode='none'" if k == 'transfer_mode' else ''))
+        self.transfer_mode = opt.transfer_mode
         self.vocab_size = opt.vocab_size
         self.detect_size = opt.detect_size
         self.rnn_size = H = opt.rnn_size
@@ -137,7 +142,13 @@ class TopDownModel(nn.Module):
         p = self.drop_prob_lm
 
         # parameter layout == reference (model.py:75-161); Sequential indices keep the '.0.' names
-        self.vis_classifiers_bias = nn.Parameter(torch.zeros(D1))
+        if self.transfer_mode == 'cls':
+            self.vis_classifiers_bias = nn.Parameter(torch.zeros(D1))
+        else:
+            # transfer_mode='none' (model.py:214-215): no class-score transfer, hence NO `vis_classifiers_bias` parameter in the
+            # reference (created only at model.py:198; every use is behind hasattr -> bias None, model.py:328-332,472-476) and
+            # none in the state_dict here: a zero buffer that is not part of it stands in (x + 0 = x)
+            self.register_buffer('vis_classifiers_bias', torch.zeros(D1), persistent=False)
         self.loc_fc = nn.Sequential(nn.Linear(5, 300), nn.ReLU(), nn.Dropout(0.5))
         self.embed = nn.Sequential(nn.Embedding(self.vocab_size, self.input_encoding_size), nn.ReLU(), nn.Dropout(p))
         self.vis_embed = nn.Sequential(nn.Embedding(D1, self.vis_encoding_size), nn.ReLU(), nn.Dropout(p))
@@ -200,6 +211,9 @@ class TopDownModel(nn.Module):
         with torch.no_grad():
             self.ctx2pool_grd[0].weight[:self.att_feat_size].copy_(load['fc7_w'])
             self.ctx2pool_grd[0].bias[:self.att_feat_size].copy_(load['fc7_b'])
+            if self.transfer_mode == 'none':               # model.py:214-215: only the fc7 layer is transferred
+                self.matched_cls = self.max_sim = None
+                return
             assert len(opt.itod) + 1 == opt.glove_clss.size(0)        # index 0 is background (model.py:189)
             assert len(opt.vg_cls) == opt.glove_vg_cls.size(0)
             vg = opt.glove_vg_cls / torch.norm(opt.glove_vg_cls, dim=1).unsqueeze(1)
@@ -727,8 +741,16 @@ class TopDownModel(nn.Module):
         s_dec.wait_stream(cur)
         outs, keep = [], []          # keep: (preamble tensors, decode-finished event) of the batches still in flight
         P = {k: v.detach() for k, v in self._decode_params().items()}
+        trace = eval_opt.get('trace')        # a list: per batch host time stamps + stream events (tools/files_timeline.py)
+        import time as _time
+        t_prev = _time.perf_counter()
         with torch.no_grad():
             for b in batches:
+                tr = None
+                if trace is not None:
+                    tr = {'asked': t_prev, 'got': _time.perf_counter()}
+                    for k in ('pre_start', 'pre_end', 'dec_start', 'dec_end'):
+                        tr[k] = torch.cuda.Event(enable_timing=True)
                 # `batches` may be a lazy producer (InferenceIngest.batches uploads on the caller's stream while we
                 # iterate): order the preamble stream after everything the caller's stream has enqueued so far
                 s_pre.wait_stream(cur)
@@ -736,15 +758,24 @@ class TopDownModel(nn.Module):
                     t.record_stream(s_pre)        # allocator must not hand their memory out again before those reads ran
                 b[5].record_stream(s_dec)         # (a lazy producer drops its reference as soon as we ask for the next batch)
                 with torch.cuda.stream(s_pre):
+                    if tr is not None:
+                        tr['pre_start'].record(s_pre)
                     pre = self._preamble(b[0], b[2], b[1], b[3], b[4], b[5], allow_compact=True)
                     ev = torch.cuda.Event()
                     ev.record(s_pre)
+                    if tr is not None:
+                        tr['pre_end'].record(s_pre)
                 with torch.cuda.stream(s_dec):
                     s_dec.wait_event(ev)
+                    if tr is not None:
+                        tr['dec_start'].record(s_dec)
                     seq, lps, att2 = ops.greedy_decode(pre, P, pre['pnt_mask'], self.seq_length, self.unk_idx,
                                                        prof=getattr(self, 'kernel_timer', None), flags=self._flags())
                     done = torch.cuda.Event()
                     done.record(s_dec)
+                    if tr is not None:
+                        tr['dec_end'].record(s_dec)
+                        tr['enqueued'] = _time.perf_counter()
                 # the features stay alive until their token loop has run - but no more than `max_in_flight` batches of them
                 # (a long split through a lazy producer would otherwise hold every batch's [B,R,.] tensors until the end):
                 # the host waits for the oldest decode before it enqueues further ahead
@@ -752,6 +783,9 @@ class TopDownModel(nn.Module):
                 while len(keep) > eval_opt.get('max_in_flight', 3):
                     keep.pop(0)[1].synchronize()
                 outs.append((seq, lps, att2, pre['sim_mat_static']))
+                if tr is not None:
+                    tr['throttled'] = t_prev = _time.perf_counter()
+                    trace.append(tr)
         cur.wait_stream(s_pre)
         cur.wait_stream(s_dec)
         for o in outs:                               # allocated on the side streams, consumed on the caller's

@@ -32,7 +32,7 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
 
 // one WAVE per row (4 rows per workgroup), the row held in registers (N <= 64 * SM_PER): one read, one write, shuffle-only
 // reductions - these rows are short (R = 1000 regions / Ft frames) and the launch is latency-, not bandwidth-bound
-constexpr int SM_PER = 32;
+template <int SM_PER>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int64_t ldx, int rows, int N,
                                                            float* __restrict__ out, int64_t ldo) {
   const int lane = threadIdx.x & 63;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     float se = 0.f;
 #pragma unroll
     for (int k = 0; k < SM_PER; ++k) {
-      v[k] = expf(v[k] - mx);              // exp(-inf) = 0 on the pad lanes
+      v[k] = __expf(v[k] - mx);            // exp(-inf) = 0 on the pad lanes
       se += v[k];
     }
     se = wave_sum(se);
@@ -244,7 +244,12 @@ __global__ __launch_bounds__(256) void bn_sum_parts_kernel(const float* __restri
 
 extern "C" int gvd_softmax_rows(const float* x, int64_t ldx, int rows, int N, float* out, int64_t ldo, gvd_stream_t stream) {
   if (!x || !out || rows <= 0 || N <= 0) return GVD_EINVAL;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, gvd_s(stream), x, ldx, rows, N, out, ldo);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t st = gvd_s(stream);
+  if (N <= 256) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, dim3(256), 0, st, x, ldx, rows, N, out, ldo);
+  else if (N <= 512) hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, dim3(256), 0, st, x, ldx, rows, N, out, ldo);
+  else if (N <= 1024) hipLaunchKernelGGL(softmax_rows_kernel<16>, grid, dim3(256), 0, st, x, ldx, rows, N, out, ldo);
+  else hipLaunchKernelGGL(softmax_rows_kernel<32>, grid, dim3(256), 0, st, x, ldx, rows, N, out, ldo);
   GVD_CHECK_LAUNCH();
   return 0;
 }

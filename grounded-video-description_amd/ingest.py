@@ -20,6 +20,7 @@ while batch i is being decoded.  All compute is in the HIP library: there is no 
 import ctypes as C
 import os
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -126,20 +127,23 @@ class InferenceIngest:
                     os.sched_setaffinity(0, cpus)         # (0 = the calling THREAD on Linux)
                 except OSError:
                     pass
-        self.pool = ThreadPoolExecutor(max_workers=workers, initializer=pin_worker)
+        self.workers = workers
+        # ONE staging thread (pinned to the staging buffers' NUMA node; the native reader threads it spawns per batch inherit
+        # its affinity).  It holds the GIL only for the per-record bookkeeping below - the file reads of a whole batch are one
+        # GIL-free native call - so it does not fight the main thread, which is busy enqueueing the previous batch's launches.
+        self._outer = ThreadPoolExecutor(max_workers=1, initializer=pin_worker)
         self.copy_stream = torch.cuda.Stream(device=device) if device is not None else None
         self._next = 0
         self._tls = threading.local()
+        self.trace = None           # a list: every batch appends its host time stamps + copy-stream events (tools/files_timeline.py)
 
     # ------------------------------------------------------------------ host half
-    def _stage_one(self, slot, b, rec):
+    def _prep_one(self, slot, b, rec):
+        """Everything of one record that does not need a file: proposals, byte mask, `num`.  -> (n proposals, n_pps)"""
         opt = self.opt
-        seg_id = rec['seg_id']
-        vid, seg_idx = seg_id.split('_segment_')
         props = np.asarray(rec['proposals'], dtype=np.float64)
         n = props.shape[0]
-        n_pps, rows_file = _read_rows_into(os.path.join(self.feature_root, seg_id + '.npy'), slot.feat_np[b], self.R)
-        assert n == rows_file, 'proposal count does not match the region feature file'          # l.191
+        n_pps = min(n, self.R)
         masked = props[:, 6] <= opt.prop_thresh                                                   # l.194-196
         if self.exclude_bgd_det:
             masked |= props[:, 5] == 0
@@ -148,33 +152,80 @@ class InferenceIngest:
         m[0] = 0                                                          # legacy pad column, main.py:345
         m[1:1 + n_pps] = masked[:n_pps]
         m[1 + n_pps:] = 1
-        # frame features: the two files are the two column blocks of one 3072-wide row -> scatter reads straight into the
-        # pinned rows
-        seg = slot.segs_np[b]
-        n_frm, num_frm = _read_rows_into(os.path.join(self.seg_feature_root, vid[2:] + '_resnet.npy'), seg[:, :2048], self.Ft)
-        _read_rows_into(os.path.join(self.seg_feature_root, vid[2:] + '_bn.npy'), seg[:, 2048:], self.Ft)
-        fm = slot.fmask_np[b]
-        fm[:n_frm] = 0
-        fm[n_frm:] = 1
         t0, t1 = rec['timestamps']
         dur = rec['duration']
-        sidx = np.array([np.round(num_frm * t0 * 1. / dur), np.round(num_frm * t1 * 1. / dur)])   # l.207-208
-        slot.sidx_np[b] = np.clip(np.round(sidx), 0, self.Ft).astype(np.int64)
+        seg_idx = rec['seg_id'].split('_segment_')[1]
         # main.py copies the FloatTensor `num` into a LongTensor: float32 rounding, then the two time stamps truncate
         slot.num_np[b] = np.array([1, n_pps, 0, int(seg_idx), rec['n_seg_in_vid'], t0 * 1. / dur, t1 * 1. / dur],
                                   dtype=np.float32).astype(np.int64)
-        slot.n_pps[b], slot.n_frm[b] = n_pps, n_frm
+        return n, n_pps
 
     def stage(self, records):
-        """Fill the next staging slot from the feature files (thread pool, one task per segment)."""
+        """Fill the next staging slot from the feature files: per-record bookkeeping on this thread, then ALL file reads of
+        the batch (3 per segment: region features, resnet / bn frame features - the two column blocks of segs_feat's
+        3072-wide rows, scatter-read straight into the pinned rows) as ONE native call on `workers` native threads."""
         assert 0 < len(records) <= self.max_batch
+        tr = {'stage_begin': time.perf_counter()} if self.trace is not None else None
         slot = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
         if slot.free is not None:
             slot.free.synchronize()                 # its previous upload still reads the pinned buffers
             slot.free = None
-        slot.B = len(records)
-        list(self.pool.map(lambda br: self._stage_one(slot, br[0], br[1]), enumerate(records)))
+        if tr is not None:
+            tr['slot_free'] = time.perf_counter()
+        B = slot.B = len(records)
+        nj = 3 * B
+        paths = (C.c_char_p * nj)()
+        dsts = (C.c_void_p * nj)()
+        max_rows, Dd, stride = (C.c_int64 * nj)(), (C.c_int64 * nj)(), (C.c_int64 * nj)()
+        rows_read, rows_file = (C.c_int64 * nj)(), (C.c_int64 * nj)()
+        counts = []
+        feat_base, feat_step = slot.feat_np.ctypes.data, slot.feat_np.strides[0]
+        segs_base, segs_step, segs_row = slot.segs_np.ctypes.data, slot.segs_np.strides[0], slot.segs_np.strides[1]
+        for b, rec in enumerate(records):
+            counts.append(self._prep_one(slot, b, rec))
+            seg_id = rec['seg_id']
+            vid = seg_id.split('_segment_')[0]
+            for k, (pth, dst, mr, d, st) in enumerate((
+                    (os.path.join(self.feature_root, seg_id + '.npy'), feat_base + b * feat_step, self.R,
+                     slot.feat_np.shape[2], slot.feat_np.strides[1]),
+                    (os.path.join(self.seg_feature_root, vid[2:] + '_resnet.npy'), segs_base + b * segs_step, self.Ft, 2048, segs_row),
+                    (os.path.join(self.seg_feature_root, vid[2:] + '_bn.npy'), segs_base + b * segs_step + 2048 * 4, self.Ft,
+                     slot.segs_np.shape[2] - 2048, segs_row))):
+                j = 3 * b + k
+                paths[j], dsts[j], max_rows[j], Dd[j], stride[j] = os.fsencode(pth), dst, mr, d, st
+        if tr is not None:
+            tr['prep_done'] = time.perf_counter()
+        job_ns = (C.c_int64 * nj)() if tr is not None else None
+        failed = hip.lib().gvd_npy_read_batch_f32(paths, dsts, max_rows, Dd, stride, nj, self.workers, rows_read, rows_file,
+                                                  job_ns)
+        if tr is not None:
+            tr['read_done'] = time.perf_counter()
+            tr['job_ms_sum'], tr['job_ms_max'] = sum(job_ns) / 1e6, max(job_ns) / 1e6
+        if failed:
+            for j in range(nj):
+                rc = rows_file[j]
+                if rc < 0:
+                    pth = os.fsdecode(paths[j])
+                    if rc <= -1000:
+                        raise ValueError('%s: not a C-ordered float32 .npy with last dimension %d (reader code %d)' % (pth, Dd[j], rc))
+                    raise OSError(-rc, os.strerror(-rc), pth)
+        for b, rec in enumerate(records):
+            n, n_pps = counts[b]
+            assert n == rows_file[3 * b], 'proposal count does not match the region feature file'          # l.191
+            assert n_pps == rows_read[3 * b]
+            n_frm, num_frm = rows_read[3 * b + 1], rows_file[3 * b + 1]
+            fm = slot.fmask_np[b]
+            fm[:n_frm] = 0
+            fm[n_frm:] = 1
+            t0, t1 = rec['timestamps']
+            dur = rec['duration']
+            sidx = np.array([np.round(num_frm * t0 * 1. / dur), np.round(num_frm * t1 * 1. / dur)])   # l.207-208
+            slot.sidx_np[b] = np.clip(np.round(sidx), 0, self.Ft).astype(np.int64)
+            slot.n_pps[b], slot.n_frm[b] = n_pps, n_frm
+        if tr is not None:
+            tr['stage_end'] = time.perf_counter()
+            slot.trace = tr
         return slot
 
     # ------------------------------------------------------------------ device half
@@ -195,6 +246,12 @@ class InferenceIngest:
         sidx = torch.empty(B, 2, dtype=torch.int64, device=dev)
         cs = self.copy_stream
         cs.wait_stream(cur)                        # the allocator may hand out blocks earlier kernels still use
+        tr = getattr(slot, 'trace', None) if self.trace is not None else None
+        if tr is not None:
+            tr['upload_enqueue'] = time.perf_counter()
+            tr['h2d_start'] = torch.cuda.Event(enable_timing=True)
+            tr['h2d_end'] = torch.cuda.Event(enable_timing=True)
+            tr['h2d_start'].record(cs)
         with torch.cuda.stream(cs):
             mask.copy_(slot.mask[:B, :Rb + 1], non_blocking=True)
             fmask.copy_(slot.fmask[:B], non_blocking=True)
@@ -235,6 +292,10 @@ class InferenceIngest:
             ops.zero_masked_rows(segs, fmask)
             slot.free = torch.cuda.Event()
             slot.free.record(cs)
+            if tr is not None:
+                tr['h2d_end'].record(cs)
+                tr['upload_enqueued'] = time.perf_counter()
+                self.trace.append(tr)
         cur.wait_stream(cs)
         out = dict(segs_feat=segs, num=num, ppls=ppls, ppls_feat=feat, sample_idx=sidx, pnt_mask=mask)
         out.update(extra)
@@ -257,9 +318,7 @@ class InferenceIngest:
             yield ch, tensors
 
     def pool_stage(self, records):
-        # staging itself fans out over self.pool; a one-thread outer executor keeps the order of the slots
-        if not hasattr(self, '_outer'):
-            self._outer = ThreadPoolExecutor(max_workers=1)
+        # the one staging thread keeps the order of the slots; the reads of a batch fan out inside its native call
         return self._outer.submit(self.stage, records)
 
 

@@ -43,6 +43,8 @@ def init_state_dict(opt, seed=0, profile='default'):
             sd[name + '.bias'] = _uniform(g, (out_f,), b)
 
     sd['vis_classifiers_bias'] = 0.01 * torch.randn(D1, generator=g)
+    if getattr(opt, 'transfer_mode', 'cls') == 'none':       # (drawn all the same: the other tensors keep their values)
+        del sd['vis_classifiers_bias']                         # model.py:198 creates it under 'cls' / 'both' only
     linear('loc_fc.0', 300, 5)
     sd['embed.0.weight'] = torch.randn(V, E, generator=g)
     sd['vis_embed.0.weight'] = 0.01 * torch.randn(D1, venc, generator=g)

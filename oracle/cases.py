@@ -64,6 +64,16 @@ CASES = {
                                        opt=dict(obj_interact=False)),
     'mle_b4_v1000_ft10_noenc': dict(mode='MLE', B=4, V=1000, Ft=10, seed=17, profile='trained_like',
                                     opt=dict(obj_interact=False)),
+    # transfer_mode='none' (opts.py:62; model.py:214-215): no class-score transfer -> no `vis_classifiers_bias` in the
+    # state_dict, bias-free similarity / grounding logits
+    'greedy_b4_v1000_ft10_tnone': dict(mode='sample', B=4, V=1000, Ft=10, seed=23, profile='trained_like',
+                                       opt=dict(transfer_mode='none')),
+    # (seed 25, not 24: at seed 24 the REFERENCE's own fp32 gradient of ctx2pool_grd.0.weight is 0.9 % away from the fp64
+    # value of the same graph - one ReLU pre-activation of the fc7 layer on the other side of zero in fp32 - and the HIP
+    # gradient, which agrees with the fp64 value, fails the 5e-3 direction check against it: tools/reference_grad_noise.py,
+    # profiles/r05/reference_grad_noise.txt)
+    'mle_b4_v1000_ft10_tnone': dict(mode='MLE', B=4, V=1000, Ft=10, seed=25, profile='trained_like',
+                                    opt=dict(transfer_mode='none')),
     'grd_b4_v1000_ft10_l40': dict(mode='GRD', B=4, V=1000, Ft=10, seed=18, profile='trained_like',
                                   opt=dict(seq_length=40)),
     # BASELINE configs[4]'s region count under GREEDY decode: 20 sampled frames x 100 proposals = 2000 regions (the beam

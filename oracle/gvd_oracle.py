@@ -227,7 +227,8 @@ def preamble(W, opt, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, fast
     # region-class similarity (model.py:321-340)
     vis_word = F.relu(W['vis_embed.0.weight'])                       # embedding of 0..D1-1, then ReLU
     p_vis = vis_word.view(1, D1, -1).expand(B, D1, vis_word.shape[1]).contiguous()
-    bias = W['vis_classifiers_bias'].view(1, -1, 1).expand(B, D1, g_pool.shape[1])
+    # (transfer_mode='none': the reference has no `vis_classifiers_bias` and passes bias = None, model.py:328-332)
+    bias = W['vis_classifiers_bias'].view(1, -1, 1).expand(B, D1, g_pool.shape[1]) if 'vis_classifiers_bias' in W else None
     sim_logits = grounder_dot(p_vis, g_pool, pnt_mask[:, 1:], bias)
     sim_mat = F.softmax(sim_logits, dim=1)
     out['sim_mat_static'] = sim_mat
@@ -410,7 +411,8 @@ def forward_train(W, opt, segs_feat, input_seq, gt_seq, num, ppls, gt_boxes, mas
     logp = word_logprobs(W, rnn_out).view(Lc * B, -1)                                 # model.py:464-465
     xt_clamp = torch.clamp(input_seq[:, 1:Lc + 1, 0] - V, min=0)                      # model.py:469
     xt_all = F.relu(F.embedding(xt_clamp, W['vis_embed.0.weight']))
-    bias = W['vis_classifiers_bias'][xt_clamp].unsqueeze(2).expand(B, Lc, R)
+    # (transfer_mode='none': bias = 0, model.py:472-476)
+    bias = W['vis_classifiers_bias'][xt_clamp].unsqueeze(2).expand(B, Lc, R) if 'vis_classifiers_bias' in W else 0
     if not eval_obj_ground:
         fmask_all = torch.stack(fmasks, 1)
         ground = grounder_dot(xt_all, pre['g_pool'], fmask_all[:, :, 1:], bias + att2_weights)

@@ -43,7 +43,7 @@ struct RankUpdParams {
   int M, R, N, tiles;
 };
 
-template <int KP, bool MATH = true>
+template <int KP>
 __global__ __launch_bounds__(256, 2) void rank_update_kernel(const RankUpdParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, half = lane >> 5;
@@ -87,19 +87,12 @@ __global__ __launch_bounds__(256, 2) void rank_update_kernel(const RankUpdParams
     f32x16 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = zero16();
-    if (MATH) {
 #pragma unroll
-      for (int i = 0; i < KP; ++i)
+    for (int i = 0; i < KP; ++i)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[i][t], xb[i][t][j], acc[j], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = s[0][e & 3] + xb[0][e & 3][j];
-    }
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[i][t], xb[i][t][j], acc[j], 0, 0, 0);
     const int r0 = tile * 32;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -131,9 +124,8 @@ struct ContractParams {
   const float* St; int64_t stbs;   // optional transposed copy of S: [B][R][32] (mask applied, rows m >= M zero)
 };
 
-constexpr int CT_RING = 8, CT_PD = 6;
+constexpr int CT_RING = 4, CT_PD = 3;     // (ring 8 / 6 ahead: same time, 252 registers - profiles/r05/stream_wide_k.txt)
 
-template <bool MATH>
 __global__ __launch_bounds__(256, 2) void rows_contract_kernel(const ContractParams p) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64 * 4];     // 64 KiB: [wave][e][lane][4]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -194,17 +186,10 @@ __global__ __launch_bounds__(256, 2) void rows_contract_kernel(const ContractPar
       const int blk = base + k;
       if (blk < nblk) {
         if (blk + CT_PD < nblk) issue((k + CT_PD) % CT_RING, blk + CT_PD);
-        if (MATH) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[k][t], fr[k][t][j], acc[j], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j][t] += sr[k][t] + fr[k][t][j];
-        }
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[k][t], fr[k][t][j], acc[j], 0, 0, 0);
       }
     }
   }
@@ -250,7 +235,7 @@ struct GroundFwdParams {
 constexpr int GS_X = 32 * 32;                           // floats per X tile (32 words x 32 k)
 
 // NW waves x 32 region rows per workgroup, STAGES ring slots (STAGES - 1 tiles in flight)
-template <int NW, int STAGES, bool MATH = true>
+template <int NW, int STAGES>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void grounder_fwd_kernel(const GroundFwdParams p) {
   constexpr int ROWS = 32 * NW, GS_A = ROWS * 32, SLOT = GS_A + GS_X;
   __shared__ __attribute__((aligned(16))) float smem[STAGES * SLOT];
@@ -310,15 +295,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void grounder_fwd_kernel(
       a[q] = *reinterpret_cast<const f32x4*>(As + so4);
       x[q] = *reinterpret_cast<const f32x4*>(Xs + so4);
     }
-    if (MATH) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][t], x[q][t], acc, 0, 0, 0);
-    } else {                                    // (diagnostic build of the access pattern alone: GVD_STREAM_NOMATH)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] += a[q][0] + x[q][1];
-    }
+      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][t], x[q][t], acc, 0, 0, 0);
   }
   // epilogue: accumulator row = region row, column = word m = r (lane); registers 4 g .. 4 g + 3 are 4 consecutive regions
   const int m = r;
@@ -339,221 +319,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void grounder_fwd_kernel(
         if (mk && mk[reg]) v = GVD_MIN_VALUE;
         ob[reg] = v;
       }
-    }
-  }
-}
-
-// ---- wide-tile form (K % 128 == 0): the 32-deep tiles above fetch 128 contiguous bytes per region row and k tile, and
-// that access pattern alone - the same kernel with its MFMAs removed - tops out at 4.7 TB/s (profiles/r05/stream_nomath_j.txt),
-// while 512-byte pieces stream at 6.0 TB/s (rows_contract without its MFMAs).  Here a workgroup of 8 waves owns 64 region rows
-// and walks K in 128-float tiles: every direct load instruction moves 2 rows x 512 contiguous bytes; a ring slot is 64 rows x
-// 512 B = 32 KB, FOUR slots (three tiles = 96 KB of the region stream in flight per CU).  The words' tile does not go
-// through LDS at all: a lane's four 16-byte fragments of xt[m, k tile] (a 160 KB matrix per segment that every workgroup of
-// the segment re-reads: L2 hits) are fetched into registers two tiles ahead.  Waves = 2 row blocks x 4 k-subtiles of a tile
-// (16 MFMAs per wave and tile); the four partial accumulators of a row block are added through LDS at the end.  16-byte slot
-// s of a row holds k-chunk s ^ (row & 31): conflict-free ds_read_b128 fragments.
-constexpr int GW_ROWS = 64, GW_KT = 128, GW_STAGES = 4;
-constexpr int GW_A = GW_ROWS * GW_KT;
-
-template <bool MATH>
-__global__ __launch_bounds__(512, 1) void grounder_fwd_wide_kernel(const GroundFwdParams p) {
-  __shared__ __attribute__((aligned(16))) float smem[GW_STAGES * GW_A];          // 131,072 B
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, half = lane >> 5;
-  const int b = blockIdx.y, r0 = blockIdx.x * GW_ROWS;
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const int slot = lane & 31, rsel = lane >> 5;
-  const int rb = wave & 1, ks = wave >> 1;
-  const __amdgpu_buffer_rsrc_t ra = gvd_rsrc(p.feats + (int64_t)b * p.fbs + (int64_t)r0 * p.ldf);
-  unsigned voa[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 2 * (wv + 8 * i) + rsel;                    // tile row this lane fills with instruction i
-    voa[i] = (unsigned)(min(r0 + row, p.R - 1) - r0) * (unsigned)p.ldf * 4u + 16u * (unsigned)(slot ^ (row & 31));
-  }
-  auto issue = [&](int kt) {                                     // region tile kt -> ring slot kt % 4: 4 direct loads per lane
-    float* As = smem + (kt % GW_STAGES) * GW_A;
-    const unsigned so = (unsigned)(GW_KT * 4) * (unsigned)kt;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)&As[2 * (wv + 8 * i) * GW_KT], 16,
-                                               voa[i], so, 0, 0);
-  };
-  // the wave's word fragments of tile kt: xt[m = r][128 kt + 32 ks + 8 q + 4 half .. + 3], q = 0..3 (4 loads per lane)
-  const float* xrow = p.xt + (int64_t)b * p.xbs + (int64_t)min(r, p.M - 1) * p.ldxt + 32 * ks + 4 * half;
-  auto xfetch = [&](f32x4 (&x)[4], int kt) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) x[q] = *reinterpret_cast<const f32x4*>(xrow + GW_KT * kt + 8 * q);
-  };
-  const int nkt = p.K / GW_KT;
-  f32x16 acc = zero16();
-  f32x4 xs[3][4];                                // word fragments of tiles kt, kt + 1, kt + 2 (set = tile % 3: no register copies)
-  // issue order (vmcnt counts completions in order): X(0) D(0) | X(1) D(1) D(2); iteration kt then adds X(kt + 2) D(kt + 3):
-  // at the top of iteration kt the loads younger than D(kt) and X(kt) are D(kt + 1), X(kt + 1), D(kt + 2) = 12 (8 / 0 at the end)
-  xfetch(xs[0], 0);
-  issue(0);
-  if (nkt > 1) { xfetch(xs[1], 1); issue(1); }
-  if (nkt > 2) issue(2);
-  // full: tiles kt + 2 and kt + 3 exist (steady state: straight-line code, so that the compiler's own wait-count bookkeeping for
-  // the fragment registers stays exact - with the fetches under conditions it drained the queue before every third tile)
-  auto step = [&](const int cur, const int ld, int kt, const bool full) {
-    const int rem = nkt - 1 - kt;
-    if (full || rem >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (full || kt + 2 < nkt) xfetch(xs[ld], kt + 2);
-    if (full || kt + 3 < nkt) issue(kt + 3);     // into the slot tile kt - 1 used: everyone is past its reads
-    const float* As = smem + (kt % GW_STAGES) * GW_A + (rb * 32 + r) * GW_KT;
-    f32x4 a[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(As + ((ks * 8 + 2 * q + half) ^ r) * 4);
-    if (MATH) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][t], xs[cur][q][t], acc, 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] += a[q][0] + xs[cur][q][1];
-    }
-  };
-  int kt = 0;
-#pragma unroll 1
-  for (; kt + 5 < nkt; kt += 3) {                // tiles kt .. kt + 2 with everything they prefetch in range
-    step(0, 2, kt, true);
-    step(1, 0, kt + 1, true);
-    step(2, 1, kt + 2, true);
-  }
-#pragma unroll 1
-  for (; kt + 2 < nkt; kt += 3) {
-    step(0, 2, kt, false);
-    step(1, 0, kt + 1, false);
-    step(2, 1, kt + 2, false);
-  }
-  if (kt < nkt) step(0, 2, kt, false);
-  if (kt + 1 < nkt) step(1, 0, kt + 1, false);
-  // partial accumulators of the 4 k-subtile waves of a row block -> LDS -> wave (rb, ks) adds registers 4 ks .. 4 ks + 3
-  __syncthreads();
-  float* red = smem;                                              // [wave][16][64]
-#pragma unroll
-  for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[e];
-  __syncthreads();
-  const int m = r;
-  if (m >= p.M) return;
-  const float mb = p.mbias ? p.mbias[(int64_t)b * p.mb_bs + m] : 0.f;
-  const float* rbp = p.rowbias ? p.rowbias + (int64_t)b * p.rb_bs + (int64_t)m * p.rb_ld : nullptr;
-  const uint8_t* mk = p.mask ? p.mask + (int64_t)b * p.mk_bs + (int64_t)m * p.ldmk : nullptr;
-  float* ob = p.out + (int64_t)b * p.obs + (int64_t)m * p.ldo;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int e = 4 * ks + t;
-    float v = 0.f;
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) v += red[((rb + 2 * k2) * 16 + e) * 64 + lane];      // k-subtile order: deterministic
-    const int reg = r0 + 32 * rb + 8 * ks + 4 * half + t;        // accumulator register e = 4 g + t  <->  region 8 g + 4 half + t
-    if (reg < p.R) {
-      v += mb;
-      if (rbp) v += rbp[reg];
-      if (mk && mk[reg]) v = GVD_MIN_VALUE;
-      ob[reg] = v;
-    }
-  }
-}
-
-// wide tile with the words' tile in LDS too: ring slot = [64 rows x 512 B | 32 words x 512 B] = 48 KB, 3 slots
-constexpr int GL_STAGES = 3;
-constexpr int GL_X = 32 * GW_KT, GL_SLOT = GW_A + GL_X;
-
-template <bool MATH>
-__global__ __launch_bounds__(512, 1) void grounder_fwd_wide3_kernel(const GroundFwdParams p) {
-  __shared__ __attribute__((aligned(16))) float smem[GL_STAGES * GL_SLOT];       // 147,456 B
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, half = lane >> 5;
-  const int b = blockIdx.y, r0 = blockIdx.x * GW_ROWS;
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const int slot = lane & 31, rsel = lane >> 5;
-  const __amdgpu_buffer_rsrc_t ra = gvd_rsrc(p.feats + (int64_t)b * p.fbs + (int64_t)r0 * p.ldf);
-  const __amdgpu_buffer_rsrc_t rx = gvd_rsrc(p.xt + (int64_t)b * p.xbs);
-  unsigned voa[4], vox[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 2 * (wv + 8 * i) + rsel;
-    voa[i] = (unsigned)(min(r0 + row, p.R - 1) - r0) * (unsigned)p.ldf * 4u + 16u * (unsigned)(slot ^ (row & 31));
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = 2 * (wv + 8 * j) + rsel;
-    vox[j] = (unsigned)min(row, p.M - 1) * (unsigned)p.ldxt * 4u + 16u * (unsigned)(slot ^ (row & 31));
-  }
-  auto issue = [&](int kt) {
-    float* As = smem + (kt % GL_STAGES) * GL_SLOT;
-    float* Xs = As + GW_A;
-    const unsigned so = (unsigned)(GW_KT * 4) * (unsigned)kt;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)&As[2 * (wv + 8 * i) * GW_KT], 16,
-                                               voa[i], so, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)&Xs[2 * (wv + 8 * j) * GW_KT], 16,
-                                               vox[j], so, 0, 0);
-  };
-  const int nkt = p.K / GW_KT;
-  const int rb = wave & 1, ks = wave >> 1;
-  f32x16 acc = zero16();
-  issue(0);
-  if (nkt > 1) issue(1);
-#pragma unroll 1
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + 2 < nkt) issue(kt + 2);
-    const float* As = smem + (kt % GL_STAGES) * GL_SLOT + (rb * 32 + r) * GW_KT;
-    const float* Xs = smem + (kt % GL_STAGES) * GL_SLOT + GW_A + r * GW_KT;
-    f32x4 a[4], x[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int so4 = ((ks * 8 + 2 * q + half) ^ r) * 4;
-      a[q] = *reinterpret_cast<const f32x4*>(As + so4);
-      x[q] = *reinterpret_cast<const f32x4*>(Xs + so4);
-    }
-    if (MATH) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][t], x[q][t], acc, 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] += a[q][0] + x[q][1];
-    }
-  }
-  __syncthreads();
-  float* red = smem;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[e];
-  __syncthreads();
-  const int m = r;
-  if (m >= p.M) return;
-  const float mb = p.mbias ? p.mbias[(int64_t)b * p.mb_bs + m] : 0.f;
-  const float* rbp = p.rowbias ? p.rowbias + (int64_t)b * p.rb_bs + (int64_t)m * p.rb_ld : nullptr;
-  const uint8_t* mk = p.mask ? p.mask + (int64_t)b * p.mk_bs + (int64_t)m * p.ldmk : nullptr;
-  float* ob = p.out + (int64_t)b * p.obs + (int64_t)m * p.ldo;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int e = 4 * ks + t;
-    float v = 0.f;
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) v += red[((rb + 2 * k2) * 16 + e) * 64 + lane];
-    const int reg = r0 + 32 * rb + 8 * ks + 4 * half + t;
-    if (reg < p.R) {
-      v += mb;
-      if (rbp) v += rbp[reg];
-      if (mk && mk[reg]) v = GVD_MIN_VALUE;
-      ob[reg] = v;
     }
   }
 }
@@ -581,10 +346,7 @@ extern "C" int gvd_rank_update_f32(const float* S, int64_t lds_, int64_t s_batch
   switch (kp) {
     case 1: hipLaunchKernelGGL(rank_update_kernel<1>, grid, dim3(256), 0, st, p); break;
     case 2: hipLaunchKernelGGL(rank_update_kernel<2>, grid, dim3(256), 0, st, p); break;
-    case 3:
-      if (getenv("GVD_STREAM_NOMATH")) hipLaunchKernelGGL((rank_update_kernel<3, false>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL(rank_update_kernel<3>, grid, dim3(256), 0, st, p);
-      break;
+    case 3: hipLaunchKernelGGL(rank_update_kernel<3>, grid, dim3(256), 0, st, p); break;
     default: hipLaunchKernelGGL(rank_update_kernel<4>, grid, dim3(256), 0, st, p); break;
   }
   GVD_CHECK_LAUNCH();
@@ -601,9 +363,7 @@ extern "C" int gvd_rows_contract_f32(const float* S, int64_t lds_, int64_t s_bat
   ContractParams p = {S, lds_, s_batch_stride, mask, ld_mask, mask_batch_stride, F, ldf, f_batch_stride,
                       out, ldo, out_batch_stride, M, R, N, 0, S_t, (int64_t)R * 32};
   p.s_vec = (gvd_aligned16(S) && (lds_ % 4) == 0 && (s_batch_stride % 4) == 0) ? 1 : 0;
-  static const bool nomath = getenv("GVD_STREAM_NOMATH") != nullptr;
-  if (nomath) hipLaunchKernelGGL(rows_contract_kernel<false>, dim3((unsigned)(N / 128), (unsigned)B), dim3(256), 0, gvd_s(stream), p);
-  else hipLaunchKernelGGL(rows_contract_kernel<true>, dim3((unsigned)(N / 128), (unsigned)B), dim3(256), 0, gvd_s(stream), p);
+  hipLaunchKernelGGL(rows_contract_kernel, dim3((unsigned)(N / 128), (unsigned)B), dim3(256), 0, gvd_s(stream), p);
   GVD_CHECK_LAUNCH();
   return 0;
 }
@@ -622,21 +382,11 @@ extern "C" int gvd_grounder_fwd_f32(const float* feats, int64_t ldf, int64_t f_b
                        rowbias, rowbias_ld, rowbias_batch_stride, mask, ld_mask, mask_batch_stride,
                        out, ldo, out_batch_stride, M, R, K};
   // 8 waves x 32 region rows per workgroup, 4 ring slots (three 36 KB tiles in flight per CU): measured best of
-  // {4 waves, 8 waves} x {3, 4} slots at the training shape (profiles/r05/stream_variants_b.jsonl)
-  static const bool nomath = getenv("GVD_STREAM_NOMATH") != nullptr;       // (diagnostic: the access pattern without the MFMAs)
-  static const bool narrow = getenv("GVD_GS_NARROW") != nullptr;           // (measurement knob: the 32-deep-tile kernel)
-  static const bool wide3 = getenv("GVD_GS_WIDE3") != nullptr;             // (measurement knob: words' tile in LDS, 3 slots)
-  if ((K % GW_KT) == 0 && !narrow) {
-    const dim3 grid((unsigned)((R + GW_ROWS - 1) / GW_ROWS), (unsigned)B);
-    if (wide3) hipLaunchKernelGGL(grounder_fwd_wide3_kernel<true>, grid, dim3(512), 0, gvd_s(stream), p);
-    else if (nomath) hipLaunchKernelGGL(grounder_fwd_wide_kernel<false>, grid, dim3(512), 0, gvd_s(stream), p);
-    else hipLaunchKernelGGL(grounder_fwd_wide_kernel<true>, grid, dim3(512), 0, gvd_s(stream), p);
-    GVD_CHECK_LAUNCH();
-    return 0;
-  }
-  if (nomath)
-    hipLaunchKernelGGL((grounder_fwd_kernel<8, 4, false>), dim3((unsigned)((R + 255) / 256), (unsigned)B), dim3(512), 0, gvd_s(stream), p);
-  else
+  // {4 waves, 8 waves} x {3, 4} slots at the training shape (profiles/r05/stream_variants_b.jsonl).  Measured and NOT adopted
+  // (profiles/r05/stream_nomath_j.txt, stream_wide_*): this kernel with its MFMAs removed runs in the same time - the 128-byte-
+  // per-row-and-tile access pattern, not the matrix pipe, sets its pace (4.7 TB/s); two 128-float-tile forms (64 rows x 512 B per
+  // ring slot, words' tile in LDS or in registers) reach 5.1 TB/s without MFMAs but lose it again with them (one workgroup per
+  // CU, 16 MFMAs per wave between barriers): within the box-to-box noise of this one, so the simpler kernel stays.
   hipLaunchKernelGGL((grounder_fwd_kernel<8, 4>), dim3((unsigned)((R + 255) / 256), (unsigned)B), dim3(512), 0, gvd_s(stream), p);
   GVD_CHECK_LAUNCH();
   return 0;

@@ -286,6 +286,10 @@ class TopDownModel(nn.Module):
             kernels are switched off for the process (ops.disable_persistent_kernels) and the batch is decoded again on the
             kernel-per-op decoder / the cooperative GRU launch.
         Only a failure of the retry raises."""
+        if self.__dict__.get('_dense_preamble_sticky') and not eval_opt.get('dense_preamble'):
+            # an earlier call met masked proposals that are not zero rows: this data source breaks the loader contract, so the
+            # compacted preamble would be computed and thrown away on every call (compact + dense = ~2x) - go dense directly
+            eval_opt = dict(eval_opt, dense_preamble=True)
         out = self._sample(segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, eval_opt)
         st = self._status_host()                    # one device->host read per call
         if st is None or st == (0, 0):
@@ -293,6 +297,13 @@ class TopDownModel(nn.Module):
         bad, contract = st
         if bad:
             ops.disable_persistent_kernels(bad)
+        if contract and not self.__dict__.get('_dense_preamble_sticky'):
+            self._dense_preamble_sticky = True
+            import warnings
+            warnings.warn("TopDownModel: masked proposals (pnt_mask = 1) with non-zero features / boxes - inputs the reference "
+                          "accepts but that break the loader's zero-row contract (dataloader_anet.py:343-344) the compacted "
+                          "preamble relies on; this and every later 'sample' call of this model run on the dense preamble",
+                          RuntimeWarning, stacklevel=3)
         opt2 = dict(eval_opt, dense_preamble=True) if contract else eval_opt
         out = self._sample(segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, opt2)
         bad2, contract2 = self._status_host() or (0, 0)
@@ -308,9 +319,10 @@ class TopDownModel(nn.Module):
                               "{'dense_preamble': True} or set GVD_COMPACT=0" % contract)
         if bad:
             raise GvdHipError('%d persistent-kernel launch(es) hit a grid-barrier timeout (workgroups not co-resident, '
-                              'e.g. a shared GPU): results are invalid.  forward() / Trainer.step() / sample_pipelined() '
-                              'recompute such calls without the persistent kernels by themselves; direct callers of '
-                              '_sample call ops.disable_persistent_kernels() and run again' % bad)
+                              'e.g. a shared GPU): results are invalid.  forward() / Trainer.step() recompute such calls without the '
+                              'persistent kernels by themselves, sample_pipelined() does when its batches are a list (a lazy '
+                              'producer cannot be replayed: driver.eval_split then falls back to its batch-by-batch loop); '
+                              'direct callers of _sample call ops.disable_persistent_kernels() and run again' % bad)
 
     def check_kernel_status(self):
         """The persistent kernels (greedy decoder B <= 4, bi-GRU) bound their grid-barrier spins and latch a flag
@@ -782,7 +794,10 @@ class TopDownModel(nn.Module):
                 keep.append((pre, done))
                 while len(keep) > eval_opt.get('max_in_flight', 3):
                     keep.pop(0)[1].synchronize()
-                outs.append((seq, lps, att2, pre['sim_mat_static']))
+                # (a whole split through a lazy producer: callers that need neither tensor say so - sim_mat_static is
+                # [B, 433, R], 1.7 MB per segment, att2 [B, L, R] 80 KB - instead of holding them for every batch until the end)
+                outs.append((seq, lps, att2 if eval_opt.get('keep_att2', True) else None,
+                             pre['sim_mat_static'] if eval_opt.get('keep_sim_mat', True) else None))
                 if tr is not None:
                     tr['throttled'] = t_prev = _time.perf_counter()
                     trace.append(tr)
@@ -790,7 +805,8 @@ class TopDownModel(nn.Module):
         cur.wait_stream(s_dec)
         for o in outs:                               # allocated on the side streams, consumed on the caller's
             for t in o:
-                t.record_stream(cur)
+                if t is not None:
+                    t.record_stream(cur)
         self._pipeline_keepalive = keep              # released on the next call, after the streams were joined
         counts = self.kernel_status_counts()
         if counts is not None:

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapPara
       const int q = m0 + ql;
       const bool qok = q < R;
       const float lq = rowv[2 * ql], dq = rowv[2 * ql + 1];
-      const uint32_t dkey = drop ? gvd_encdrop_row((uint32_t)bh * (uint32_t)p.Rp + (uint32_t)q, p.seed_lo, p.seed_hi) : 0u;
+      const gvd_encdrop_key dkey = drop ? gvd_encdrop_row((uint32_t)bh * (uint32_t)p.Rp + (uint32_t)q, p.seed_lo, p.seed_hi) : gvd_encdrop_key{0u, 0u};
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int k = n0 + cb + j * 32 + r;

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pad_kernel(const PParams p)
   }
   const bool skew = NW == 8 && wave >= NW / 2;     // wave-uniform (4-wave shape: the SIMD partner is another workgroup)
   // TRAIN: this lane's query in the dropout hash (enc_dropout.h): row id = (sample * heads + head) * rstride + query
-  const uint32_t dkey = TRAIN ? gvd_encdrop_row((uint32_t)(b * p.n_heads + h) * (uint32_t)p.rstride + (uint32_t)qrow, p.seed_lo, p.seed_hi) : 0u;
+  const gvd_encdrop_key dkey = TRAIN ? gvd_encdrop_row((uint32_t)(b * p.n_heads + h) * (uint32_t)p.rstride + (uint32_t)qrow, p.seed_lo, p.seed_hi) : gvd_encdrop_key{0u, 0u};
   const bool drop = TRAIN && p.thresh != 0u;       // wave-uniform
   const bool biased = TRAIN && p.kbias != nullptr;
   // first K fragments of the next tile, read right after the barrier that publishes it (under the last 44 MFMAs)

@@ -19,6 +19,8 @@ from collections import defaultdict
 
 import torch
 
+from .hip import GvdHipError
+
 
 def decode_sequence(itow, seq):
     """utils.decode_sequence (utils.py:90-106): words joined by ' ', stop at token 0; itow maps str(id) -> word."""
@@ -162,12 +164,21 @@ def eval_split(model, ingest_pipeline, records, batch_size, itow, opt, eval_opt=
                 chunks.append(chunk)
                 ppls_of.append(t['ppls'])
                 yield (t['segs_feat'], t['ppls'], t['num'], t['ppls_feat'], t['sample_idx'], t['pnt_mask'])
-        outs = model.sample_pipelined(produce(), eval_opt)
-        for chunk, ppls, (seq, _, att2_weights, _) in zip(chunks, ppls_of, outs):
-            collect_predictions(seq, [r['seg_id'] for r in chunk], itow, timestamps=timestamps,
-                                att2_weights=att2_weights if grounding else None, ppls=ppls, opt=opt, wtol=wtol,
-                                lemma_det_dict=lemma_det_dict, itod=itod, predictions=predictions, grd_output=grd_output)
-        records = ()                                  # (done: the loop below has nothing left)
+        try:
+            # (the sentences need the ids only; the attention logits only when grounding boxes are asked for: nothing else of a
+            # batch stays on the device until the end of the split)
+            outs = model.sample_pipelined(produce(), dict(eval_opt, keep_sim_mat=False, keep_att2=grounding))
+            for chunk, ppls, (seq, _, att2_weights, _) in zip(chunks, ppls_of, outs):
+                collect_predictions(seq, [r['seg_id'] for r in chunk], itow, timestamps=timestamps,
+                                    att2_weights=att2_weights if grounding else None, ppls=ppls, opt=opt, wtol=wtol,
+                                    lemma_det_dict=lemma_det_dict, itod=itod, predictions=predictions, grd_output=grd_output)
+            records = ()                              # (done: the loop below has nothing left)
+        except GvdHipError:
+            # a lazily produced batch cannot be replayed inside sample_pipelined (its staging buffers were recycled): a batch
+            # that broke the loader's zero-row contract, or a persistent-kernel barrier timeout, lands here - the records CAN be
+            # read again: the batch-by-batch loop below recomputes every batch through forward(..., 'sample'), which handles both
+            predictions.clear()
+            grd_output.clear()
     with torch.no_grad():
         for chunk, t in ingest_pipeline.batches(records, batch_size):
             dummy = t['ppls'].new_zeros(t['ppls'].shape[0]).byte()                     # main.py:353

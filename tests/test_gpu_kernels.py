@@ -760,6 +760,34 @@ def test_enc_dropout_mask_statistics():
     assert float(ops.enc_dropout_mask(2, 64, 0.0, 1).float().mean()) == 1.0
 
 
+def test_enc_dropout_rows_with_near_equal_additive_keys_do_not_share_a_shifted_mask():
+    """with a 32-bit row key that enters the element hash by addition, two map rows whose keys differ by d < Rp carry
+    the same mask shifted by d - at 64 x 6 maps of 1024 rows tens of thousands of such pairs exist.  The second key word (XORed
+    onto the draw, csrc/enc_dropout.h) must bring their agreement down to chance: P(both kept) + P(both dropped) = 0.68 at
+    p = 0.2.  The additive word is recomputed here on the host exactly as gvd_encdrop_row does."""
+    n_maps, Rp, p, seed = 384, 1024, 0.2, 0x1234567899
+    m = ops.enc_dropout_mask(n_maps, Rp, p, seed).view(-1, Rp).cpu().numpy()            # [rows, Rp] u8
+
+    def mix32(x):
+        x = x.astype(np.uint64)
+        x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & np.uint64(0xffffffff)
+        x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & np.uint64(0xffffffff)
+        x ^= x >> np.uint64(16)
+        return x
+    lo, hi = np.uint64(seed & 0xffffffff), np.uint64(seed >> 32)
+    rows = np.arange(n_maps * Rp, dtype=np.uint64)
+    add = mix32(rows ^ hi) ^ lo
+    order = np.argsort(add)
+    d = np.diff(add[order].astype(np.int64))
+    close = np.nonzero((d > 0) & (d < 256))[0]
+    assert len(close) > 1000                         # the birthday pairs exist in numbers
+    agree = []
+    for i in close[:300]:
+        a, b, dd = order[i], order[i + 1], int(d[i])           # add[b] = add[a] + dd: draw_b(key) shares mix32 with draw_a(key + dd)
+        agree.append(float((m[b, :Rp - dd] == m[a, dd:]).mean()))
+    assert abs(np.mean(agree) - 0.68) < 0.02, np.mean(agree)    # (identical shifted masks would give 1.0)
+
+
 def test_enc_attn_core_key_bias():
     """The per-sample key bias of the training attention core (compacted training layout, train_compact.py): 0 leaves the
     result bit-identical to the unbiased call, log n weights a key n-fold, -inf removes it - forward and gradient against

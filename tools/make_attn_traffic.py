@@ -30,5 +30,18 @@ for kind, kernel, B, Ft, R, cmd in (('greedy', 'attn_partial_kernel', 256, 10, 1
                  'traffic_over_algorithmic': round((2 * fk * 1024 + wk * 1024) / alg, 4),
                  'avg_duration_us_under_pmc': f.get('avg_duration_us'),
                  'source': 'separate rocprofv3 --pmc passes of ' + cmd}
+# the grounding stream of the training step (tools/stream_mm_bench.py 64 5 grounder_fwd under the same PMC passes): labels
+# gfwd_fetch / gfwd_write; bench.py's configs2_train_b64.grounding_stream quotes it for the shape it times
+f, w = pmc.get('gfwd_fetch'), pmc.get('gfwd_write')
+if f and w and 'FETCH_SIZE' in f and 'WRITE_SIZE' in w:
+    B, M, R, K = 64, 20, 1000, 2048
+    alg = 4 * (B * R * K + B * M * K + 2 * B * M * R + B * M) + B * M * R
+    out['grounder_fwd'] = {'kernel': 'grounder_fwd_kernel<8, 4>', 'shape': [B, M, R, K], 'FETCH_SIZE_KB_mean': f['FETCH_SIZE'],
+                           'WRITE_SIZE_KB_mean': w['WRITE_SIZE'],
+                           'hbm_bytes_per_launch': int(2 * f['FETCH_SIZE'] * 1024 + w['WRITE_SIZE'] * 1024),
+                           'algorithmic_bytes_per_launch': alg,
+                           'traffic_over_algorithmic': round((2 * f['FETCH_SIZE'] * 1024 + w['WRITE_SIZE'] * 1024) / alg, 4),
+                           'avg_duration_us_under_pmc': f.get('avg_duration_us'),
+                           'source': 'separate rocprofv3 --pmc passes of tools/stream_mm_bench.py 64 5 grounder_fwd'}
 json.dump(out, open(sys.argv[2], 'w'), indent=1)
 print(json.dumps(out, indent=1))

@@ -214,15 +214,21 @@ int pick_split(const gvd_dx_group* g, int ngroups, int M, int ncb) {
 
 }  // namespace
 
-static size_t dx_counter_bytes(int M, int ncb) {
-  return (((size_t)ncb * (size_t)((M + 63) / 64) * sizeof(unsigned) + 255) / 256) * 256;
+// The tile counters live in a FIXED region at the head of the workspace, whatever the launch's shape: a workspace is reused by
+// launches of different shapes (the M = 64 products of every BPTT step, then the [Lc B, .] post-loop ones), and a counter region
+// sized per launch would let one launch's counters fall onto bytes an earlier launch used for partial sums - non-zero counters,
+// a wrong "last workgroup", a wrong sum.  (Found by the full GPU suite in round 5: the gradient of `embed` at B = 64.)
+constexpr size_t DX_COUNTER_BYTES = 65536;
+
+static bool dx_counters_fit(int M, int ncb) {
+  return (size_t)ncb * (size_t)((M + 63) / 64) * sizeof(unsigned) <= DX_COUNTER_BYTES;
 }
 
 extern "C" size_t gvd_gemm_dx_small_workspace_bytes(int M, int total_cols) {
   if (M <= 0 || total_cols <= 0) return 0;
   const int ncb = (total_cols + 127) / 128;
   // one counter per output tile (zero before the FIRST launch; every launch leaves them zero), then up to 16 partial slabs
-  return dx_counter_bytes(M, ncb) + (size_t)16 * ((size_t)(M + 63) / 64 * 64) * (size_t)ncb * 128 * sizeof(float);
+  return DX_COUNTER_BYTES + (size_t)16 * ((size_t)(M + 63) / 64 * 64) * (size_t)ncb * 128 * sizeof(float);
 }
 
 extern "C" int gvd_gemm_dx_small_f32(const gvd_dx_group* groups, int ngroups, int M, void* workspace, size_t workspace_bytes,
@@ -243,7 +249,8 @@ extern "C" int gvd_gemm_dx_small_f32(const gvd_dx_group* groups, int ngroups, in
   p.ngroups = ngroups; p.M = M; p.ncb = ncb;
   p.split = pick_split(groups, ngroups, M, ncb);
   const int mblk64 = (M + 63) / 64;
-  const size_t cbytes = dx_counter_bytes(M, ncb);
+  if (!dx_counters_fit(M, ncb)) return GVD_EINVAL;
+  const size_t cbytes = DX_COUNTER_BYTES;
   p.part_slab = (int64_t)mblk64 * 64 * ncb * 128;
   if (cbytes + (p.split > 1 ? (size_t)p.split * p.part_slab * sizeof(float) : 0) > workspace_bytes) return GVD_EINVAL;
   if ((int64_t)p.part_slab * 4 >= (1ll << 31)) return GVD_EINVAL;              // 32-bit buffer offsets inside one slab

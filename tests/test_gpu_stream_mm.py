@@ -162,6 +162,30 @@ def test_dx_products_one_launch(M):
         _close(o, (A.double() @ w_ih[:, 1024:1536].double()).cpu(), what='post-loop dx')
 
 
+def test_dx_products_share_one_workspace_across_shapes():
+    """One workspace serves launches of different shapes (every BPTT step's M = 64 products, then the [Lc B, .] post-loop ones):
+    the tile counters must stay zero and never land on bytes another shape used for partial sums.  Largest shape FIRST, so that
+    the workspace is never regrown (a fresh, zeroed one would hide the bug the full suite found at B = 64)."""
+    g = _g(77)
+    H = 1024
+    A_big, W_big = torch.randn(1280, 4 * H, generator=g).cuda(), torch.randn(4 * H, 512, generator=g).cuda() * 0.05
+    A64 = torch.randn(64, 4 * H, generator=g).cuda()
+    W3 = [torch.randn(4 * H, n, generator=g).cuda() * 0.05 for n in (2 * H, H, H)]
+    want_big = (A_big.double() @ W_big.double()).cpu()
+    want3 = [(A64.double() @ w.double()).cpu() for w in W3]
+    for rnd in range(3):
+        o = torch.empty(1280, 512, device='cuda')
+        ops.dx_products([dict(A=A_big, W=W_big, out=o)], 1280)
+        _close(o, want_big, what='post-loop shape, round %d' % rnd)
+        outs = [torch.empty(64, w.shape[1], device='cuda') for w in W3]
+        ops.dx_products([dict(A=A64, W=w, out=t) for w, t in zip(W3, outs)], 64)
+        for t, wnt in zip(outs, want3):
+            _close(t, wnt, what='step shape, round %d' % rnd)
+        o32 = torch.empty(32, 512, device='cuda')
+        ops.dx_products([dict(A=A_big[:32], W=W_big, out=o32)], 32)
+        _close(o32, want_big[:32], what='M = 32, round %d' % rnd)
+
+
 def test_softmax_rows_and_loss_backwards():
     g = _g(3)
     x = (torch.randn(6, 20, 1000, generator=g) * 4)

@@ -590,6 +590,20 @@ def section_files_to_captions(dev, n_seg=1024, B=64):
                 break
         except OSError:
             pass
+    if base != '/dev/shm' and n_seg > 256:
+        # no room in /dev/shm for the 16-batch split (10 GB): do not spend minutes writing it to a disk-backed directory
+        # inside a benchmark run - fall back to the 4-batch split
+        n_seg = 256
+        need = n_seg * (1000 * 2048 * 4) + (n_seg // 4 + 1) * 600 * 3072 * 4
+        base = None
+        for cand in ('/dev/shm', tempfile.gettempdir()):
+            try:
+                st = os.statvfs(cand)
+                if st.f_bavail * st.f_frsize > 1.3 * need:
+                    base = cand
+                    break
+            except OSError:
+                pass
     if base is None:
         return {'skipped': 'no scratch directory with %.1f GB free' % (1.3 * need / 1e9)}
     root = tempfile.mkdtemp(prefix='gvd_split_', dir=base)

@@ -659,6 +659,8 @@ def section_files_to_captions(dev, n_seg=1024, B=64):
         for r in (short, full):
             r['fraction_of_the_slower_stage'] = round(r['captions_per_s'] / min(r['ingest_alone_segments_per_s'], dec), 3)
         full.update(batch=B, t_attn_size=480, scratch=base, decode_alone_captions_per_s=dec, dataset_write_seconds=round(t_write, 1),
+                    reader_threads=ing.workers, cpu_budget=round(ingest.cpu_budget(), 1),
+                    read=('mapped' if ing.read_mode == 1 else 'pread'),
                     short_split_256=short,
                     path="synth.write_feature_split -> ingest.InferenceIngest -> TopDownModel.sample_pipelined -> "
                          "driver.collect_predictions + densecap-<split>-<id>.json")

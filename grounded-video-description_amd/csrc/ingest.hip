@@ -9,10 +9,15 @@
 #include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sys/uio.h>
 #include <unistd.h>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -88,8 +93,24 @@ extern "C" int64_t gvd_pread_rows(int fd, int64_t file_off, void* dst, int64_t r
 // per-file work of the ingest as ONE native call: no Python header parsing (ast.literal_eval), no file object, no GIL.
 // Returns the rows in the file (>= 0; *rows_read = rows copied) or a negative code: -errno, or -1000 - k for a malformed /
 // unsupported header (k: 1 magic, 2 header length, 3 dtype, 4 order, 5 shape, 6 last dimension, 7 short read).
-extern "C" int64_t gvd_npy_read_rows_f32(const char* path, void* dst, int64_t max_rows, int64_t D, int64_t dst_stride,
-                                         int64_t* rows_read) {
+// How the payload travels from the page cache into the (pinned, GPU-mapped) destination rows:
+//   GVD_READ_MAPPED  the file is mapped (no MAP_POPULATE: fault-around maps 16 resident pages per fault under the per-VMA
+//                    lock) and the rows are copied in user space, then the mapping is dropped.  Default of the ingest.
+//   GVD_READ_PREAD   pread() straight into the destination rows.
+// Both were timed under the running GPU pipeline (files -> captions, profiles/r05/files_read_path.txt): the read() system
+// call is the part that slows down 2.5-3.5x while the decode is enqueued next to it, and every few batches all readers
+// stall in it for ~50 ms; the user-space copy out of a mapping stays at its idle speed.  A file that is truncated by
+// another process WHILE it is mapped raises SIGBUS instead of a short read - callers that read feature files being
+// rewritten select GVD_READ_PREAD (ingest.py: GVD_INGEST_READ=pread).
+
+
+static void copy_rows(char* d, const char* src, int64_t rows, int64_t row_bytes, int64_t dst_stride) {
+  if (dst_stride == row_bytes) { memcpy(d, src, (size_t)(rows * row_bytes)); return; }
+  for (int64_t r = 0; r < rows; ++r) memcpy(d + r * dst_stride, src + r * row_bytes, (size_t)row_bytes);
+}
+
+static int64_t npy_read_rows(const char* path, void* dst, int64_t max_rows, int64_t D, int64_t dst_stride, int64_t* rows_read,
+                             int mode) {
   if (!path || !dst || max_rows < 0 || D <= 0 || dst_stride < D * 4 || !rows_read) return -EINVAL;
   *rows_read = 0;
   const int fd = open(path, O_RDONLY | O_CLOEXEC);
@@ -138,7 +159,20 @@ extern "C" int64_t gvd_npy_read_rows_f32(const char* path, void* dst, int64_t ma
   }
   if (!rc) {
     const int64_t rows = rows_file < max_rows ? rows_file : max_rows;
-    if (rows > 0) {
+    if (rows > 0 && mode == GVD_READ_MAPPED) {
+      const int64_t off = hoff + hlen, len = off + rows * D * 4;
+      struct stat st;
+      if (fstat(fd, &st) != 0) rc = -errno;
+      else if ((int64_t)st.st_size < len) rc = -1007;          // the header promises more rows than the file holds
+      else {
+        void* m = mmap(nullptr, (size_t)len, PROT_READ, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) rc = -errno;
+        else {
+          copy_rows(static_cast<char*>(dst), static_cast<const char*>(m) + off, rows, D * 4, dst_stride);
+          munmap(m, (size_t)len);
+        }
+      }
+    } else if (rows > 0) {
       const int64_t n = gvd_pread_rows(fd, hoff + hlen, dst, rows, D * 4, dst_stride);
       if (n < 0) rc = n;
       else if (n != rows * D * 4) rc = -1007;
@@ -149,6 +183,70 @@ extern "C" int64_t gvd_npy_read_rows_f32(const char* path, void* dst, int64_t ma
   return rc;
 }
 
+extern "C" int64_t gvd_npy_read_rows_f32(const char* path, void* dst, int64_t max_rows, int64_t D, int64_t dst_stride,
+                                         int64_t* rows_read) {
+  return npy_read_rows(path, dst, max_rows, D, dst_stride, rows_read, GVD_READ_PREAD);
+}
+
+// Persistent reader threads (host side only).  Spawning the readers per batch - clone + an 8 MB stack mapping + its teardown,
+// 31 times per batch - put every batch's first reads behind the process's address-space lock while the GPU pipeline was
+// running (files -> captions timeline, profiles/r05): the threads are created once, sleep on a condition variable between
+// batches and inherit the CPU affinity of the thread that makes the FIRST call (ingest.py's pinned staging thread).
+namespace {
+class ReaderPool {
+ public:
+  template <typename F> void run(int helpers, F& work) {
+    std::unique_lock<std::mutex> call(call_mu_);              // one batch at a time
+    if (helpers > (int)threads_.size()) grow(helpers);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      fn_ = [&work]() { work(); };
+      want_ = helpers; done_ = 0; ++gen_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> g(mu_);
+    cv_done_.wait(g, [&] { return done_ == want_; });
+    fn_ = nullptr;
+  }
+  ~ReaderPool() {
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+ private:
+  void grow(int n) {
+    while ((int)threads_.size() < n) {
+      const int id = (int)threads_.size();
+      threads_.emplace_back([this, id]() {
+        uint64_t seen = 0;
+        for (;;) {
+          std::function<void()> f;
+          {
+            std::unique_lock<std::mutex> g(mu_);
+            cv_.wait(g, [&] { return stop_ || (gen_ != seen && id < want_); });
+            if (stop_) return;
+            seen = gen_;
+            f = fn_;
+          }
+          f();
+          { std::lock_guard<std::mutex> g(mu_); ++done_; }
+          cv_done_.notify_one();
+        }
+      });
+    }
+  }
+  std::mutex call_mu_, mu_;
+  std::condition_variable cv_, cv_done_;
+  std::vector<std::thread> threads_;
+  std::function<void()> fn_;
+  int want_ = 0, done_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+ReaderPool& reader_pool() { static ReaderPool* p = new ReaderPool(); return *p; }     // (never destroyed: no join at exit)
+}  // namespace
+
 // All feature files of ONE batch in one native call: n (path, destination) jobs handed to `n_threads` native threads that
 // pull job indices from an atomic counter (the files differ in size: 8 MB region features, 4 + 2 MB frame features).  The
 // Python side makes ONE GIL-free call per batch instead of three per segment from a pool of Python threads: those threads
@@ -158,26 +256,22 @@ extern "C" int64_t gvd_npy_read_rows_f32(const char* path, void* dst, int64_t ma
 // rows_file[i] receives gvd_npy_read_rows_f32's result for job i (rows in the file, or a negative code), rows_read[i] the
 // rows copied.  Returns the number of failed jobs.
 extern "C" int gvd_npy_read_batch_f32(const char* const* paths, void* const* dsts, const int64_t* max_rows, const int64_t* D,
-                                      const int64_t* dst_stride, int n, int n_threads, int64_t* rows_read, int64_t* rows_file,
-                                      int64_t* job_ns) {
-  if (!paths || !dsts || !max_rows || !D || !dst_stride || !rows_read || !rows_file || n < 0) return -EINVAL;
+                                      const int64_t* dst_stride, int n, int n_threads, int mode, int64_t* rows_read,
+                                      int64_t* rows_file, int64_t* job_ns) {
+  if (!paths || !dsts || !max_rows || !D || !dst_stride || !rows_read || !rows_file || n < 0 || (mode != GVD_READ_PREAD && mode != GVD_READ_MAPPED)) return -EINVAL;
   std::atomic<int> next(0), failed(0);
   auto work = [&]() {
     for (;;) {
       const int i = next.fetch_add(1, std::memory_order_relaxed);
       if (i >= n) break;
       const auto t0 = std::chrono::steady_clock::now();
-      rows_file[i] = gvd_npy_read_rows_f32(paths[i], dsts[i], max_rows[i], D[i], dst_stride[i], &rows_read[i]);
+      rows_file[i] = npy_read_rows(paths[i], dsts[i], max_rows[i], D[i], dst_stride[i], &rows_read[i], mode);
       if (job_ns) job_ns[i] = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
       if (rows_file[i] < 0) failed.fetch_add(1, std::memory_order_relaxed);
     }
   };
   int nt = n_threads < 1 ? 1 : n_threads;
   if (nt > n) nt = n;
-  std::vector<std::thread> pool;
-  pool.reserve(nt > 1 ? nt - 1 : 0);
-  for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-  work();
-  for (auto& t : pool) t.join();
+  reader_pool().run(nt - 1, work);          // nt - 1 pooled threads + the caller
   return failed.load();
 }

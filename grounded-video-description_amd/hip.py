@@ -183,7 +183,7 @@ _SIG = {
     'gvd_greedy_decode': (C.c_int, [C.POINTER(GreedyArgs), C.c_void_p]),
     'gvd_pread_rows': (C.c_int64, [C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
     'gvd_npy_read_rows_f32': (C.c_int64, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
-    'gvd_npy_read_batch_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+    'gvd_npy_read_batch_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     'gvd_zero_masked_rows': (C.c_int, [c_f32p, C.c_int64, C.c_int, c_u8p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     'gvd_iou_targets': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_u8p, c_u8p, C.c_int, C.c_int, C.c_int,

@@ -98,6 +98,39 @@ class _Slot:
         self.free = None            # event: the previous upload from this slot has finished reading it
 
 
+def cpu_budget():
+    """CPUs this process may actually burn: the smaller of its affinity mask and its container's CFS quota (cgroup v2
+    cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  The GPU box shows 256 CPUs and grants 16: 32 busy reader threads
+    next to the launching main thread ran the container into its quota, the kernel throttled every thread for the rest of the
+    100 ms period, and the files -> captions timeline showed it as all readers stalling ~50 ms at once every few batches
+    (profiles/r05/files_read_path.txt)."""
+    try:
+        n = float(len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        n = float(os.cpu_count() or 8)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, float(quota) / float(period))
+    except (OSError, ValueError):
+        try:
+            quota = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0 and period > 0:
+                n = min(n, quota / period)
+        except (OSError, ValueError):
+            pass
+    return max(1.0, n)
+
+
+def default_workers():
+    """Reader threads of one staging call.  One segment is three page-cache -> pinned-memory copies (8 + 4 + 2 MB at Ft =
+    480); 8 to 16 mapped-copy readers keep the staging of a batch of 64 under the GPU's time for it (28 vs 31.7 ms, profiles/r05)
+    and more only help while the CPU budget holds: four CPUs stay free for the launching thread, the staging thread and the
+    HIP runtime's own threads."""
+    return int(max(2, min(16, cpu_budget() - 4)))
+
+
 class InferenceIngest:
     """records: dicts with seg_id '<vid>_segment_<k>', n_seg_in_vid, timestamps (t0, t1), duration, proposals [n,7]."""
 
@@ -106,10 +139,7 @@ class InferenceIngest:
         if numa_local is None:
             numa_local = os.environ.get('GVD_INGEST_NUMA', '1') == '1'
         if workers is None:
-            # one segment is three page-cache -> pinned-memory copies (8 + 4 + 2 MB at Ft = 480): a host thread moves
-            # ~3 GB/s, so the reader pool is sized to the host, not to a fixed 8 (measured on the 256-thread GPU box:
-            # tools/ingest_bench.py)
-            workers = max(8, min(32, (os.cpu_count() or 8) // 4))
+            workers = default_workers()
         self.opt = opt
         self.feature_root, self.seg_feature_root = feature_root, seg_feature_root
         self.device = device
@@ -128,6 +158,12 @@ class InferenceIngest:
                 except OSError:
                     pass
         self.workers = workers
+        # 'mapped' (default): map each file, copy its rows in user space; 'pread': read() into the staging rows - for feature
+        # files another process may truncate while they are read (csrc/ingest.hip, GVD_READ_*)
+        how = os.environ.get('GVD_INGEST_READ', 'mapped')
+        if how not in ('mapped', 'pread'):
+            raise ValueError("GVD_INGEST_READ must be 'mapped' or 'pread', got %r" % how)
+        self.read_mode = 1 if how == 'mapped' else 0
         # ONE staging thread (pinned to the staging buffers' NUMA node; the native reader threads it spawns per batch inherit
         # its affinity).  It holds the GIL only for the per-record bookkeeping below - the file reads of a whole batch are one
         # GIL-free native call - so it does not fight the main thread, which is busy enqueueing the previous batch's launches.
@@ -197,8 +233,8 @@ class InferenceIngest:
         if tr is not None:
             tr['prep_done'] = time.perf_counter()
         job_ns = (C.c_int64 * nj)() if tr is not None else None
-        failed = hip.lib().gvd_npy_read_batch_f32(paths, dsts, max_rows, Dd, stride, nj, self.workers, rows_read, rows_file,
-                                                  job_ns)
+        failed = hip.lib().gvd_npy_read_batch_f32(paths, dsts, max_rows, Dd, stride, nj, self.workers, self.read_mode,
+                                                  rows_read, rows_file, job_ns)
         if tr is not None:
             tr['read_done'] = time.perf_counter()
             tr['job_ms_sum'], tr['job_ms_max'] = sum(job_ns) / 1e6, max(job_ns) / 1e6

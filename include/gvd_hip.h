@@ -461,11 +461,17 @@ int64_t gvd_npy_read_rows_f32(const char* path, void* dst, int64_t max_rows, int
                               int64_t* rows_read);
 
 /* Every feature file of one batch in ONE call: job i reads paths[i] like gvd_npy_read_rows_f32 (rows_file[i] = its result,
- * rows_read[i] = rows copied) on `n_threads` native threads that inherit the caller's CPU affinity.  Returns the number of
- * failed jobs (< 0: -EINVAL).  One GIL-free call per batch instead of three per segment from Python threads.  job_ns
- * (nullable): wall nanoseconds every job took (timeline diagnostics). */
+ * rows_read[i] = rows copied) on the caller + n_threads - 1 PERSISTENT native threads (created at the first call, asleep on
+ * a condition variable between batches; they inherit the first caller's CPU affinity).  Returns the number of failed jobs
+ * (< 0: -EINVAL).  One GIL-free call per batch instead of three per segment from Python threads.
+ * mode: GVD_READ_PREAD (0) = pread / preadv straight into the destination rows; GVD_READ_MAPPED (1) = map the file, copy
+ * its rows in user space, unmap (a file shorter than its header promises is -1007 in both; a file truncated by another
+ * process WHILE mapped raises SIGBUS - use 0 for files that are being rewritten).  job_ns (nullable): wall nanoseconds per
+ * job (timeline diagnostics).  Replaces the DataLoader workers' np.load calls (dataloader_anet.py:189,198-199). */
+#define GVD_READ_PREAD 0
+#define GVD_READ_MAPPED 1
 int gvd_npy_read_batch_f32(const char* const* paths, void* const* dsts, const int64_t* max_rows, const int64_t* D,
-                           const int64_t* dst_stride, int n, int n_threads, int64_t* rows_read, int64_t* rows_file,
+                           const int64_t* dst_stride, int n, int n_threads, int mode, int64_t* rows_read, int64_t* rows_file,
                            int64_t* job_ns);
 
 /* ---------------------------------------------------------------------------------------------

@@ -108,3 +108,86 @@ def test_train_ingest_host_half_matches_oracle(dataset):
         assert np.array_equal(boxes, want['gt_boxes'][b, :k].numpy()) and float(want['gt_boxes'][b, k:].abs().sum()) == 0
         assert np.array_equal(bmask, want['mask_boxes'][b, :, :k].numpy()) and bool((want['mask_boxes'][b, :, k:] == 1).all())
         assert k <= NB
+
+
+@pytest.mark.parametrize('mode', [0, 1])                       # GVD_READ_PREAD, GVD_READ_MAPPED (include/gvd_hip.h)
+def test_native_batch_reader_modes(tmp_path, mode):
+    """gvd_npy_read_batch_f32 (csrc/ingest.hip; replaces the np.load calls of dataloader_anet.py:189,198-199): both ways of
+    moving a file's rows into strided destination rows give np.load's bytes - row caps, ragged files, more threads than jobs,
+    a second call on the persistent reader threads - and report bad files per job instead of failing the batch: a file cut
+    short of what its header promises (-1007, also for the mapped read, which checks the size BEFORE it maps), a float64
+    file (-1003), a wrong last dimension (-1006), a missing file (-ENOENT)."""
+    import ctypes
+    import errno
+    from gvd_amd import hip
+    rng = np.random.default_rng(5)
+    D = 96
+    good = []
+    for i, rows in enumerate((1, 7, 100, 2500)):
+        a = rng.standard_normal((rows, D)).astype(np.float32)
+        if i == 2:
+            a = a.reshape(4, 25, D)                                # rows = product of all but the last dimension
+        np.save(tmp_path / ('g%d.npy' % i), a)
+        good.append((str(tmp_path / ('g%d.npy' % i)), a.reshape(-1, D)))
+    whole = np.load(good[3][0])
+    np.save(tmp_path / 'short.npy', whole)
+    with open(tmp_path / 'short.npy', 'r+b') as f:
+        f.truncate(128 + 2000 * D * 4)
+    np.save(tmp_path / 'f64.npy', whole[:3].astype(np.float64))
+    np.save(tmp_path / 'dim.npy', whole[:3, :D - 1].copy())
+    bad = [(str(tmp_path / 'short.npy'), -1007), (str(tmp_path / 'f64.npy'), -1003), (str(tmp_path / 'dim.npy'), -1006),
+           (str(tmp_path / 'missing.npy'), -errno.ENOENT)]
+    jobs = [(p, a, cap) for (p, a), cap in zip(good, (4, 3, 100, 2048))] + [(p, None, 2048) for p, _ in bad]
+    n = len(jobs)
+    stride = (D + 8) * 4                                           # destination rows wider than the file's
+    lib = hip.lib()
+    for n_threads in (1, 3, 32):
+        dst = [np.full((cap, D + 8), -7.0, np.float32) for _, _, cap in jobs]
+        paths = (ctypes.c_char_p * n)(*[p.encode() for p, _, _ in jobs])
+        dsts = (ctypes.c_void_p * n)(*[d.ctypes.data for d in dst])
+        caps = (ctypes.c_int64 * n)(*[cap for _, _, cap in jobs])
+        Ds = (ctypes.c_int64 * n)(*([D] * n))
+        strides = (ctypes.c_int64 * n)(*([stride] * n))
+        rows_read = (ctypes.c_int64 * n)()
+        rows_file = (ctypes.c_int64 * n)()
+        ns = (ctypes.c_int64 * n)()
+        failed = lib.gvd_npy_read_batch_f32(paths, dsts, caps, Ds, strides, n, n_threads, mode, rows_read, rows_file, ns)
+        assert failed == len(bad)
+        for i, (p, a, cap) in enumerate(jobs):
+            if a is None:
+                assert rows_file[i] == bad[i - len(good)][1] and rows_read[i] == 0, (p, rows_file[i])
+                continue
+            k = min(cap, a.shape[0])
+            assert rows_file[i] == a.shape[0] and rows_read[i] == k and ns[i] > 0
+            assert np.array_equal(dst[i][:k, :D], a[:k])
+            assert np.all(dst[i][:k, D:] == -7.0) and np.all(dst[i][k:] == -7.0)      # nothing outside the rows it was given
+    assert lib.gvd_npy_read_batch_f32(paths, dsts, caps, Ds, strides, n, 2, 7, rows_read, rows_file, None) == -errno.EINVAL
+
+
+def test_read_mode_selection(dataset, monkeypatch):
+    opt, fr, sr, recs = dataset
+    assert ingest.InferenceIngest(opt, fr, sr, device=None, max_batch=2).read_mode == 1
+    monkeypatch.setenv('GVD_INGEST_READ', 'pread')
+    ing = ingest.InferenceIngest(opt, fr, sr, device=None, max_batch=2)
+    assert ing.read_mode == 0 and ing.stage(recs[:2]).B == 2
+    monkeypatch.setenv('GVD_INGEST_READ', 'bounce')
+    with pytest.raises(ValueError):
+        ingest.InferenceIngest(opt, fr, sr, device=None, max_batch=2)
+
+
+def test_default_reader_threads_follow_the_cpu_budget(monkeypatch):
+    """ingest.default_workers: sized to what the container may burn (affinity mask, CFS quota), not to os.cpu_count() - the GPU
+    box shows 256 CPUs and grants 16."""
+    import builtins
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == '/sys/fs/cgroup/cpu.max':
+            import io
+            return io.StringIO('1600000 100000\n')
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(256)))
+    monkeypatch.setattr(builtins, 'open', fake_open)
+    assert ingest.cpu_budget() == 16.0 and ingest.default_workers() == 12
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(4)))
+    assert ingest.cpu_budget() == 4.0 and ingest.default_workers() == 2

@@ -106,17 +106,21 @@ class _Core(nn.Module):
 class TopDownModel(nn.Module):
     def __init__(self, opt):
         super().__init__()
-        for k, want in (('att_model', ('topdown',)), ('att_input_mode', ('both',)), ('region_attn_mode', ('mix',)),
+        for k, want in (('att_model', ('topdown',)), ('att_input_mode', ('both', 'featmap', 'region')),
+                        ('region_attn_mode', ('mix',)),
                         ('transfer_mode', ('cls', 'none')), ('t_attn_mode', ('bigru',)), ('seq_per_img', (1,)),
                         ('enable_BUTD', (False,))):
             if getattr(opt, k) not in want:
                 # (profiles/r05/reference_option_survey.json: which other values the REFERENCE itself can run at its README
                 # dimensions - region_attn_mode add / cat, att_input_mode dual_region, transfer_mode glove / both raise inside
-                # misc/model.py / misc/AttModel.py; mix_mul, dp, featmap, region, bilstm run there and are not built here)
-                raise NotImplementedError('%s=%r: the HIP path is built for %s (the reference README recipe%s)'
-                                          % (k, getattr(opt, k), ' / '.join(repr(w) for w in want),
-                                             " and transfer_mode='none'" if k == 'transfer_mode' else ''))
+                # misc/model.py / misc/AttModel.py; mix_mul, dp, bilstm run there and are not built here)
+                raise NotImplementedError('%s=%r: the HIP path is built for %s (the reference README recipe is the first)'
+                                          % (k, getattr(opt, k), ' / '.join(repr(w) for w in want)))
         self.transfer_mode = opt.transfer_mode
+        # what the language LSTM is fed (opts.py:58, AttModel.py:140-151): 'both' att + att2 (README), 'featmap' the frame-wise
+        # context alone (the region attention still runs: its logits are the grounding output), 'region' the region context
+        # alone - no frame-wise encoder / attention at all (model.py:393,406-409).  Same parameters in all three.
+        self.att_input_mode = opt.att_input_mode
         self.vocab_size = opt.vocab_size
         self.detect_size = opt.detect_size
         self.rnn_size = H = opt.rnn_size
@@ -643,6 +647,10 @@ class TopDownModel(nn.Module):
         Ft = segs_feat.shape[1]
         fc = self._lin_k32(fc, self.fc_embed[0], act=1, x_padded=fc.shape[-1] != self.fc_embed[0].in_features,
                            p_drop=self._fused_drop_p())
+        if self.att_input_mode == 'region':
+            # model.py:393,406-409: no frame-wise context (the reference hands the core 1 x 1 dummies it never reads)
+            return dict(fc=fc, pool=pool, p_pool=p_pool, conv=None, p_conv=None, g_pool=g_pool, sim_mat_static=sim_mat,
+                        pnt_mask=pm, att_input_mode='region')
         # frame-wise context (model.py:393-405)
         # frame embeddings (model.py:393-395) on the MFMA GEMM, straight from the two column blocks of segs_feat
         if not self.training and not torch.is_grad_enabled():
@@ -693,7 +701,7 @@ class TopDownModel(nn.Module):
             conv = c.masked_fill(~keep.unsqueeze(-1), 0).contiguous()
         p_conv = self._lin(conv, self.ctx2att)                            # MFMA GEMM (model.py:405)
         return dict(fc=fc, pool=pool, p_pool=p_pool, conv=conv, p_conv=p_conv, g_pool=g_pool,
-                    sim_mat_static=sim_mat, pnt_mask=pm)
+                    sim_mat_static=sim_mat, pnt_mask=pm, att_input_mode=self.att_input_mode)
 
     @staticmethod
     def _dense_regions(pre):
@@ -734,7 +742,8 @@ class TopDownModel(nn.Module):
                                                    fused_step=opt.get('beam_fused_step', True))
             else:
                 seq, lps, att2 = ops.greedy_decode(pre, P, pre['pnt_mask'], self.seq_length, self.unk_idx,
-                                                    prof=getattr(self, 'kernel_timer', None), flags=self._flags())
+                                                    prof=getattr(self, 'kernel_timer', None), flags=self._flags(),
+                                                       att_input_mode=self.att_input_mode)
         if len(self._flags()) + len(self.__dict__.get('_contract_flags', ())) > 4096:   # a caller that never checks must not grow the lists without bound
             self.check_kernel_status()
         return seq, lps, att2, pre['sim_mat_static']
@@ -782,7 +791,8 @@ class TopDownModel(nn.Module):
                     if tr is not None:
                         tr['dec_start'].record(s_dec)
                     seq, lps, att2 = ops.greedy_decode(pre, P, pre['pnt_mask'], self.seq_length, self.unk_idx,
-                                                       prof=getattr(self, 'kernel_timer', None), flags=self._flags())
+                                                       prof=getattr(self, 'kernel_timer', None), flags=self._flags(),
+                                                       att_input_mode=self.att_input_mode)
                     done = torch.cuda.Event()
                     done.record(s_dec)
                     if tr is not None:

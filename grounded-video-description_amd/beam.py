@@ -49,9 +49,10 @@ def _core_rows(P, st, xt, fc_gates, pre, pmask_rows, K, att2_out):
     region = dict(feats=pre['pool'], p_feats=pre['p_pool'], q=q12[:, A:], w=P['att2_alpha_w'].view(-1),
                   alpha_bias=P['att2_alpha_b'], att_mask=pmask_rows[:, 1:], pnt_mask=pmask_rows[:, 1:],
                   logits_out=att2_out, group=K)
-    temporal = dict(feats=pre['conv'], p_feats=pre['p_conv'], q=q12[:, :A], w=P['att1_alpha_w'].view(-1),
-                    alpha_bias=P['att1_alpha_b'], group=K)
-    att_sum = ops.attention_step(region, temporal)
+    # att_input_mode (AttModel.py:140-151): 'region' has no frame-wise side, 'featmap' feeds the frame-wise context alone
+    temporal = None if pre['conv'] is None else dict(feats=pre['conv'], p_feats=pre['p_conv'], q=q12[:, :A],
+                                                     w=P['att1_alpha_w'].view(-1), alpha_bias=P['att1_alpha_b'], group=K)
+    att_sum = ops.attention_step(region, temporal, sum_region=pre.get('att_input_mode', 'both') != 'featmap')
     ops.lstm_cell([att_sum, h_att], [P['lang_w_ih'][:, :H], P['lang_w_ih'][:, H:]], st['h_lang'],
                   P['lang_w_hh'], P['lang_b_ih'], P['lang_b_hh'], st['c_lang'], h_out=nxt[2], c_out=nxt[3])
     return _state(nxt)

@@ -84,7 +84,10 @@ extern "C" size_t gvd_greedy_workspace_bytes(int B, int Ft, int R, int H, int A,
 
 extern "C" int gvd_greedy_decode(const gvd_greedy_args* a, gvd_stream_t stream) {
   if (!a || !a->workspace || !gvd_aligned16(a->workspace) || a->B <= 0 || a->L <= 0) return GVD_EINVAL;
-  const int B = a->B, H = a->H, A = a->A, E = a->E, V = a->V, R = a->R, Ft = a->Ft, L = a->L;
+  const int mode = a->att_input_mode;
+  if (mode != GVD_ATT_INPUT_BOTH && mode != GVD_ATT_INPUT_FEATMAP && mode != GVD_ATT_INPUT_REGION) return GVD_EINVAL;
+  const bool use_temporal = mode != GVD_ATT_INPUT_REGION;          // AttModel.py:140-141
+  const int B = a->B, H = a->H, A = a->A, E = a->E, V = a->V, R = a->R, Ft = use_temporal ? a->Ft : 0, L = a->L;
   hipStream_t st = gvd_s(stream);
   Ws w = carve(a->workspace, B, Ft, R, H, A, E, V);
 
@@ -114,7 +117,7 @@ extern "C" int gvd_greedy_decode(const gvd_greedy_args* a, gvd_stream_t stream) 
     g.C = w.fc_gates; g.ldc = 4 * H; g.M = B; g.N = 4 * H; g.batch = 1;
     GVD_TRY(gvd_gemm_nt_f32(&g, stream));
   }
-  const bool persistent = !a->no_persistent && gvd_pd_eligible(B, H, A, E, V, R, Ft);
+  const bool persistent = !a->no_persistent && mode == GVD_ATT_INPUT_BOTH && gvd_pd_eligible(B, H, A, E, V, R, Ft);
   if (a->pool_row_map && persistent) return GVD_EINVAL;   // persistent kernel: dense layout
   if (persistent) {
     // decode batch: the whole token loop as ONE persistent cooperative launch (decode_persistent.hip).  The event
@@ -169,7 +172,14 @@ extern "C" int gvd_greedy_decode(const gvd_greedy_args* a, gvd_stream_t stream) 
       gvd_attn_side tmp = {};
       tmp.feats = a->conv; tmp.p_feats = a->p_conv; tmp.q = w.q12; tmp.ldq = 2 * A;
       tmp.w = a->att1_alpha_w; tmp.alpha_bias = a->att1_alpha_b; tmp.N = Ft;
-      GVD_TRY(gvd_attn_fwd_prof(&reg, &tmp, B, A, H, w.att_sum, H, nullptr, nullptr, w.attn_ws, a->prof, stream));
+      // what reaches the language LSTM (AttModel.py:147-152): att + att2, att alone (the temporal context written straight
+      // into att_sum, the region side still produces its logits), or att2 alone (no temporal side in the launch)
+      if (mode == GVD_ATT_INPUT_BOTH)
+        GVD_TRY(gvd_attn_fwd_prof(&reg, &tmp, B, A, H, w.att_sum, H, nullptr, nullptr, w.attn_ws, a->prof, stream));
+      else if (mode == GVD_ATT_INPUT_FEATMAP)
+        GVD_TRY(gvd_attn_fwd_prof(&reg, &tmp, B, A, H, nullptr, 0, nullptr, w.att_sum, w.attn_ws, a->prof, stream));
+      else
+        GVD_TRY(gvd_attn_fwd_prof(&reg, nullptr, B, A, H, w.att_sum, H, nullptr, nullptr, w.attn_ws, a->prof, stream));
     }
     {  // language LSTM
       gvd_lstm_args l = {};

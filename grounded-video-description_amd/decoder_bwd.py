@@ -47,11 +47,13 @@ def _dx(K, groups, M):
 class DecoderLoopFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, att_mask, pnt_masks, keys, fc, conv, p_conv, pool, p_pool, xt_all, *params):
+        keys, mode = keys if isinstance(keys, tuple) else (keys, 'both')        # (parameter names, att_input_mode)
         P = dict(zip(keys, params))
         save = {}
         h_all, att2_w = decoder_fn.forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks,
-                                                save=save)
+                                                save=save, mode=mode)
         ctx.keys = keys
+        ctx.mode = mode
         ctx.save = save
         ctx.masks = (att_mask, pnt_masks)
         ctx.save_for_backward(fc, conv, p_conv, pool, p_pool, xt_all, *params)
@@ -67,7 +69,12 @@ class DecoderLoopFn(torch.autograd.Function):
         B, Lc, E = xt_all.shape
         H = fc.shape[1]
         A = p_pool.shape[2]
-        R, Ft = pool.shape[1], conv.shape[1]
+        # att_input_mode (AttModel.py:140-151).  'region': no frame-wise side - its scores, queries and parameters get no
+        # gradient (zeros where the reference leaves .grad = None).  'featmap': the region context is not an input of the
+        # language LSTM - the region side's d_ctx is zero (its scores still carry the grounding losses' gradient) and the
+        # region features get a gradient through the projection only
+        use_t, sum_r = ctx.mode != 'region', ctx.mode != 'featmap'
+        R, Ft = pool.shape[1], (conv.shape[1] if use_t else 0)
         dev = fc.device
         per_step_mask = pnt_masks.dim() == 3
         am = att_mask[:, 1:]
@@ -75,7 +82,7 @@ class DecoderLoopFn(torch.autograd.Function):
         a1_aw, a2_aw = P['a1_aw'].reshape(-1), P['a2_aw'].reshape(-1)
         softmax = getattr(K, 'softmax_rows', None) or (lambda x: torch.softmax(x, dim=-1))
         alpha_r = softmax(S['scores_r'])                        # [B,Lc,R]
-        alpha_t = softmax(S['scores_t'])                        # [B,Lc,Ft]
+        alpha_t = softmax(S['scores_t']) if use_t else None     # [B,Lc,Ft]
         if d_h_all is None:
             d_h_all = torch.zeros(B, Lc, H, device=dev, dtype=fc.dtype)
         dG_lang = torch.empty(Lc, B, 4 * H, device=dev, dtype=fc.dtype)
@@ -85,14 +92,15 @@ class DecoderLoopFn(torch.autograd.Function):
         de_r_all = torch.empty(Lc, B, R, device=dev, dtype=fc.dtype)
         de_t_all = torch.empty(Lc, B, Ft, device=dev, dtype=fc.dtype)
         # per-chunk partials of the alpha_net gradients of every step: reduced ONCE after the loop
-        nc_r, nc_t = K.attn_bwd_chunks(R, B), K.attn_bwd_chunks(Ft, B)
+        nc_r, nc_t = K.attn_bwd_chunks(R, B), (K.attn_bwd_chunks(Ft, B) if use_t else 1)
         dw_r_all = torch.empty(Lc, B, nc_r, A, device=dev, dtype=fc.dtype)
         dw_t_all = torch.empty(Lc, B, nc_t, A, device=dev, dtype=fc.dtype)
         dab_r_all = torch.empty(Lc, B, nc_r, device=dev, dtype=fc.dtype)
         dab_t_all = torch.empty(Lc, B, nc_t, device=dev, dtype=fc.dtype)
         # per-chunk partials of one step's two query gradients (rewritten every step; summed into dq12_all[t] by ONE launch)
         dq_r_part = torch.empty(B, nc_r, A, device=dev, dtype=fc.dtype)
-        dq_t_part = torch.empty(B, nc_t, A, device=dev, dtype=fc.dtype)
+        dq_t_part = (torch.empty if use_t else torch.zeros)(B, nc_t, A, device=dev, dtype=fc.dtype)
+        zero_ctx = None if sum_r else torch.zeros(B, H, device=dev, dtype=fc.dtype)
         dh_att_next = dh_lang_next = None
         dc_att_next = dc_lang_next = None
         w_lang_ih, w_lang_hh, w_att_hh = P['lang_w_ih'], P['lang_w_hh'], P['att_w_hh']
@@ -121,19 +129,23 @@ class DecoderLoopFn(torch.autograd.Function):
             q12 = S['q12'][t]
             region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P['a2_ab'], att_mask=am,
                           pnt_mask=pmask)
-            temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab'])
+            temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab']) if use_t else None
             dl = d_att2w[:, t] if d_att2w is not None else None
             dq12 = dq12_all[t]
-            K.attn_bwd_step(region, alpha_r[:, t], S['ctx_r'][t], d_att_sum, dl, de_out=de_r_all[t],
+            K.attn_bwd_step(region, alpha_r[:, t], S['ctx_r'][t], d_att_sum if sum_r else zero_ctx, dl, de_out=de_r_all[t],
                             dq_part=dq_r_part, dw_part=dw_r_all[t], dab_part=dab_r_all[t])
-            K.attn_bwd_step(temporal, alpha_t[:, t], S['ctx_t'][t], d_att_sum, None, de_out=de_t_all[t],
-                            dq_part=dq_t_part, dw_part=dw_t_all[t], dab_part=dab_t_all[t])
+            if use_t:
+                K.attn_bwd_step(temporal, alpha_t[:, t], (S['ctx_t'] if sum_r else S['att_sum'])[t], d_att_sum, None, de_out=de_t_all[t],
+                                dq_part=dq_t_part, dw_part=dw_t_all[t], dab_part=dab_t_all[t])
             K.sum_chunks_pair(dq_t_part, dq_r_part, dq12)        # [:, :A] temporal (a1), [:, A:] region (a2)
             _dx(K, [dict(A=dq12, W=w_stack, out=dh_att_cur, addend=dX[:, H:])], B)      # d h_att = dX[:, H:] + dq12 W_h2att
             dg_att_prev, dc_att_next = K.lstm_cell_bwd(dh_att_cur, dc_att_next, S['gates_att'][t], S['c_att'][t],
                                                        S['c_att'][t + 1], dg_out=dG_att[t], dh2=dh_att_next)
-        dw_r, dw_t = dw_r_all.sum((0, 1, 2)), dw_t_all.sum((0, 1, 2))
-        dab_r, dab_t = dab_r_all.sum().view(1), dab_t_all.sum().view(1)
+        dw_r, dab_r = dw_r_all.sum((0, 1, 2)), dab_r_all.sum().view(1)
+        if use_t:
+            dw_t, dab_t = dw_t_all.sum((0, 1, 2)), dab_t_all.sum().view(1)
+        else:
+            dw_t, dab_t = torch.zeros(A, device=dev, dtype=fc.dtype), torch.zeros(1, device=dev, dtype=fc.dtype)
         dctx_all = dX_all[:, :, :H]
 
         # ---- gradients formed once for all steps
@@ -169,15 +181,13 @@ class DecoderLoopFn(torch.autograd.Function):
         g['a1_ab'], g['a2_ab'] = dab_t, dab_r
         dctx_b = dctx_all.transpose(0, 1)                        # [B,Lc,H] view of dX_all[:, :, :H]
         ru = getattr(K, 'rank_update', None)
-        if ru is not None and Lc <= 32 and H % 128 == 0:
-            # alpha^T d_ctx over all steps: one streaming write of [B,R,H] / [B,Ft,H] (csrc/stream_mm.hip)
-            g['pool'] = ru(alpha_r, dctx_b)                      # [B,R,H]
-            g['conv'] = ru(alpha_t, dctx_b)
-        else:
-            g['pool'] = torch.bmm(alpha_r.transpose(1, 2), dctx_b)
-            g['conv'] = torch.bmm(alpha_t.transpose(1, 2), dctx_b)
+        if ru is None or Lc > 32 or H % 128 != 0:
+            ru = lambda alpha, d: torch.bmm(alpha.transpose(1, 2), d)            # noqa: E731
+        # alpha^T d_ctx over all steps: one streaming write of [B,R,H] / [B,Ft,H] (csrc/stream_mm.hip)
+        g['pool'] = ru(alpha_r, dctx_b) if sum_r else torch.zeros_like(pool)     # [B,R,H]
+        g['conv'] = ru(alpha_t, dctx_b) if use_t else None
         g['p_pool'] = K.attn_bwd_pfeats(p_pool, S['q12'][:, :, A:], de_r_all, a2_aw)
-        g['p_conv'] = K.attn_bwd_pfeats(p_conv, S['q12'][:, :, :A], de_t_all, a1_aw)
+        g['p_conv'] = K.attn_bwd_pfeats(p_conv, S['q12'][:, :, :A], de_t_all, a1_aw) if use_t else None
         ctx.save = None
         names = ['fc', 'conv', 'p_conv', 'pool', 'p_pool', 'xt_all'] + list(ctx.keys)
         out = [None, None, None]

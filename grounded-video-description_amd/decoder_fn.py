@@ -26,8 +26,11 @@ def _params(model):
         a2_aw=c.attention2.alpha_net.weight, a2_ab=c.attention2.alpha_net.bias)
 
 
-def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks, save=None):
-    """The forward recurrence.  `save` (dict) receives what the BPTT needs when given."""
+def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks, save=None, mode='both'):
+    """The forward recurrence.  `save` (dict) receives what the BPTT needs when given.  mode = att_input_mode
+    (AttModel.py:140-151): 'region' runs no frame-wise side (conv / p_conv are not read), 'featmap' feeds the frame-wise
+    context alone to the language LSTM (the region side still runs for the grounding logits)."""
+    use_t, sum_r = mode != 'region', mode != 'featmap'
     B, Lc, E = xt_all.shape
     H = fc.shape[1]
     A = p_pool.shape[2]
@@ -52,7 +55,8 @@ def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks,
                     h_att=torch.empty(Lc + 1, B, H, device=dev, dtype=fc.dtype), h_lang=torch.empty(Lc + 1, B, H, device=dev, dtype=fc.dtype),
                     q12=torch.empty(Lc, B, 2 * A, device=dev, dtype=fc.dtype), att_sum=torch.empty(Lc, B, H, device=dev, dtype=fc.dtype),
                     ctx_r=torch.empty(Lc, B, H, device=dev, dtype=fc.dtype), ctx_t=torch.empty(Lc, B, H, device=dev, dtype=fc.dtype),
-                    scores_r=torch.empty(B, Lc, R, device=dev, dtype=fc.dtype), scores_t=torch.empty(B, Lc, conv.shape[1], device=dev, dtype=fc.dtype),
+                    scores_r=torch.empty(B, Lc, R, device=dev, dtype=fc.dtype),
+                    scores_t=torch.empty(B, Lc, conv.shape[1] if use_t else 0, device=dev, dtype=fc.dtype),
                     w_stack=w_stack)
         for k in ('c_att', 'c_lang', 'h_att', 'h_lang'):
             save[k][0].zero_()
@@ -67,9 +71,10 @@ def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks,
             region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P['a2_ab'], att_mask=am,
                           pnt_mask=pmask, logits_out=att2_w[:, t], scores_out=save['scores_r'][:, t])
             temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab'],
-                            scores_out=save['scores_t'][:, t])
+                            scores_out=save['scores_t'][:, t]) if use_t else None
             att_sum, _, _ = K.attention_step(region, temporal, want_separate=True, out=save['att_sum'][t],
-                                             cr_out=save['ctx_r'][t], ct_out=save['ctx_t'][t])
+                                             cr_out=save['ctx_r'][t], ct_out=save['ctx_t'][t] if (use_t and sum_r) else None,
+                                             sum_region=sum_r)          # ('featmap': att_sum[t] IS the temporal context)
             K.lstm_cell([att_sum, h_att], [w_ih_att, w_ih_h], save['h_lang'][t], P['lang_w_hh'], P['lang_b_ih'],
                         P['lang_b_hh'], save['c_lang'][t], gates_out=save['gates_lang'][t],
                         h_out=save['h_lang'][t + 1], c_out=save['c_lang'][t + 1])
@@ -82,8 +87,8 @@ def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks,
         pmask = (pnt_masks[:, t] if per_step_mask else pnt_masks)[:, 1:]
         region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P['a2_ab'], att_mask=am,
                       pnt_mask=pmask, logits_out=att2_w[:, t])
-        temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab'])
-        att_sum = K.attention_step(region, temporal)
+        temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab']) if use_t else None
+        att_sum = K.attention_step(region, temporal, sum_region=sum_r)
         h_lang, c_lang = K.lstm_cell([att_sum, h_att], [w_ih_att, w_ih_h], h_lang, P['lang_w_hh'],
                                      P['lang_b_ih'], P['lang_b_hh'], c_lang, h_out=h_all[:, t])
     return h_all, att2_w
@@ -91,12 +96,17 @@ def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks,
 
 def decoder_loop(model, pre, xt_all, att_mask, pnt_masks):
     P = _params(model)
-    tensors = [pre['fc'], pre['conv'], pre['p_conv'], pre['pool'], pre['p_pool'], xt_all] + list(P.values())
+    mode = getattr(model, 'att_input_mode', 'both')
+    conv, p_conv = pre['conv'], pre['p_conv']
+    if mode == 'region':
+        # no frame-wise side: one-element stand-ins keep the autograd.Function's argument list (nothing reads them)
+        conv = p_conv = pre['fc'].new_zeros(1)
+    tensors = [pre['fc'], conv, p_conv, pre['pool'], pre['p_pool'], xt_all] + list(P.values())
     if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
         from .decoder_bwd import DecoderLoopFn
         keys = list(P.keys())
-        return DecoderLoopFn.apply(att_mask, pnt_masks, keys, pre['fc'], pre['conv'], pre['p_conv'], pre['pool'],
+        return DecoderLoopFn.apply(att_mask, pnt_masks, (keys, mode), pre['fc'], conv, p_conv, pre['pool'],
                                    pre['p_pool'], xt_all.contiguous(), *[P[k] for k in keys])
     Pd = {k: v.detach() for k, v in P.items()}
-    return forward_loop(Pd, pre['fc'].detach(), pre['conv'].detach(), pre['p_conv'].detach(), pre['pool'].detach(),
-                        pre['p_pool'].detach(), xt_all.detach().contiguous(), att_mask, pnt_masks)
+    return forward_loop(Pd, pre['fc'].detach(), conv.detach(), p_conv.detach(), pre['pool'].detach(),
+                        pre['p_pool'].detach(), xt_all.detach().contiguous(), att_mask, pnt_masks, mode=mode)

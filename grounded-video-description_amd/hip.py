@@ -73,7 +73,7 @@ class GreedyArgs(C.Structure):
                 ('B', C.c_int), ('Ft', C.c_int), ('R', C.c_int), ('H', C.c_int), ('A', C.c_int), ('E', C.c_int),
                 ('V', C.c_int), ('L', C.c_int), ('unk_idx', C.c_int), ('no_persistent', C.c_int),
                 ('seq', c_i64p), ('seq_logprobs', c_f32p), ('att2_weights', c_f32p), ('workspace', C.c_void_p),
-                ('prof', C.c_void_p), ('status', C.c_void_p), ('trace', C.c_void_p)]
+                ('prof', C.c_void_p), ('status', C.c_void_p), ('trace', C.c_void_p), ('att_input_mode', C.c_int)]
 
 
 class BeamStepArgs(C.Structure):
@@ -228,7 +228,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 17        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 18        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

@@ -325,12 +325,14 @@ def set_kernel_timer(timer):
     _kernel_timer = timer
 
 
-def attention_step(region, temporal, want_separate=False, out=None, cr_out=None, ct_out=None):
+def attention_step(region, temporal, want_separate=False, out=None, cr_out=None, ct_out=None, sum_region=True):
     """Both additive attentions of one decoder step (AttModel.py:33-53,71-108) in one streaming pass.
 
     region / temporal: dicts(feats, p_feats, q, w, alpha_bias[, att_mask, pnt_mask, logits_out]).
     Returns att+att2 [B,H] (and the two contexts when want_separate); `out` ([B,H], unit inner stride) and the contiguous
-    `cr_out` / `ct_out` receive them in place when given."""
+    `cr_out` / `ct_out` receive them in place when given.  att_input_mode (AttModel.py:140-151): temporal = None is
+    'region' (out = att2); sum_region = False is 'featmap' (out = att, the frame-wise context alone - the region side still
+    runs for its logits / scores and, with want_separate, its context)."""
     f = region['feats']
     B = region['q'].shape[0]                      # rows (= feats.shape[0] * group)
     if region.get('row_map') is not None:
@@ -353,6 +355,14 @@ def attention_step(region, temporal, want_separate=False, out=None, cr_out=None,
             ct = torch.empty(B, H, device=f.device, dtype=torch.float32) if ct_out is None else ct_out
     assert out.stride(-1) == 1 and out.shape == (B, H) and all(t is None or t.is_contiguous() for t in (cr, ct))
     prof = _kernel_timer.h if _kernel_timer is not None else None
+    if not sum_region:
+        # 'featmap': the kernel writes the temporal context where the sum would go (its per-side outputs are contiguous rows)
+        assert st is not None and out.is_contiguous()
+        check(lib().gvd_attn_fwd_prof(C.byref(sr), C.byref(st), B, A, H, None, 0, ptr(cr), ptr(out), ptr(ws), prof,
+                                      stream_ptr()), 'gvd_attn_fwd')
+        if ct is not None and ct.data_ptr() != out.data_ptr():
+            ct.copy_(out)
+        return (out, cr, out if ct is None else ct) if want_separate else out
     check(lib().gvd_attn_fwd_prof(C.byref(sr), C.byref(st) if st is not None else None, B, A, H, ptr(out), out.stride(0),
                                   ptr(cr), ptr(ct), ptr(ws), prof, stream_ptr()), 'gvd_attn_fwd')
     return (out, cr, ct) if want_separate else out
@@ -380,13 +390,18 @@ def logsoftmax_rows(logits, target=None, topk=0):
     return lse, picked, tv, ti
 
 
-def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None, flags=None):
+ATT_INPUT_MODES = {'both': 0, 'featmap': 1, 'region': 2}          # GVD_ATT_INPUT_* (include/gvd_hip.h)
+
+
+def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None, flags=None, att_input_mode='both'):
     """Whole greedy token loop (AttModel._sample, model.py:580-624) in one C call.
     pre: dict(fc, conv, p_conv, pool, p_pool) from the preamble; P: dict of parameter tensors.
     `flags`: list that receives the launch's device status word (non-zero after a sync = the persistent kernel's grid
     barrier timed out and the ids are poisoned); the caller must check it before trusting the result
     (TopDownModel.check_kernel_status)."""
-    fc, conv, p_conv = (pre[k].contiguous() for k in ('fc', 'conv', 'p_conv'))
+    fc = pre['fc'].contiguous()
+    # att_input_mode='region' (AttModel.py:140-141,151-152): no frame-wise attention, the preamble holds no conv / p_conv
+    conv, p_conv = (None, None) if att_input_mode == 'region' else (pre['conv'].contiguous(), pre['p_conv'].contiguous())
     B, H = fc.shape
     row_map = None
     if pre.get('pool') is None:
@@ -398,8 +413,8 @@ def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None, flags=None):
             pool, p_pool = pre['ci'].expand(pre['pool_c']), pre['ci'].expand(pre['p_pool_c'])
     else:
         pool, p_pool = pre['pool'].contiguous(), pre['p_pool'].contiguous()
-    require_cuda_f32(fc, conv, p_conv, pool, p_pool)
-    Ft, R, A = conv.shape[1], pnt_mask.shape[1] - 1, p_pool.shape[-1]
+    require_cuda_f32(fc, pool, p_pool, *([] if conv is None else [conv, p_conv]))
+    Ft, R, A = (0 if conv is None else conv.shape[1]), pnt_mask.shape[1] - 1, p_pool.shape[-1]
     V, E = P['embed'].shape
     dev = fc.device
     seq = torch.empty(B, L, dtype=torch.int64, device=dev)
@@ -422,6 +437,7 @@ def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None, flags=None):
     a.seq, a.seq_logprobs, a.att2_weights, a.workspace = ptr(seq), ptr(lps), ptr(att2), ptr(ws)
     a.prof = prof.h if prof is not None else None
     a.no_persistent = 0 if _persistent['on'] else 1
+    a.att_input_mode = ATT_INPUT_MODES[att_input_mode]
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     a.status = ptr(status)
     trace = None

@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 17
+#define GVD_ABI_VERSION 18
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -432,7 +432,15 @@ typedef struct {
                           kernel timed out (token ids are then all -1) */
   uint64_t* trace;     /* optional device buffer of 1 + 7*L words: 100 MHz wall-clock stamps of workgroup 0 at every
                           phase boundary of the persistent decode-batch kernel (profiling aid) */
+  int att_input_mode;  /* opts.py:58 `--att_input_mode` (AttModel.py:140-151): what the language LSTM is fed -
+                          GVD_ATT_INPUT_BOTH (0) att + att2; GVD_ATT_INPUT_FEATMAP (1) the frame-wise context alone (the
+                          region attention still runs: its logits are the grounding output); GVD_ATT_INPUT_REGION (2) the
+                          region context alone - conv / p_conv are not read (may be NULL, Ft is ignored).  Non-zero modes
+                          always run the kernel-per-op loop */
 } gvd_greedy_args;
+#define GVD_ATT_INPUT_BOTH 0
+#define GVD_ATT_INPUT_FEATMAP 1
+#define GVD_ATT_INPUT_REGION 2
 
 size_t gvd_greedy_workspace_bytes(int B, int Ft, int R, int H, int A, int E, int V);
 int gvd_greedy_decode(const gvd_greedy_args* args, gvd_stream_t stream);

@@ -74,6 +74,19 @@ CASES = {
     # profiles/r05/reference_grad_noise.txt)
     'mle_b4_v1000_ft10_tnone': dict(mode='MLE', B=4, V=1000, Ft=10, seed=25, profile='trained_like',
                                     opt=dict(transfer_mode='none')),
+    # att_input_mode (opts.py:58; AttModel.py:140-151): what the language LSTM is fed - 'featmap' the frame-wise context
+    # alone (the region attention still produces the grounding logits), 'region' the region context alone (no frame-wise
+    # encoder / attention at all, model.py:393,406-409)
+    'greedy_b4_v1000_ft10_featmap': dict(mode='sample', B=4, V=1000, Ft=10, seed=26, profile='trained_like',
+                                         opt=dict(att_input_mode='featmap')),
+    'mle_b4_v1000_ft10_featmap': dict(mode='MLE', B=4, V=1000, Ft=10, seed=27, profile='trained_like',
+                                      opt=dict(att_input_mode='featmap')),
+    'greedy_b8_v1000_ft10_region': dict(mode='sample', B=8, V=1000, Ft=10, seed=28, profile='trained_like',
+                                        opt=dict(att_input_mode='region')),
+    'mle_b4_v1000_ft10_region': dict(mode='MLE', B=4, V=1000, Ft=10, seed=29, profile='trained_like',
+                                     opt=dict(att_input_mode='region')),
+    'beam3_b4_v1000_ft10_region': dict(mode='beam', B=4, V=1000, Ft=10, K=3, seed=30, profile='trained_like',
+                                       opt=dict(att_input_mode='region')),
     'grd_b4_v1000_ft10_l40': dict(mode='GRD', B=4, V=1000, Ft=10, seed=18, profile='trained_like',
                                   opt=dict(seq_length=40)),
     # BASELINE configs[4]'s region count under GREEDY decode: 20 sampled frames x 100 proposals = 2000 regions (the beam

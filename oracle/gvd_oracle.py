@@ -243,6 +243,12 @@ def preamble(W, opt, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, fast
     if opt.obj_interact:
         pool = obj_interact(pool, W, key_bias=enc_key_bias)           # model.py:387-388
     p_pool = linear(pool, W, 'ctx2pool')                              # model.py:391
+    out['att_input_mode'] = getattr(opt, 'att_input_mode', 'both')
+    out['region_attn_mode'] = getattr(opt, 'region_attn_mode', 'mix')
+    if out['att_input_mode'] == 'region':
+        # model.py:406-409: no frame-wise context at all (the reference passes 1 x 1 dummies the core never reads)
+        out.update(fc=fc, pool=pool, p_pool=p_pool, conv=None, p_conv=None)
+        return out
     # frame-wise context (model.py:393-405)
     c = torch.cat([F.relu(linear(segs_feat[:, :, :2048], W, 'att_embed.0.0')),
                    F.relu(linear(segs_feat[:, :, 2048:], W, 'att_embed.1.0'))], dim=2)
@@ -278,11 +284,16 @@ def attention_temporal(h, conv, p_conv, W):
     return torch.bmm(w.unsqueeze(1), conv).squeeze(1)
 
 
-def attention_region(h, pool, p_pool, att_mask, pnt_mask, W):
-    """AttModel.py:71-108 ('mix' -> additive): returns (context, masked pre-softmax logits, q)."""
+def attention_region(h, pool, p_pool, att_mask, pnt_mask, W, mode='mix'):
+    """AttModel.py:71-108: returns (context, masked pre-softmax logits, q).  region_attn_mode 'mix' -> additive score
+    alpha_net(tanh(p + q)) (AttModel.py:84-91), 'mix_mul' -> alpha_net(tanh(p * q)) (AttModel.py:82-83), 'dp' -> the plain
+    dot product p . q, no alpha_net in the module (AttModel.py:92-95)."""
     q = linear(h, W, 'core.attention2.h2att')
-    dot = torch.tanh(p_pool + q.unsqueeze(1))
-    e = linear(dot, W, 'core.attention2.alpha_net').squeeze(-1)
+    if mode == 'dp':
+        e = torch.matmul(p_pool, q.unsqueeze(-1)).squeeze(-1)
+    else:
+        dot = torch.tanh(p_pool * q.unsqueeze(1) if mode == 'mix_mul' else p_pool + q.unsqueeze(1))
+        e = linear(dot, W, 'core.attention2.alpha_net').squeeze(-1)
     e = e.masked_fill(att_mask.bool(), MIN_VALUE)
     w = F.softmax(e, dim=1)
     logits = e.masked_fill(pnt_mask.bool(), MIN_VALUE)
@@ -291,13 +302,17 @@ def attention_region(h, pool, p_pool, att_mask, pnt_mask, W):
 
 
 def core_step(W, xt, pre, att_mask, pnt_mask, state):
-    """TopDownCore.forward, att_input_mode='both' (AttModel.py:134-164). state = (h[2,B,H], c[2,B,H])."""
+    """TopDownCore.forward (AttModel.py:134-164). state = (h[2,B,H], c[2,B,H]).  att_input_mode (AttModel.py:140-151):
+    'both' feeds att + att2 to the language LSTM, 'featmap' the frame-wise context alone (the region attention still runs:
+    its logits are the grounding output), 'region' the region context alone (no frame-wise attention)."""
     h, c = state
+    mode = pre.get('att_input_mode', 'both')
     h_att, c_att = lstm_cell(torch.cat([pre['fc'], xt], 1), h[0], c[0], W, 'core.att_lstm')
-    att = attention_temporal(h_att, pre['conv'], pre['p_conv'], W)
+    att = attention_temporal(h_att, pre['conv'], pre['p_conv'], W) if mode != 'region' else None
     att2, att2_logits, att_h = attention_region(h_att, pre['pool'], pre['p_pool'],
-                                                att_mask[:, 1:], pnt_mask[:, 1:], W)
-    h_lang, c_lang = lstm_cell(torch.cat([att + att2, h_att], 1), h[1], c[1], W, 'core.lang_lstm')
+                                                att_mask[:, 1:], pnt_mask[:, 1:], W, pre.get('region_attn_mode', 'mix'))
+    ctx = att + att2 if mode == 'both' else (att if mode == 'featmap' else att2)
+    h_lang, c_lang = lstm_cell(torch.cat([ctx, h_att], 1), h[1], c[1], W, 'core.lang_lstm')
     return h_lang, (torch.stack([h_att, h_lang]), torch.stack([c_att, c_lang])), att2_logits, att_h
 
 
@@ -450,8 +465,9 @@ def sample_beam(W, opt, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, b
     lp_out = torch.zeros(L, B)
     att2_out = torch.full((L, B), -1, dtype=torch.long)
     for k in range(B):
-        pk = {n: pre[n][k:k + 1].expand(K, *pre[n].shape[1:]).contiguous()
+        pk = {n: (None if pre[n] is None else pre[n][k:k + 1].expand(K, *pre[n].shape[1:]).contiguous())
               for n in ('fc', 'pool', 'p_pool', 'conv', 'p_conv')}
+        pk.update(att_input_mode=pre.get('att_input_mode', 'both'), region_attn_mode=pre.get('region_attn_mode', 'mix'))
         pmk = pnt_mask[k:k + 1].expand(K, pnt_mask.shape[1]).contiguous()
         state = (torch.zeros(2, K, H), torch.zeros(2, K, H))
         rnn_out, state, a2, _ = core_step(W, embed_word(W, torch.zeros(K, dtype=torch.long)), pk, pmk, pmk, state)

@@ -79,3 +79,48 @@ def test_bptt_matches_autograd_through_oracle(fake_kernels, per_step):
     assert torch.allclose(xm.grad, xr.grad, rtol=1e-8, atol=1e-10)
     for k, p in zip(keys, Pm):
         assert torch.allclose(p.grad, Wr[KEYMAP[k]].grad, rtol=1e-8, atol=1e-10), k
+
+
+@pytest.mark.parametrize('mode', ['featmap', 'region'])
+def test_bptt_att_input_modes_match_autograd_through_oracle(fake_kernels, mode):
+    """att_input_mode (opts.py:58, AttModel.py:140-151): 'featmap' feeds the frame-wise context alone to the language LSTM
+    (the region attention still produces the grounding logits, so the region side gets a gradient through its scores only),
+    'region' has no frame-wise side at all (its parameters: zero gradient here, None in autograd)."""
+    W, pre, xt_all, att_mask, pnt_masks, Gh, Ga = _problem(5, per_step=True)
+    B, Lc = xt_all.shape[:2]
+    H = pre['fc'].shape[1]
+    Wr = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    prer = {k: v.clone().requires_grad_(True) for k, v in pre.items()}
+    xr = xt_all.clone().requires_grad_(True)
+    state = (torch.zeros(2, B, H, dtype=torch.float64), torch.zeros(2, B, H, dtype=torch.float64))
+    outs, atts = [], []
+    for t in range(Lc):
+        out, state, a2, _ = O.core_step(Wr, xr[:, t], dict(prer, att_input_mode=mode), att_mask, pnt_masks[:, t], state)
+        outs.append(out); atts.append(a2)
+    h_ref, a_ref = torch.stack(outs, 1), torch.stack(atts, 1)
+    ((h_ref * Gh).sum() + (a_ref * Ga).sum()).backward()
+    keys = list(KEYMAP)
+    Pm = [W[KEYMAP[k]].clone().requires_grad_(True) for k in keys]
+    prem = {k: v.clone().requires_grad_(True) for k, v in pre.items()}
+    xm = xt_all.clone().requires_grad_(True)
+    conv, p_conv = (prem['conv'], prem['p_conv']) if mode != 'region' else (torch.zeros(1, dtype=torch.float64),) * 2
+    h, a = decoder_bwd.DecoderLoopFn.apply(att_mask, pnt_masks, (keys, mode), prem['fc'], conv, p_conv,
+                                           prem['pool'], prem['p_pool'], xm, *Pm)
+    assert torch.allclose(h, h_ref, atol=1e-10) and torch.allclose(a, a_ref, atol=1e-6)
+    ((h * Gh).sum() + (a * Ga).sum()).backward()
+    zero = lambda g: g is None or float(g.abs().max()) == 0.0
+    for k in pre:
+        if mode == 'region' and k in ('conv', 'p_conv'):
+            assert prem[k].grad is None and prer[k].grad is None
+            continue
+        if prer[k].grad is None:                           # the region features under 'featmap': context unused
+            assert mode == 'featmap' and k == 'pool' and zero(prem[k].grad)
+            continue
+        assert torch.allclose(prem[k].grad, prer[k].grad, rtol=1e-8, atol=1e-10), k
+    assert torch.allclose(xm.grad, xr.grad, rtol=1e-8, atol=1e-10)
+    for k, p in zip(keys, Pm):
+        want = Wr[KEYMAP[k]].grad
+        if want is None:                                    # the frame-wise attention's parameters under 'region'
+            assert mode == 'region' and k.startswith('a1_') and zero(p.grad), k
+        else:
+            assert torch.allclose(p.grad, want, rtol=1e-8, atol=1e-10), k

@@ -144,6 +144,12 @@ def test_mle_gradients_match_reference(name, golden_dir):
     _check_projections({n: params[n].grad for n in names}, names, g['grad_norms'], g['grad_proj'])
     for n in ('core.i2h_2.weight', 'core.h2h_2.weight'):
         assert params[n].grad is None or float(params[n].grad.abs().sum()) == 0.0
+    if 'att_input_mode' in spec.get('opt', {}):
+        # parameters the reference's backward leaves without a gradient under this mode (the frame-wise encoder + attention
+        # under 'region'): None or exactly zero here
+        for n, p in params.items():
+            if n not in ref:
+                assert p.grad is None or float(p.grad.abs().sum()) == 0.0, n
     print('worst relative grad-norm error', worst)
 
 

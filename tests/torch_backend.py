@@ -51,10 +51,10 @@ def _one_side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, lo
     return torch.bmm(a.unsqueeze(1), feats).squeeze(1)
 
 
-def attention_step(region, temporal, want_separate=False, out=None, cr_out=None, ct_out=None):
+def attention_step(region, temporal, want_separate=False, out=None, cr_out=None, ct_out=None, sum_region=True):
     cr = _one_side(**region)
     ct = _one_side(**temporal) if temporal is not None else torch.zeros_like(cr)
-    s = cr + ct
+    s = cr + ct if sum_region else ct.clone()
     if out is not None:
         s = out.copy_(s)
     if cr_out is not None:

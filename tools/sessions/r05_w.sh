@@ -1,0 +1,5 @@
+#!/bin/bash
+# att_input_mode featmap / region: the new reference goldens through the HIP path
+set -u
+R=$PWD; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -x -q -k "featmap or region or tnone" 2>&1 | tail -25 | tee $O/r05w_modes.txt

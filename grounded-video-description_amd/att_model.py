@@ -19,7 +19,9 @@ remain for BatchNorm1d, the three few-MB dropout sites (token / visual-word embe
 path: inputs must live on the GPU.
 
 Supported configuration = the reference's README recipe (att_model='topdown', att_input_mode='both',
-region_attn_mode='mix', transfer_mode='cls', t_attn_mode='bigru', seq_per_img=1, enable_BUTD=False).
+region_attn_mode='mix', transfer_mode='cls', t_attn_mode='bigru', seq_per_img=1, enable_BUTD=False) and the other option
+values the reference itself can run: att_input_mode 'featmap' / 'region', region_attn_mode 'mix_mul' /
+'dp', transfer_mode 'none' - all but t_attn_mode='bilstm'.
 """
 import math
 import os
@@ -83,10 +85,11 @@ def _build_obj_interact(d_model, d_hidden, n_layers, drop_ratio=0.2):
 
 
 class _AttParams(nn.Module):
-    def __init__(self, H, A):
+    def __init__(self, H, A, alpha_net=True):
         super().__init__()
         self.h2att = nn.Linear(H, A)
-        self.alpha_net = nn.Linear(A, 1)
+        if alpha_net:                     # (Attention2 with region_attn_mode='dp' has none: AttModel.py:63-66)
+            self.alpha_net = nn.Linear(A, 1)
 
 
 class _Core(nn.Module):
@@ -98,7 +101,7 @@ class _Core(nn.Module):
         self.att_lstm = nn.LSTMCell(E + H, H)
         self.lang_lstm = nn.LSTMCell(2 * H, H)
         self.attention = _AttParams(H, A)
-        self.attention2 = _AttParams(H, A)
+        self.attention2 = _AttParams(H, A, alpha_net=opt.region_attn_mode != 'dp')
         self.i2h_2 = nn.Linear(2 * H, H)   # unused in the reference too (AttModel.py:130-131)
         self.h2h_2 = nn.Linear(H, H)
 
@@ -107,13 +110,13 @@ class TopDownModel(nn.Module):
     def __init__(self, opt):
         super().__init__()
         for k, want in (('att_model', ('topdown',)), ('att_input_mode', ('both', 'featmap', 'region')),
-                        ('region_attn_mode', ('mix',)),
+                        ('region_attn_mode', ('mix', 'mix_mul', 'dp')),
                         ('transfer_mode', ('cls', 'none')), ('t_attn_mode', ('bigru',)), ('seq_per_img', (1,)),
                         ('enable_BUTD', (False,))):
             if getattr(opt, k) not in want:
                 # (profiles/r05/reference_option_survey.json: which other values the REFERENCE itself can run at its README
                 # dimensions - region_attn_mode add / cat, att_input_mode dual_region, transfer_mode glove / both raise inside
-                # misc/model.py / misc/AttModel.py; mix_mul, dp, bilstm run there and are not built here)
+                # misc/model.py / misc/AttModel.py; bilstm runs there and is not built here)
                 raise NotImplementedError('%s=%r: the HIP path is built for %s (the reference README recipe is the first)'
                                           % (k, getattr(opt, k), ' / '.join(repr(w) for w in want)))
         self.transfer_mode = opt.transfer_mode
@@ -121,6 +124,9 @@ class TopDownModel(nn.Module):
         # context alone (the region attention still runs: its logits are the grounding output), 'region' the region context
         # alone - no frame-wise encoder / attention at all (model.py:393,406-409).  Same parameters in all three.
         self.att_input_mode = opt.att_input_mode
+        # score function of the region attention (opts.py:63, AttModel.py:82-95): 'mix' w . tanh(p + q) (README), 'mix_mul'
+        # w . tanh(p * q), 'dp' p . q (no alpha_net in the module, none in the state_dict)
+        self.region_attn_mode = opt.region_attn_mode
         self.vocab_size = opt.vocab_size
         self.detect_size = opt.detect_size
         self.rnn_size = H = opt.rnn_size
@@ -650,7 +656,7 @@ class TopDownModel(nn.Module):
         if self.att_input_mode == 'region':
             # model.py:393,406-409: no frame-wise context (the reference hands the core 1 x 1 dummies it never reads)
             return dict(fc=fc, pool=pool, p_pool=p_pool, conv=None, p_conv=None, g_pool=g_pool, sim_mat_static=sim_mat,
-                        pnt_mask=pm, att_input_mode='region')
+                        pnt_mask=pm, att_input_mode='region', region_attn_mode=self.region_attn_mode)
         # frame-wise context (model.py:393-405)
         # frame embeddings (model.py:393-395) on the MFMA GEMM, straight from the two column blocks of segs_feat
         if not self.training and not torch.is_grad_enabled():
@@ -701,7 +707,8 @@ class TopDownModel(nn.Module):
             conv = c.masked_fill(~keep.unsqueeze(-1), 0).contiguous()
         p_conv = self._lin(conv, self.ctx2att)                            # MFMA GEMM (model.py:405)
         return dict(fc=fc, pool=pool, p_pool=p_pool, conv=conv, p_conv=p_conv, g_pool=g_pool,
-                    sim_mat_static=sim_mat, pnt_mask=pm, att_input_mode=self.att_input_mode)
+                    sim_mat_static=sim_mat, pnt_mask=pm, att_input_mode=self.att_input_mode,
+                    region_attn_mode=self.region_attn_mode)
 
     @staticmethod
     def _dense_regions(pre):
@@ -722,8 +729,9 @@ class TopDownModel(nn.Module):
             att1_h2att_w=c.attention.h2att.weight, att1_h2att_b=c.attention.h2att.bias,
             att1_alpha_w=c.attention.alpha_net.weight, att1_alpha_b=c.attention.alpha_net.bias,
             att2_h2att_w=c.attention2.h2att.weight, att2_h2att_b=c.attention2.h2att.bias,
-            att2_alpha_w=c.attention2.alpha_net.weight, att2_alpha_b=c.attention2.alpha_net.bias,
-            logit_w=self.logit.weight, logit_b=self.logit.bias)
+            logit_w=self.logit.weight, logit_b=self.logit.bias,
+            **({} if self.region_attn_mode == 'dp' else
+               dict(att2_alpha_w=c.attention2.alpha_net.weight, att2_alpha_b=c.attention2.alpha_net.bias)))
 
     # ------------------------------------------------------------------ 'sample' (model.py:492-624)
     def _sample(self, segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, opt={}):
@@ -743,7 +751,7 @@ class TopDownModel(nn.Module):
             else:
                 seq, lps, att2 = ops.greedy_decode(pre, P, pre['pnt_mask'], self.seq_length, self.unk_idx,
                                                     prof=getattr(self, 'kernel_timer', None), flags=self._flags(),
-                                                       att_input_mode=self.att_input_mode)
+                                                       att_input_mode=self.att_input_mode, region_attn_mode=self.region_attn_mode)
         if len(self._flags()) + len(self.__dict__.get('_contract_flags', ())) > 4096:   # a caller that never checks must not grow the lists without bound
             self.check_kernel_status()
         return seq, lps, att2, pre['sim_mat_static']
@@ -792,7 +800,7 @@ class TopDownModel(nn.Module):
                         tr['dec_start'].record(s_dec)
                     seq, lps, att2 = ops.greedy_decode(pre, P, pre['pnt_mask'], self.seq_length, self.unk_idx,
                                                        prof=getattr(self, 'kernel_timer', None), flags=self._flags(),
-                                                       att_input_mode=self.att_input_mode)
+                                                       att_input_mode=self.att_input_mode, region_attn_mode=self.region_attn_mode)
                     done = torch.cuda.Event()
                     done.record(s_dec)
                     if tr is not None:

@@ -46,9 +46,10 @@ def _core_rows(P, st, xt, fc_gates, pre, pmask_rows, K, att2_out):
     h_att, c_att = ops.lstm_cell([xt], [P['att_w_ih'][:, H:]], st['h_att'], P['att_w_hh'], None, None, st['c_att'],
                                  rowbias=fc_gates, h_out=nxt[0], c_out=nxt[1])
     q12 = ops.gemm_nt(h_att, P['w_stack'], P['b_stack'])
-    region = dict(feats=pre['pool'], p_feats=pre['p_pool'], q=q12[:, A:], w=P['att2_alpha_w'].view(-1),
-                  alpha_bias=P['att2_alpha_b'], att_mask=pmask_rows[:, 1:], pnt_mask=pmask_rows[:, 1:],
-                  logits_out=att2_out, group=K)
+    sm = ops.SCORE_MODES[pre.get('region_attn_mode', 'mix')]           # AttModel.py:82-95; 'dp' has no alpha_net
+    region = dict(feats=pre['pool'], p_feats=pre['p_pool'], q=q12[:, A:], w=P['att2_alpha_w'].view(-1) if sm != 2 else None,
+                  alpha_bias=P.get('att2_alpha_b'), att_mask=pmask_rows[:, 1:], pnt_mask=pmask_rows[:, 1:],
+                  logits_out=att2_out, group=K, score_mode=sm)
     # att_input_mode (AttModel.py:140-151): 'region' has no frame-wise side, 'featmap' feeds the frame-wise context alone
     temporal = None if pre['conv'] is None else dict(feats=pre['conv'], p_feats=pre['p_conv'], q=q12[:, :A],
                                                      w=P['att1_alpha_w'].view(-1), alpha_bias=P['att1_alpha_b'], group=K)

@@ -57,7 +57,22 @@ __device__ __forceinline__ T ld_stream(const T* ptr) {
   else return *ptr;
 }
 
-template <bool NT>
+// the region side's score function (gvd_attn_side.score_mode); the temporal side of the same launch is always additive.
+// MODE = GVD_SCORE_ADD compiles to attn_score_lane alone: the README configuration's kernels are unchanged.
+template <int MODE>
+__device__ __forceinline__ float score_sel(bool addm, f32x4 x0, f32x4 x1, f32x4 q0, f32x4 q1, const AttnLaneW& W) {
+  if constexpr (MODE == GVD_SCORE_ADD) return attn_score_lane(x0, x1, q0, q1, W);
+  else return addm ? attn_score_lane(x0, x1, q0, q1, W) : attn_score_lane_m<MODE>(x0, x1, q0, q1, W);
+}
+template <int MODE>
+__device__ __forceinline__ AttnLaneW lane_w_sel(bool addm, const float* w, int lane) {
+  if constexpr (MODE == GVD_SCORE_DOT) {
+    if (!addm) { AttnLaneW o; o.wn0 = f32x4{0.f, 0.f, 0.f, 0.f}; o.wn1 = o.wn0; o.wsum = 0.f; return o; }
+  }
+  return attn_lane_w(w, lane);
+}
+
+template <bool NT, int MODE>
 __global__ __launch_bounds__(256, 8) void attn_partial_kernel(const FwdParams p) {   // 8 waves / SIMD (<= 64 VGPRs, no spill)
   __shared__ float s_score[MAX_CHUNK];
   __shared__ float s_red[8];
@@ -76,10 +91,12 @@ __global__ __launch_bounds__(256, 8) void attn_partial_kernel(const FwdParams p)
 
   // ---- phase 1: scores.  lane owns columns [4*lane, 4*lane+4) and [256+4*lane, ...+4) of A = 512
   const float* qb = S.q + (int64_t)b * S.ldq;
-  const f32x4 q0 = GVD_TWO_LOG2E * *reinterpret_cast<const f32x4*>(qb + 4 * lane);         // pre-scaled: see tanh_fast
-  const f32x4 q1 = GVD_TWO_LOG2E * *reinterpret_cast<const f32x4*>(qb + 256 + 4 * lane);
-  const AttnLaneW W = attn_lane_w(S.w, lane);
-  const float ab = *S.alpha_bias;
+  const bool addm = MODE == GVD_SCORE_ADD || sidx == 1;      // (compile-time true for the README configuration)
+  const float qscale = (MODE == GVD_SCORE_DOT && !addm) ? 1.0f : GVD_TWO_LOG2E;
+  const f32x4 q0 = qscale * *reinterpret_cast<const f32x4*>(qb + 4 * lane);         // pre-scaled: see tanh_fast
+  const f32x4 q1 = qscale * *reinterpret_cast<const f32x4*>(qb + 256 + 4 * lane);
+  const AttnLaneW W = lane_w_sel<MODE>(addm, S.w, lane);
+  const float ab = (MODE == GVD_SCORE_DOT && !addm) ? 0.f : *S.alpha_bias;
   const int fbi = S.group > 1 ? b / S.group : b;   // beams of one sample share its features
   // compacted features (masked-proposal compaction, csrc/compact.hip): the side's rows are looked up through row_map in
   // the flat [rows, .] arrays - the dense [B,N,.] copies are never materialised
@@ -121,8 +138,8 @@ __global__ __launch_bounds__(256, 8) void attn_partial_kernel(const FwdParams p)
     f32x4 x01 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane));
     f32x4 x10 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 4 * lane));
     f32x4 x11 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 256 + 4 * lane));
-    float s0 = attn_score_lane(x00, x01, q0, q1, W);
-    float s1 = attn_score_lane(x10, x11, q0, q1, W);
+    float s0 = score_sel<MODE>(addm, x00, x01, q0, q1, W);
+    float s1 = score_sel<MODE>(addm, x10, x11, q0, q1, W);
     s0 = wave_sum(s0) + ab;
     s1 = wave_sum(s1) + ab;
     if (lane == 0) {
@@ -190,7 +207,7 @@ __global__ __launch_bounds__(256, 8) void attn_partial_kernel(const FwdParams p)
 // projection row, G context accumulators per feature row, so the HBM stream is the sample's bytes, not G x them
 // ("shared across beams in a batched redesign").  Partials are written per beam row in the layout
 // attn_combine_kernel expects.  grid = (chunks, samples).
-template <int G, bool NT>
+template <int G, bool NT, int MODE>
 __global__ __launch_bounds__(256, 6) void attn_partial_group_kernel(const FwdParams p) {   // >= 6 waves / SIMD: <= 80 VGPRs
   __shared__ float s_score[G][MAX_CHUNK];
   __shared__ float s_m[G];
@@ -209,13 +226,15 @@ __global__ __launch_bounds__(256, 6) void attn_partial_group_kernel(const FwdPar
   const int n0 = c * S.chunk;
   const int rows = min(S.chunk, S.N - n0);
 
-  const AttnLaneW W = attn_lane_w(S.w, lane);
+  const bool addm = MODE == GVD_SCORE_ADD || sidx == 1;      // (compile-time true for the README configuration)
+  const float qscale = (MODE == GVD_SCORE_DOT && !addm) ? 1.0f : GVD_TWO_LOG2E;
+  const AttnLaneW W = lane_w_sel<MODE>(addm, S.w, lane);
   for (int i = tid; i < G * (ATT_A / 4); i += 256) {      // pre-scaled queries (tanh_fast, gvd_common.h)
     const int g = i / (ATT_A / 4), a4 = i % (ATT_A / 4);
     *reinterpret_cast<f32x4*>(&s_q[g][4 * a4]) =
-        GVD_TWO_LOG2E * *reinterpret_cast<const f32x4*>(S.q + (int64_t)(smp * G + g) * S.ldq + 4 * a4);
+        qscale * *reinterpret_cast<const f32x4*>(S.q + (int64_t)(smp * G + g) * S.ldq + 4 * a4);
   }
-  const float ab = *S.alpha_bias;
+  const float ab = (MODE == GVD_SCORE_DOT && !addm) ? 0.f : *S.alpha_bias;
   const float* pf = S.p_feats + ((int64_t)smp * S.N + n0) * ATT_A;
 
   // Rows masked for EVERY beam of the sample are not fetched (score -1e8 whatever the features; weight exactly 0 as
@@ -264,8 +283,8 @@ __global__ __launch_bounds__(256, 6) void attn_partial_group_kernel(const FwdPar
     for (int g = 0; g < G; ++g) {
       const f32x4 q0 = *reinterpret_cast<const f32x4*>(&s_q[g][4 * lane + lz]);
       const f32x4 q1 = *reinterpret_cast<const f32x4*>(&s_q[g][256 + 4 * lane + lz]);
-      sc0[g] = wave_sum(attn_score_lane(x00, x01, q0, q1, W)) + ab;
-      sc1[g] = wave_sum(attn_score_lane(x10, x11, q0, q1, W)) + ab;
+      sc0[g] = wave_sum(score_sel<MODE>(addm, x00, x01, q0, q1, W)) + ab;
+      sc1[g] = wave_sum(score_sel<MODE>(addm, x10, x11, q0, q1, W)) + ab;
     }
     if (lane < 2 * G) {
       const int g = lane % G, second = lane / G;
@@ -450,8 +469,10 @@ int pick_chunk(int N, int B) {
 int nchunks_of(int N, int B) { int c = pick_chunk(N, B); return (N + c - 1) / c; }
 
 bool side_ok(const gvd_attn_side* s) {
-  return s && s->feats && s->p_feats && s->q && s->w && s->alpha_bias && s->N > 0 && gvd_aligned16(s->feats) &&
-         gvd_aligned16(s->p_feats) && gvd_aligned16(s->q) && gvd_aligned16(s->w) && (s->ldq % 4) == 0;
+  if (!s || s->score_mode < GVD_SCORE_ADD || s->score_mode > GVD_SCORE_DOT) return false;
+  const bool has_alpha = s->score_mode != GVD_SCORE_DOT;      // 'dp': no alpha_net in the module (AttModel.py:63-66,92-95)
+  return s->feats && s->p_feats && s->q && (!has_alpha || (s->w && s->alpha_bias && gvd_aligned16(s->w))) && s->N > 0 &&
+         gvd_aligned16(s->feats) && gvd_aligned16(s->p_feats) && gvd_aligned16(s->q) && (s->ldq % 4) == 0;
 }
 
 void fill_side(SideDev& d, const gvd_attn_side* s, int B) {
@@ -482,8 +503,9 @@ extern "C" int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_sid
                                  float* out_sum, int64_t ld_out, float* ctx_region, float* ctx_temporal,
                                  void* workspace, gvd_prof* prof, gvd_stream_t stream) {
   if (A != ATT_A || H != ATT_H || B <= 0 || !workspace || !gvd_aligned16(workspace)) return GVD_EINVAL;
-  if (!side_ok(region) || (temporal && !side_ok(temporal))) return GVD_EINVAL;
+  if (!side_ok(region) || (temporal && (!side_ok(temporal) || temporal->score_mode != GVD_SCORE_ADD))) return GVD_EINVAL;
   if (out_sum && (!gvd_aligned16(out_sum) || (ld_out % 4) != 0)) return GVD_EINVAL;
+  const int mode = region->score_mode;
   FwdParams p = {};
   fill_side(p.side[0], region, B);
   p.nside = 1;
@@ -507,9 +529,13 @@ extern "C" int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_sid
   if (grouped && (region->row_map || (temporal && temporal->row_map))) return GVD_EINVAL;   // (row kernel only)
   if (grouped) {
     const dim3 grid((unsigned)p.nctot, (unsigned)(B / G));
+#define GVD_LAUNCH_GROUP_M(GG, MM)                                                                             \
+    if (nt) hipLaunchKernelGGL((attn_partial_group_kernel<GG, true, MM>), grid, dim3(256), 0, st, p);          \
+    else hipLaunchKernelGGL((attn_partial_group_kernel<GG, false, MM>), grid, dim3(256), 0, st, p)
 #define GVD_LAUNCH_GROUP(GG)                                                                                   \
-    if (nt) hipLaunchKernelGGL((attn_partial_group_kernel<GG, true>), grid, dim3(256), 0, st, p);              \
-    else hipLaunchKernelGGL((attn_partial_group_kernel<GG, false>), grid, dim3(256), 0, st, p)
+    if (mode == GVD_SCORE_ADD) { GVD_LAUNCH_GROUP_M(GG, GVD_SCORE_ADD); }                                      \
+    else if (mode == GVD_SCORE_MUL) { GVD_LAUNCH_GROUP_M(GG, GVD_SCORE_MUL); }                                 \
+    else { GVD_LAUNCH_GROUP_M(GG, GVD_SCORE_DOT); }
     switch (G) {
       case 2: GVD_LAUNCH_GROUP(2); break;
       case 3: GVD_LAUNCH_GROUP(3); break;
@@ -517,10 +543,17 @@ extern "C" int gvd_attn_fwd_prof(const gvd_attn_side* region, const gvd_attn_sid
       default: GVD_LAUNCH_GROUP(5); break;
     }
 #undef GVD_LAUNCH_GROUP
-  } else if (nt)
-    hipLaunchKernelGGL(attn_partial_kernel<true>, dim3((unsigned)p.nctot, (unsigned)B), dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL(attn_partial_kernel<false>, dim3((unsigned)p.nctot, (unsigned)B), dim3(256), 0, st, p);
+#undef GVD_LAUNCH_GROUP_M
+  } else {
+    const dim3 grid((unsigned)p.nctot, (unsigned)B);
+#define GVD_LAUNCH_ROW(MM)                                                                                     \
+    if (nt) hipLaunchKernelGGL((attn_partial_kernel<true, MM>), grid, dim3(256), 0, st, p);                    \
+    else hipLaunchKernelGGL((attn_partial_kernel<false, MM>), grid, dim3(256), 0, st, p)
+    if (mode == GVD_SCORE_ADD) { GVD_LAUNCH_ROW(GVD_SCORE_ADD); }
+    else if (mode == GVD_SCORE_MUL) { GVD_LAUNCH_ROW(GVD_SCORE_MUL); }
+    else { GVD_LAUNCH_ROW(GVD_SCORE_DOT); }
+#undef GVD_LAUNCH_ROW
+  }
   gvd_prof_end(prof, st);
   GVD_CHECK_LAUNCH();
   CombParams c = {};

@@ -57,6 +57,11 @@ struct BwdStepParams {
   int N, chunk, nchunks;
 };
 
+// MODE = the side's score function (gvd_attn_side.score_mode): with u = x + q (ADD) or u = x q (MUL), t = tanh(u):
+//   ADD  d q += de w (1 - t^2)          d w += de t     d alpha_bias += de
+//   MUL  d q += de w (1 - t^2) x        d w += de t     d alpha_bias += de
+//   DOT  d q += de x                    (no alpha_net: the d w / d alpha_bias partials are written as zeros)
+template <int MODE>
 __global__ __launch_bounds__(256) void attn_bwd_step_kernel(const BwdStepParams p) {
   __shared__ float s_red[8];
   __shared__ float s_acc[4][2 * ATT_A];
@@ -81,8 +86,11 @@ __global__ __launch_bounds__(256) void attn_bwd_step_kernel(const BwdStepParams 
   const float* qb = p.q + (int64_t)b * p.ldq;
   const f32x4 q0 = *reinterpret_cast<const f32x4*>(qb + 4 * lane);
   const f32x4 q1 = *reinterpret_cast<const f32x4*>(qb + 256 + 4 * lane);
-  const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.w + 4 * lane);
-  const f32x4 w1 = *reinterpret_cast<const f32x4*>(p.w + 256 + 4 * lane);
+  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+  if constexpr (MODE != GVD_SCORE_DOT) {
+    w0 = *reinterpret_cast<const f32x4*>(p.w + 4 * lane);
+    w1 = *reinterpret_cast<const f32x4*>(p.w + 256 + 4 * lane);
+  }
   const float* fb = p.feats + ((int64_t)b * p.N + n0) * ATT_H;
   const float* pf = p.p_feats + ((int64_t)b * p.N + n0) * ATT_A;
   const float* al = p.alpha + (int64_t)b * p.ld_alpha + n0;
@@ -111,13 +119,25 @@ __global__ __launch_bounds__(256) void attn_bwd_step_kernel(const BwdStepParams 
     dab += de;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float t0 = tanh_fast(x0[k] + q0[k]), t1 = tanh_fast(x1[k] + q1[k]);
-      dq0[k] = fmaf(de * w0[k], 1.f - t0 * t0, dq0[k]);
-      dq1[k] = fmaf(de * w1[k], 1.f - t1 * t1, dq1[k]);
-      dw0[k] = fmaf(de, t0, dw0[k]);
-      dw1[k] = fmaf(de, t1, dw1[k]);
+      if constexpr (MODE == GVD_SCORE_ADD) {
+        const float t0 = tanh_fast(x0[k] + q0[k]), t1 = tanh_fast(x1[k] + q1[k]);
+        dq0[k] = fmaf(de * w0[k], 1.f - t0 * t0, dq0[k]);
+        dq1[k] = fmaf(de * w1[k], 1.f - t1 * t1, dq1[k]);
+        dw0[k] = fmaf(de, t0, dw0[k]);
+        dw1[k] = fmaf(de, t1, dw1[k]);
+      } else if constexpr (MODE == GVD_SCORE_MUL) {
+        const float t0 = tanh_fast(x0[k] * q0[k]), t1 = tanh_fast(x1[k] * q1[k]);
+        dq0[k] = fmaf(de * w0[k] * x0[k], 1.f - t0 * t0, dq0[k]);
+        dq1[k] = fmaf(de * w1[k] * x1[k], 1.f - t1 * t1, dq1[k]);
+        dw0[k] = fmaf(de, t0, dw0[k]);
+        dw1[k] = fmaf(de, t1, dw1[k]);
+      } else {
+        dq0[k] = fmaf(de, x0[k], dq0[k]);
+        dq1[k] = fmaf(de, x1[k], dq1[k]);
+      }
     }
   }
+  if constexpr (MODE == GVD_SCORE_DOT) dab = 0.f;
   // cross-wave reduction of the per-lane partials through LDS, then one deterministic partial per chunk
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -145,9 +165,11 @@ struct BwdPfParams {
   float* d_p_feats;            // [B,N,A]
   int N, Lc, chunk;
 };
+// MODE as in attn_bwd_step_kernel: d x = sum_t de w (1 - t^2) [ADD], ... (1 - t^2) q [MUL], sum_t de q [DOT]
 
 constexpr int PF_MAX_L = 40;   // seq_length 20 (40 for GT-sentence grounding, README.md:115)
 
+template <int MODE>
 __global__ __launch_bounds__(256) void attn_bwd_pfeats_kernel(const BwdPfParams p) {
   extern __shared__ __attribute__((aligned(16))) float s_q[];   // [Lc][A]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -160,8 +182,11 @@ __global__ __launch_bounds__(256) void attn_bwd_pfeats_kernel(const BwdPfParams 
         *reinterpret_cast<const f32x4*>(p.q_all + (int64_t)t * p.q_step_stride + (int64_t)b * p.ldq + 4 * a4);
   }
   __syncthreads();
-  const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.w + 4 * lane);
-  const f32x4 w1 = *reinterpret_cast<const f32x4*>(p.w + 256 + 4 * lane);
+  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+  if constexpr (MODE != GVD_SCORE_DOT) {
+    w0 = *reinterpret_cast<const f32x4*>(p.w + 4 * lane);
+    w1 = *reinterpret_cast<const f32x4*>(p.w + 256 + 4 * lane);
+  }
   for (int r = wave; r < rows; r += 4) {
     const int n = n0 + r;
     const float* px = p.p_feats + ((int64_t)b * p.N + n) * ATT_A;
@@ -175,9 +200,18 @@ __global__ __launch_bounds__(256) void attn_bwd_pfeats_kernel(const BwdPfParams 
       const f32x4 q1 = *reinterpret_cast<const f32x4*>(s_q + t * ATT_A + 256 + 4 * lane);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float t0 = tanh_fast(x0[k] + q0[k]), t1 = tanh_fast(x1[k] + q1[k]);
-        a0[k] = fmaf(de * w0[k], 1.f - t0 * t0, a0[k]);
-        a1[k] = fmaf(de * w1[k], 1.f - t1 * t1, a1[k]);
+        if constexpr (MODE == GVD_SCORE_ADD) {
+          const float t0 = tanh_fast(x0[k] + q0[k]), t1 = tanh_fast(x1[k] + q1[k]);
+          a0[k] = fmaf(de * w0[k], 1.f - t0 * t0, a0[k]);
+          a1[k] = fmaf(de * w1[k], 1.f - t1 * t1, a1[k]);
+        } else if constexpr (MODE == GVD_SCORE_MUL) {
+          const float t0 = tanh_fast(x0[k] * q0[k]), t1 = tanh_fast(x1[k] * q1[k]);
+          a0[k] = fmaf(de * w0[k] * q0[k], 1.f - t0 * t0, a0[k]);
+          a1[k] = fmaf(de * w1[k] * q1[k], 1.f - t1 * t1, a1[k]);
+        } else {
+          a0[k] = fmaf(de, q0[k], a0[k]);
+          a1[k] = fmaf(de, q1[k], a1[k]);
+        }
       }
     }
     float* o = p.d_p_feats + ((int64_t)b * p.N + n) * ATT_A;
@@ -219,7 +253,8 @@ extern "C" int gvd_attn_bwd_step(const gvd_attn_side* side, int B, int A, int H,
                                  int64_t ld_de, float* dq_part, float* dw_part, float* dab_part,
                                  gvd_stream_t stream) {
   if (!side || A != ATT_A || H != ATT_H || B <= 0 || !alpha || !ctx || !d_ctx || !de_out || !dq_part || !dw_part ||
-      !dab_part || side->N <= 0)
+      !dab_part || side->N <= 0 || side->score_mode < GVD_SCORE_ADD || side->score_mode > GVD_SCORE_DOT ||
+      (side->score_mode != GVD_SCORE_DOT && !side->w))
     return GVD_EINVAL;
   if (!gvd_aligned16(side->feats) || !gvd_aligned16(side->p_feats) || !gvd_aligned16(side->q) || !gvd_aligned16(ctx) ||
       !gvd_aligned16(d_ctx) || (ld_ctx % 4) || (ld_dctx % 4) || (side->ldq % 4))
@@ -234,15 +269,20 @@ extern "C" int gvd_attn_bwd_step(const gvd_attn_side* side, int B, int A, int H,
   p.N = side->N;
   p.chunk = bwd_chunk(side->N, B);
   p.nchunks = (side->N + p.chunk - 1) / p.chunk;
-  hipLaunchKernelGGL(attn_bwd_step_kernel, dim3((unsigned)p.nchunks, (unsigned)B), dim3(256), 0, gvd_s(stream), p);
+  const dim3 grid((unsigned)p.nchunks, (unsigned)B);
+  if (side->score_mode == GVD_SCORE_ADD) hipLaunchKernelGGL(attn_bwd_step_kernel<GVD_SCORE_ADD>, grid, dim3(256), 0, gvd_s(stream), p);
+  else if (side->score_mode == GVD_SCORE_MUL) hipLaunchKernelGGL(attn_bwd_step_kernel<GVD_SCORE_MUL>, grid, dim3(256), 0, gvd_s(stream), p);
+  else hipLaunchKernelGGL(attn_bwd_step_kernel<GVD_SCORE_DOT>, grid, dim3(256), 0, gvd_s(stream), p);
   GVD_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int gvd_attn_bwd_pfeats(const float* p_feats, int B, int N, int A, const float* q_all,
                                    int64_t q_step_stride, int64_t ldq, const float* de_all, int64_t de_step_stride,
-                                   int64_t ld_de, const float* w, int Lc, float* d_p_feats, gvd_stream_t stream) {
-  if (!p_feats || !q_all || !de_all || !w || !d_p_feats || A != ATT_A || B <= 0 || N <= 0 || Lc <= 0 || Lc > PF_MAX_L)
+                                   int64_t ld_de, const float* w, int Lc, float* d_p_feats, int score_mode,
+                                   gvd_stream_t stream) {
+  if (!p_feats || !q_all || !de_all || !d_p_feats || A != ATT_A || B <= 0 || N <= 0 || Lc <= 0 || Lc > PF_MAX_L ||
+      score_mode < GVD_SCORE_ADD || score_mode > GVD_SCORE_DOT || (score_mode != GVD_SCORE_DOT && !w))
     return GVD_EINVAL;
   if (!gvd_aligned16(p_feats) || !gvd_aligned16(q_all) || !gvd_aligned16(d_p_feats) || (ldq % 4) || (q_step_stride % 4))
     return GVD_EINVAL;
@@ -254,13 +294,17 @@ extern "C" int gvd_attn_bwd_pfeats(const float* p_feats, int B, int N, int A, co
   while (chunk > 8 && (long)B * ((N + chunk - 1) / chunk) < 1024) chunk /= 2;
   p.chunk = chunk;
   const size_t lds = (size_t)Lc * ATT_A * sizeof(float);
+  const void* fn = score_mode == GVD_SCORE_ADD ? reinterpret_cast<const void*>(attn_bwd_pfeats_kernel<GVD_SCORE_ADD>)
+                   : score_mode == GVD_SCORE_MUL ? reinterpret_cast<const void*>(attn_bwd_pfeats_kernel<GVD_SCORE_MUL>)
+                                                 : reinterpret_cast<const void*>(attn_bwd_pfeats_kernel<GVD_SCORE_DOT>);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_pfeats_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(attn_bwd_pfeats_kernel, dim3((unsigned)((N + chunk - 1) / chunk), (unsigned)B), dim3(256), lds,
-                     gvd_s(stream), p);
+  const dim3 grid((unsigned)((N + chunk - 1) / chunk), (unsigned)B);
+  if (score_mode == GVD_SCORE_ADD) hipLaunchKernelGGL(attn_bwd_pfeats_kernel<GVD_SCORE_ADD>, grid, dim3(256), lds, gvd_s(stream), p);
+  else if (score_mode == GVD_SCORE_MUL) hipLaunchKernelGGL(attn_bwd_pfeats_kernel<GVD_SCORE_MUL>, grid, dim3(256), lds, gvd_s(stream), p);
+  else hipLaunchKernelGGL(attn_bwd_pfeats_kernel<GVD_SCORE_DOT>, grid, dim3(256), lds, gvd_s(stream), p);
   GVD_CHECK_LAUNCH();
   return 0;
 }

@@ -87,6 +87,7 @@ extern "C" int gvd_greedy_decode(const gvd_greedy_args* a, gvd_stream_t stream) 
   const int mode = a->att_input_mode;
   if (mode != GVD_ATT_INPUT_BOTH && mode != GVD_ATT_INPUT_FEATMAP && mode != GVD_ATT_INPUT_REGION) return GVD_EINVAL;
   const bool use_temporal = mode != GVD_ATT_INPUT_REGION;          // AttModel.py:140-141
+  const int score_mode = a->region_attn_mode;                      // AttModel.py:82-95 (checked by gvd_attn_fwd)
   const int B = a->B, H = a->H, A = a->A, E = a->E, V = a->V, R = a->R, Ft = use_temporal ? a->Ft : 0, L = a->L;
   hipStream_t st = gvd_s(stream);
   Ws w = carve(a->workspace, B, Ft, R, H, A, E, V);
@@ -117,7 +118,8 @@ extern "C" int gvd_greedy_decode(const gvd_greedy_args* a, gvd_stream_t stream) 
     g.C = w.fc_gates; g.ldc = 4 * H; g.M = B; g.N = 4 * H; g.batch = 1;
     GVD_TRY(gvd_gemm_nt_f32(&g, stream));
   }
-  const bool persistent = !a->no_persistent && mode == GVD_ATT_INPUT_BOTH && gvd_pd_eligible(B, H, A, E, V, R, Ft);
+  const bool persistent = !a->no_persistent && mode == GVD_ATT_INPUT_BOTH && score_mode == GVD_SCORE_ADD &&
+                          gvd_pd_eligible(B, H, A, E, V, R, Ft);
   if (a->pool_row_map && persistent) return GVD_EINVAL;   // persistent kernel: dense layout
   if (persistent) {
     // decode batch: the whole token loop as ONE persistent cooperative launch (decode_persistent.hip).  The event
@@ -168,7 +170,7 @@ extern "C" int gvd_greedy_decode(const gvd_greedy_args* a, gvd_stream_t stream) 
       reg.att_mask = a->pnt_mask + 1; reg.ld_att_mask = R + 1;
       reg.pnt_mask = a->pnt_mask + 1; reg.ld_pnt_mask = R + 1;
       reg.logits_out = a->att2_weights + (int64_t)t * R; reg.ld_logits = (int64_t)L * R;
-      reg.N = R; reg.row_map = a->pool_row_map;
+      reg.N = R; reg.row_map = a->pool_row_map; reg.score_mode = score_mode;
       gvd_attn_side tmp = {};
       tmp.feats = a->conv; tmp.p_feats = a->p_conv; tmp.q = w.q12; tmp.ldq = 2 * A;
       tmp.w = a->att1_alpha_w; tmp.alpha_bias = a->att1_alpha_b; tmp.N = Ft;

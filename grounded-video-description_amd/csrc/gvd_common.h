@@ -84,6 +84,29 @@ __device__ __forceinline__ float attn_score_lane(gvd_score_f32x4 x0, gvd_score_f
   return s;
 }
 
+// The other two score functions of the region attention (opts.py:63 `--region_attn_mode`; gvd_attn_side.score_mode):
+//   GVD_SCORE_MUL ('mix_mul', AttModel.py:82-83)   sum_k w_k tanh(x_k q_k): the same five issue slots per element with the
+//                 exponent x_k (C q_k) in place of x_k C + C q_k
+//   GVD_SCORE_DOT ('dp', AttModel.py:92-95)        sum_k x_k q_k: one fma per element, q unscaled, no alpha_net
+// MODE = GVD_SCORE_ADD is attn_score_lane above, instruction for instruction.  qs0 / qs1: C q for ADD / MUL, q for DOT.
+template <int MODE>
+__device__ __forceinline__ float attn_score_lane_m(gvd_score_f32x4 x0, gvd_score_f32x4 x1, gvd_score_f32x4 qs0,
+                                                   gvd_score_f32x4 qs1, const AttnLaneW& W) {
+  if constexpr (MODE == GVD_SCORE_ADD) return attn_score_lane(x0, x1, qs0, qs1, W);
+  float s = MODE == GVD_SCORE_MUL ? W.wsum : 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if constexpr (MODE == GVD_SCORE_MUL) {
+      s = fmaf(W.wn0[k], gvd_rcp_1p(__builtin_amdgcn_exp2f(x0[k] * qs0[k])), s);
+      s = fmaf(W.wn1[k], gvd_rcp_1p(__builtin_amdgcn_exp2f(x1[k] * qs1[k])), s);
+    } else {
+      s = fmaf(x0[k], qs0[k], s);
+      s = fmaf(x1[k], qs1[k], s);
+    }
+  }
+  return s;
+}
+
 // XCD-aware bijective remap of a linear workgroup id (cdna_hip_programming.md T1): hardware round-robins
 // consecutive ids over the 8 XCDs; after the remap each XCD walks a contiguous chunk of logical ids so
 // neighbouring tiles (which share an operand panel) hit the same private L2.

@@ -73,13 +73,15 @@ class DecoderLoopFn(torch.autograd.Function):
         # gradient (zeros where the reference leaves .grad = None).  'featmap': the region context is not an input of the
         # language LSTM - the region side's d_ctx is zero (its scores still carry the grounding losses' gradient) and the
         # region features get a gradient through the projection only
-        use_t, sum_r = ctx.mode != 'region', ctx.mode != 'featmap'
+        mode, region_mode = ctx.mode if isinstance(ctx.mode, tuple) else (ctx.mode, 'mix')
+        use_t, sum_r = mode != 'region', mode != 'featmap'
+        sm = {'mix': 0, 'mix_mul': 1, 'dp': 2}[region_mode]      # score function of the region side (AttModel.py:82-95)
         R, Ft = pool.shape[1], (conv.shape[1] if use_t else 0)
         dev = fc.device
         per_step_mask = pnt_masks.dim() == 3
         am = att_mask[:, 1:]
         w_stack = S['w_stack']
-        a1_aw, a2_aw = P['a1_aw'].reshape(-1), P['a2_aw'].reshape(-1)
+        a1_aw, a2_aw = P['a1_aw'].reshape(-1), (P['a2_aw'].reshape(-1) if sm != 2 else None)
         softmax = getattr(K, 'softmax_rows', None) or (lambda x: torch.softmax(x, dim=-1))
         alpha_r = softmax(S['scores_r'])                        # [B,Lc,R]
         alpha_t = softmax(S['scores_t']) if use_t else None     # [B,Lc,Ft]
@@ -127,8 +129,8 @@ class DecoderLoopFn(torch.autograd.Function):
             d_att_sum = dX[:, :H]
             pmask = (pnt_masks[:, t] if per_step_mask else pnt_masks)[:, 1:]
             q12 = S['q12'][t]
-            region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P['a2_ab'], att_mask=am,
-                          pnt_mask=pmask)
+            region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P.get('a2_ab'), att_mask=am,
+                          pnt_mask=pmask, score_mode=sm)
             temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab']) if use_t else None
             dl = d_att2w[:, t] if d_att2w is not None else None
             dq12 = dq12_all[t]
@@ -177,7 +179,7 @@ class DecoderLoopFn(torch.autograd.Function):
         d_bstack = dq_flat.sum(0)
         g['a1_w'], g['a2_w'] = d_wstack[:A], d_wstack[A:]
         g['a1_b'], g['a2_b'] = d_bstack[:A], d_bstack[A:]
-        g['a1_aw'], g['a2_aw'] = dw_t.view(1, A), dw_r.view(1, A)
+        g['a1_aw'], g['a2_aw'] = dw_t.view(1, A), dw_r.view(1, A)      # (a2_*: not among ctx.keys under 'dp' - no alpha_net)
         g['a1_ab'], g['a2_ab'] = dab_t, dab_r
         dctx_b = dctx_all.transpose(0, 1)                        # [B,Lc,H] view of dX_all[:, :, :H]
         ru = getattr(K, 'rank_update', None)
@@ -186,7 +188,7 @@ class DecoderLoopFn(torch.autograd.Function):
         # alpha^T d_ctx over all steps: one streaming write of [B,R,H] / [B,Ft,H] (csrc/stream_mm.hip)
         g['pool'] = ru(alpha_r, dctx_b) if sum_r else torch.zeros_like(pool)     # [B,R,H]
         g['conv'] = ru(alpha_t, dctx_b) if use_t else None
-        g['p_pool'] = K.attn_bwd_pfeats(p_pool, S['q12'][:, :, A:], de_r_all, a2_aw)
+        g['p_pool'] = K.attn_bwd_pfeats(p_pool, S['q12'][:, :, A:], de_r_all, a2_aw, score_mode=sm)
         g['p_conv'] = K.attn_bwd_pfeats(p_conv, S['q12'][:, :, :A], de_t_all, a1_aw) if use_t else None
         ctx.save = None
         names = ['fc', 'conv', 'p_conv', 'pool', 'p_pool', 'xt_all'] + list(ctx.keys)

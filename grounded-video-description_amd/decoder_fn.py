@@ -16,21 +16,25 @@ K = ops   # kernel backend (the HIP library); tests substitute a torch stand-in 
 def _params(model):
     c = model.core
     H = model.rnn_size
-    return dict(
+    P = dict(
         att_w_ih=c.att_lstm.weight_ih, att_w_hh=c.att_lstm.weight_hh, att_b_ih=c.att_lstm.bias_ih,
         att_b_hh=c.att_lstm.bias_hh, lang_w_ih=c.lang_lstm.weight_ih, lang_w_hh=c.lang_lstm.weight_hh,
         lang_b_ih=c.lang_lstm.bias_ih, lang_b_hh=c.lang_lstm.bias_hh,
         a1_w=c.attention.h2att.weight, a1_b=c.attention.h2att.bias,
         a1_aw=c.attention.alpha_net.weight, a1_ab=c.attention.alpha_net.bias,
-        a2_w=c.attention2.h2att.weight, a2_b=c.attention2.h2att.bias,
-        a2_aw=c.attention2.alpha_net.weight, a2_ab=c.attention2.alpha_net.bias)
+        a2_w=c.attention2.h2att.weight, a2_b=c.attention2.h2att.bias)
+    if hasattr(c.attention2, 'alpha_net'):            # (none under region_attn_mode='dp', AttModel.py:63-66)
+        P.update(a2_aw=c.attention2.alpha_net.weight, a2_ab=c.attention2.alpha_net.bias)
+    return P
 
 
 def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks, save=None, mode='both'):
     """The forward recurrence.  `save` (dict) receives what the BPTT needs when given.  mode = att_input_mode
     (AttModel.py:140-151): 'region' runs no frame-wise side (conv / p_conv are not read), 'featmap' feeds the frame-wise
     context alone to the language LSTM (the region side still runs for the grounding logits)."""
+    mode, region_mode = mode if isinstance(mode, tuple) else (mode, 'mix')      # (att_input_mode, region_attn_mode)
     use_t, sum_r = mode != 'region', mode != 'featmap'
+    sm = {'mix': 0, 'mix_mul': 1, 'dp': 2}[region_mode]          # score function of the region side (AttModel.py:82-95)
     B, Lc, E = xt_all.shape
     H = fc.shape[1]
     A = p_pool.shape[2]
@@ -40,7 +44,7 @@ def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks,
     w_ih_att, w_ih_h = P['lang_w_ih'][:, :H], P['lang_w_ih'][:, H:]
     w_stack = torch.cat([P['a1_w'], P['a2_w']], 0)
     b_stack = torch.cat([P['a1_b'], P['a2_b']], 0)
-    a1_aw, a2_aw = P['a1_aw'].reshape(-1), P['a2_aw'].reshape(-1)
+    a1_aw, a2_aw = P['a1_aw'].reshape(-1), (P['a2_aw'].reshape(-1) if sm != 2 else None)
     # loop-invariant part of the att-LSTM gates: fc W_ih[:, :H]^T + b_ih + b_hh
     fc_gates = K.gemm_nt(fc, w_ih_fc, P['att_b_ih']) + P['att_b_hh']
     h_att = torch.zeros(B, H, device=dev, dtype=fc.dtype); c_att = torch.zeros(B, H, device=dev, dtype=fc.dtype)
@@ -68,8 +72,8 @@ def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks,
                                        h_out=save['h_att'][t + 1], c_out=save['c_att'][t + 1])
             q12 = K.gemm_nt(h_att, w_stack, b_stack, out=save['q12'][t])
             pmask = (pnt_masks[:, t] if per_step_mask else pnt_masks)[:, 1:]
-            region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P['a2_ab'], att_mask=am,
-                          pnt_mask=pmask, logits_out=att2_w[:, t], scores_out=save['scores_r'][:, t])
+            region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P.get('a2_ab'), att_mask=am,
+                          pnt_mask=pmask, logits_out=att2_w[:, t], scores_out=save['scores_r'][:, t], score_mode=sm)
             temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab'],
                             scores_out=save['scores_t'][:, t]) if use_t else None
             att_sum, _, _ = K.attention_step(region, temporal, want_separate=True, out=save['att_sum'][t],
@@ -85,8 +89,8 @@ def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks,
         h_att, c_att = K.lstm_cell([xt], [w_ih_xt], h_att, P['att_w_hh'], None, None, c_att, rowbias=fc_gates)
         q12 = K.gemm_nt(h_att, w_stack, b_stack)
         pmask = (pnt_masks[:, t] if per_step_mask else pnt_masks)[:, 1:]
-        region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P['a2_ab'], att_mask=am,
-                      pnt_mask=pmask, logits_out=att2_w[:, t])
+        region = dict(feats=pool, p_feats=p_pool, q=q12[:, A:], w=a2_aw, alpha_bias=P.get('a2_ab'), att_mask=am,
+                      pnt_mask=pmask, logits_out=att2_w[:, t], score_mode=sm)
         temporal = dict(feats=conv, p_feats=p_conv, q=q12[:, :A], w=a1_aw, alpha_bias=P['a1_ab']) if use_t else None
         att_sum = K.attention_step(region, temporal, sum_region=sum_r)
         h_lang, c_lang = K.lstm_cell([att_sum, h_att], [w_ih_att, w_ih_h], h_lang, P['lang_w_hh'],
@@ -96,9 +100,9 @@ def forward_loop(P, fc, conv, p_conv, pool, p_pool, xt_all, att_mask, pnt_masks,
 
 def decoder_loop(model, pre, xt_all, att_mask, pnt_masks):
     P = _params(model)
-    mode = getattr(model, 'att_input_mode', 'both')
+    mode = (getattr(model, 'att_input_mode', 'both'), getattr(model, 'region_attn_mode', 'mix'))
     conv, p_conv = pre['conv'], pre['p_conv']
-    if mode == 'region':
+    if mode[0] == 'region':
         # no frame-wise side: one-element stand-ins keep the autograd.Function's argument list (nothing reads them)
         conv = p_conv = pre['fc'].new_zeros(1)
     tensors = [pre['fc'], conv, p_conv, pre['pool'], pre['p_pool'], xt_all] + list(P.values())

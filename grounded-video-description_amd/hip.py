@@ -59,7 +59,7 @@ class AttnSide(C.Structure):
                 ('logits_out', c_f32p), ('ld_logits', C.c_int64),
                 ('scores_out', c_f32p), ('ld_scores', C.c_int64),
                 ('row_map', C.c_void_p),
-                ('N', C.c_int), ('group', C.c_int)]
+                ('N', C.c_int), ('group', C.c_int), ('score_mode', C.c_int)]
 
 
 class GreedyArgs(C.Structure):
@@ -73,7 +73,8 @@ class GreedyArgs(C.Structure):
                 ('B', C.c_int), ('Ft', C.c_int), ('R', C.c_int), ('H', C.c_int), ('A', C.c_int), ('E', C.c_int),
                 ('V', C.c_int), ('L', C.c_int), ('unk_idx', C.c_int), ('no_persistent', C.c_int),
                 ('seq', c_i64p), ('seq_logprobs', c_f32p), ('att2_weights', c_f32p), ('workspace', C.c_void_p),
-                ('prof', C.c_void_p), ('status', C.c_void_p), ('trace', C.c_void_p), ('att_input_mode', C.c_int)]
+                ('prof', C.c_void_p), ('status', C.c_void_p), ('trace', C.c_void_p), ('att_input_mode', C.c_int),
+                ('region_attn_mode', C.c_int)]
 
 
 class BeamStepArgs(C.Structure):
@@ -172,7 +173,7 @@ _SIG = {
                                     C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p,
                                     c_f32p, c_f32p, C.c_void_p]),
     'gvd_attn_bwd_pfeats': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int64, c_f32p,
-                                      C.c_int64, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_void_p]),
+                                      C.c_int64, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_int, C.c_void_p]),
     'gvd_logsoftmax_top2_embed': (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_i64p, C.c_int64,
                                             c_f32p, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_int64, C.c_void_p]),
     'gvd_embed_relu': (C.c_int, [c_i64p, C.c_int64, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int64, C.c_void_p]),

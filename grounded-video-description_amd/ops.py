@@ -274,9 +274,13 @@ def lstm_cell(xs, ws, h_prev, w_hh, b_ih, b_hh, c_prev, rowbias=None, gates_out=
     return h, c
 
 
+SCORE_MODES = {'mix': 0, 'mix_mul': 1, 'dp': 2}          # region_attn_mode -> GVD_SCORE_ADD / MUL / DOT (include/gvd_hip.h)
+
+
 def _side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, logits_out=None, scores_out=None,
-          group=0, row_map=None):
+          group=0, row_map=None, score_mode=0):
     s = AttnSide()
+    s.score_mode = score_mode          # 2 ('dp'): no alpha_net - w / alpha_bias are None
     assert feats.is_contiguous() and p_feats.is_contiguous() and q.stride(-1) == 1
     s.feats, s.p_feats = ptr(feats), ptr(p_feats)
     s.q = ptr(q); s.ldq = q.stride(0)
@@ -393,7 +397,7 @@ def logsoftmax_rows(logits, target=None, topk=0):
 ATT_INPUT_MODES = {'both': 0, 'featmap': 1, 'region': 2}          # GVD_ATT_INPUT_* (include/gvd_hip.h)
 
 
-def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None, flags=None, att_input_mode='both'):
+def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None, flags=None, att_input_mode='both', region_attn_mode='mix'):
     """Whole greedy token loop (AttModel._sample, model.py:580-624) in one C call.
     pre: dict(fc, conv, p_conv, pool, p_pool) from the preamble; P: dict of parameter tensors.
     `flags`: list that receives the launch's device status word (non-zero after a sync = the persistent kernel's grid
@@ -430,7 +434,9 @@ def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None, flags=None, att_input
     for k in ('embed', 'att_w_ih', 'att_w_hh', 'att_b_ih', 'att_b_hh', 'lang_w_ih', 'lang_w_hh', 'lang_b_ih',
               'lang_b_hh', 'att1_h2att_w', 'att1_h2att_b', 'att1_alpha_w', 'att1_alpha_b', 'att2_h2att_w',
               'att2_h2att_b', 'att2_alpha_w', 'att2_alpha_b', 'logit_w', 'logit_b'):
-        t = P[k]
+        t = P.get(k)
+        if t is None and region_attn_mode == 'dp' and k in ('att2_alpha_w', 'att2_alpha_b'):
+            continue                  # dot-product region attention: the module has no alpha_net (AttModel.py:63-66,92-95)
         assert t.is_contiguous() and t.is_cuda and t.dtype == torch.float32, k
         setattr(a, k, ptr(t))
     a.B, a.Ft, a.R, a.H, a.A, a.E, a.V, a.L, a.unk_idx = B, Ft, R, H, A, E, V, L, unk_idx
@@ -438,6 +444,7 @@ def greedy_decode(pre, P, pnt_mask, L, unk_idx, prof=None, flags=None, att_input
     a.prof = prof.h if prof is not None else None
     a.no_persistent = 0 if _persistent['on'] else 1
     a.att_input_mode = ATT_INPUT_MODES[att_input_mode]
+    a.region_attn_mode = SCORE_MODES[region_attn_mode]
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     a.status = ptr(status)
     trace = None
@@ -916,16 +923,17 @@ def sum_chunks_pair(a, r, out):
     return out
 
 
-def attn_bwd_pfeats(p_feats, q_all, de_all, w):
+def attn_bwd_pfeats(p_feats, q_all, de_all, w, score_mode=0):
     """d_p_feats [B,N,A] = sum_t de_all[t,b,n] * w * (1 - tanh^2(p_feats[b,n] + q_all[t,b])).
-    q_all: [Lc,B,A] view (inner stride 1); de_all: [Lc,B,N] contiguous."""
-    require_cuda_f32(p_feats, q_all, de_all, w)
+    q_all: [Lc,B,A] view (inner stride 1); de_all: [Lc,B,N] contiguous.  score_mode 1 ('mix_mul'): ... (1 - tanh^2(p q)) q;
+    2 ('dp'): sum_t de q (w None)."""
+    require_cuda_f32(p_feats, q_all, de_all, *([] if w is None else [w]))
     B, N, A = p_feats.shape
     Lc = q_all.shape[0]
     assert q_all.stride(-1) == 1 and de_all.is_contiguous() and p_feats.is_contiguous()
     out = torch.empty_like(p_feats)
     check(lib().gvd_attn_bwd_pfeats(ptr(p_feats), B, N, A, ptr(q_all), q_all.stride(0), q_all.stride(1), ptr(de_all),
-                                    de_all.stride(0), de_all.stride(1), ptr(w), Lc, ptr(out), stream_ptr()),
+                                    de_all.stride(0), de_all.stride(1), ptr(w), Lc, ptr(out), score_mode, stream_ptr()),
           'gvd_attn_bwd_pfeats')
     return out
 

@@ -108,6 +108,10 @@ def init_state_dict(opt, seed=0, profile='default'):
         sd['core.lang_lstm.weight_hh'] *= 1.5
     elif profile != 'default':
         raise ValueError(profile)
+    if getattr(opt, 'region_attn_mode', 'mix') == 'dp':      # (drawn all the same: the other tensors keep their values)
+        # dot-product region attention: Attention2 has no alpha_net (AttModel.py:63-66); the projections' scale is what sets
+        # the sharpness of the softmax there - p . q over 512 terms needs none of the 'trained_like' gain
+        del sd['core.attention2.alpha_net.weight'], sd['core.attention2.alpha_net.bias']
     return sd
 
 

@@ -135,6 +135,9 @@ int gvd_lstm_cell_fwd(const gvd_lstm_args* args, gvd_stream_t stream);
 /* One attention "side": Attention2 over regions (AttModel.py:71-108) or Attention over frames
  * (AttModel.py:33-53; masks NULL).
  *   e[n] = w . tanh(p_feats[b,n,:] + q[b,:]) + *alpha_bias ; e[att_mask] = -1e8
+ *          (score_mode GVD_SCORE_ADD: `region_attn_mode` 'mix', and always the frame side;
+ *           GVD_SCORE_MUL 'mix_mul': w . tanh(p_feats * q) + *alpha_bias, AttModel.py:82-83;
+ *           GVD_SCORE_DOT 'dp': p_feats . q - no alpha_net, w / alpha_bias NULL, AttModel.py:92-95)
  *   alpha = softmax_n(e) ; ctx[b,:] = sum_n alpha[n] feats[b,n,:]
  *   logits_out[b,n] = e[n] with [pnt_mask] = -1e8          (= `att2_weight`, pre-softmax)
  */
@@ -154,7 +157,12 @@ typedef struct {
   int N;
   int group;   /* 0/1: feats/p_feats have one entry per row b.  K>1: rows b share entry b/K (the K beams of a
                   sample attend over ONE copy of its features: feats/p_feats are [B/K,N,*]) */
+  int score_mode;   /* GVD_SCORE_ADD (0) / GVD_SCORE_MUL / GVD_SCORE_DOT: the score function above (region side only; the
+                       temporal side of a launch must be GVD_SCORE_ADD) */
 } gvd_attn_side;
+#define GVD_SCORE_ADD 0
+#define GVD_SCORE_MUL 1
+#define GVD_SCORE_DOT 2
 
 /* y[i] = the kernels' tanh (csrc/gvd_common.h: tanh_fast = 1 - 2 / (1 + 2^(2 log2(e) x)) on v_exp_f32 / v_rcp_f32,
  * absolute error <= 2.5e-7) - exported so that the error bound the score kernels rely on is measured on the device
@@ -350,10 +358,12 @@ int gvd_attn_bwd_step(const gvd_attn_side* side, int B, int A, int H, const floa
                       float* dw_part, float* dab_part, gvd_stream_t stream);
 
 /* After the loop: d_p_feats[b,n,:] = sum_t de_all[t][b,n] * w * (1 - tanh^2(p_feats[b,n,:] + q_all[t][b,:])).
- * q_all + t*q_step_stride + b*ldq, de_all + t*de_step_stride + b*ld_de + n.  Lc <= 40. */
+ * q_all + t*q_step_stride + b*ldq, de_all + t*de_step_stride + b*ld_de + n.  Lc <= 40.
+ * score_mode (gvd_attn_side.score_mode): GVD_SCORE_MUL -> sum_t de w (1 - tanh^2(p q)) q; GVD_SCORE_DOT -> sum_t de q
+ * (w NULL).  gvd_attn_bwd_step reads the mode from its side. */
 int gvd_attn_bwd_pfeats(const float* p_feats, int B, int N, int A, const float* q_all, int64_t q_step_stride,
                         int64_t ldq, const float* de_all, int64_t de_step_stride, int64_t ld_de, const float* w,
-                        int Lc, float* d_p_feats, gvd_stream_t stream);
+                        int Lc, float* d_p_feats, int score_mode, gvd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Vocabulary head
@@ -437,6 +447,9 @@ typedef struct {
                           region attention still runs: its logits are the grounding output); GVD_ATT_INPUT_REGION (2) the
                           region context alone - conv / p_conv are not read (may be NULL, Ft is ignored).  Non-zero modes
                           always run the kernel-per-op loop */
+  int region_attn_mode; /* opts.py:63 `--region_attn_mode`: GVD_SCORE_ADD ('mix', README) / GVD_SCORE_MUL ('mix_mul') /
+                           GVD_SCORE_DOT ('dp': att2_alpha_w / att2_alpha_b are not read) - the score function of the region
+                           attention (gvd_attn_side.score_mode).  Non-zero modes always run the kernel-per-op loop */
 } gvd_greedy_args;
 #define GVD_ATT_INPUT_BOTH 0
 #define GVD_ATT_INPUT_FEATMAP 1

@@ -87,6 +87,20 @@ CASES = {
                                      opt=dict(att_input_mode='region')),
     'beam3_b4_v1000_ft10_region': dict(mode='beam', B=4, V=1000, Ft=10, K=3, seed=30, profile='trained_like',
                                        opt=dict(att_input_mode='region')),
+    # region_attn_mode (opts.py:63; AttModel.py:82-95): the score function of the region attention - 'mix_mul'
+    # alpha_net(tanh(p * q)), 'dp' the plain dot product p . q (no alpha_net in the module / state_dict)
+    'greedy_b8_v1000_ft10_mixmul': dict(mode='sample', B=8, V=1000, Ft=10, seed=31, profile='trained_like',
+                                        opt=dict(region_attn_mode='mix_mul')),
+    'mle_b4_v1000_ft10_mixmul': dict(mode='MLE', B=4, V=1000, Ft=10, seed=32, profile='trained_like',
+                                     opt=dict(region_attn_mode='mix_mul')),
+    'greedy_b8_v1000_ft10_dp': dict(mode='sample', B=8, V=1000, Ft=10, seed=33, profile='trained_like',
+                                    opt=dict(region_attn_mode='dp')),
+    'mle_b4_v1000_ft10_dp': dict(mode='MLE', B=4, V=1000, Ft=10, seed=34, profile='trained_like',
+                                 opt=dict(region_attn_mode='dp')),
+    'beam3_b4_v1000_ft10_mixmul': dict(mode='beam', B=4, V=1000, Ft=10, K=3, seed=35, profile='trained_like',
+                                       opt=dict(region_attn_mode='mix_mul')),
+    'beam3_b4_v1000_ft10_dp': dict(mode='beam', B=4, V=1000, Ft=10, K=3, seed=36, profile='trained_like',
+                                   opt=dict(region_attn_mode='dp')),
     'grd_b4_v1000_ft10_l40': dict(mode='GRD', B=4, V=1000, Ft=10, seed=18, profile='trained_like',
                                   opt=dict(seq_length=40)),
     # BASELINE configs[4]'s region count under GREEDY decode: 20 sampled frames x 100 proposals = 2000 regions (the beam

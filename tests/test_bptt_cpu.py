@@ -124,3 +124,37 @@ def test_bptt_att_input_modes_match_autograd_through_oracle(fake_kernels, mode):
             assert mode == 'region' and k.startswith('a1_') and zero(p.grad), k
         else:
             assert torch.allclose(p.grad, want, rtol=1e-8, atol=1e-10), k
+
+
+@pytest.mark.parametrize('region_mode', ['mix_mul', 'dp'])
+def test_bptt_region_attn_modes_match_autograd_through_oracle(fake_kernels, region_mode):
+    """region_attn_mode (opts.py:63, AttModel.py:82-95): the multiplicative score w . tanh(p * q) and the plain dot product
+    p . q (no alpha_net in the module) through the hand-written BPTT."""
+    W, pre, xt_all, att_mask, pnt_masks, Gh, Ga = _problem(6, per_step=True)
+    if region_mode == 'dp':
+        del W['core.attention2.alpha_net.weight'], W['core.attention2.alpha_net.bias']
+    B, Lc = xt_all.shape[:2]
+    H = pre['fc'].shape[1]
+    Wr = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    prer = {k: v.clone().requires_grad_(True) for k, v in pre.items()}
+    xr = xt_all.clone().requires_grad_(True)
+    state = (torch.zeros(2, B, H, dtype=torch.float64), torch.zeros(2, B, H, dtype=torch.float64))
+    outs, atts = [], []
+    for t in range(Lc):
+        out, state, a2, _ = O.core_step(Wr, xr[:, t], dict(prer, region_attn_mode=region_mode), att_mask, pnt_masks[:, t], state)
+        outs.append(out); atts.append(a2)
+    h_ref, a_ref = torch.stack(outs, 1), torch.stack(atts, 1)
+    ((h_ref * Gh).sum() + (a_ref * Ga).sum()).backward()
+    keys = [k for k in KEYMAP if KEYMAP[k] in W]
+    Pm = [W[KEYMAP[k]].clone().requires_grad_(True) for k in keys]
+    prem = {k: v.clone().requires_grad_(True) for k, v in pre.items()}
+    xm = xt_all.clone().requires_grad_(True)
+    h, a = decoder_bwd.DecoderLoopFn.apply(att_mask, pnt_masks, (keys, ('both', region_mode)), prem['fc'], prem['conv'],
+                                           prem['p_conv'], prem['pool'], prem['p_pool'], xm, *Pm)
+    assert torch.allclose(h, h_ref, atol=1e-10) and torch.allclose(a, a_ref, atol=1e-6)
+    ((h * Gh).sum() + (a * Ga).sum()).backward()
+    for k in pre:
+        assert torch.allclose(prem[k].grad, prer[k].grad, rtol=1e-8, atol=1e-10), k
+    assert torch.allclose(xm.grad, xr.grad, rtol=1e-8, atol=1e-10)
+    for k, p in zip(keys, Pm):
+        assert torch.allclose(p.grad, Wr[KEYMAP[k]].grad, rtol=1e-8, atol=1e-10), k

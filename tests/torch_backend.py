@@ -38,8 +38,12 @@ def lstm_cell(xs, ws, h_prev, w_hh, b_ih, b_hh, c_prev, rowbias=None, gates_out=
     return h, c
 
 
-def _one_side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, logits_out=None, scores_out=None):
-    e = torch.tanh(p_feats + q.unsqueeze(1)) @ w + alpha_bias
+def _one_side(feats, p_feats, q, w, alpha_bias, att_mask=None, pnt_mask=None, logits_out=None, scores_out=None,
+              score_mode=0):
+    if score_mode == 2:                                   # 'dp' (AttModel.py:92-95)
+        e = torch.bmm(p_feats, q.unsqueeze(2)).squeeze(2)
+    else:                                                 # 'mix' / 'mix_mul' (AttModel.py:82-91)
+        e = torch.tanh(p_feats * q.unsqueeze(1) if score_mode == 1 else p_feats + q.unsqueeze(1)) @ w + alpha_bias
     if att_mask is not None:
         e = e.masked_fill(att_mask.bool(), MIN_VALUE)
     if scores_out is not None:
@@ -104,10 +108,15 @@ def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None, de_out=None, dq_out=No
         if pm is not None:
             keep &= ~pm.bool()
         de = de + d_logits * keep
-    t = torch.tanh(p_feats + q.unsqueeze(1))
-    dq = ((de.unsqueeze(2) * w) * (1 - t * t)).sum(1)
-    dw = (de.unsqueeze(2) * t).sum(1)
-    dab = de.sum(1)
+    mode = side.get('score_mode', 0)
+    if mode == 2:
+        dq = (de.unsqueeze(2) * p_feats).sum(1)
+        dw, dab = torch.zeros_like(dq), torch.zeros_like(de.sum(1))
+    else:
+        t = torch.tanh(p_feats * q.unsqueeze(1) if mode == 1 else p_feats + q.unsqueeze(1))
+        dq = ((de.unsqueeze(2) * w) * (1 - t * t) * (p_feats if mode == 1 else 1)).sum(1)
+        dw = (de.unsqueeze(2) * t).sum(1)
+        dab = de.sum(1)
     if de_out is not None:
         de = de_out.copy_(de)
     if dq_part is not None:         # left as per-chunk partials (uneven split) for sum_chunks_pair
@@ -124,11 +133,15 @@ def attn_bwd_step(side, alpha, ctx, d_ctx, d_logits=None, de_out=None, dq_out=No
     return de, dq, dw, dab
 
 
-def attn_bwd_pfeats(p_feats, q_all, de_all, w):
+def attn_bwd_pfeats(p_feats, q_all, de_all, w, score_mode=0):
     out = torch.zeros_like(p_feats)
     for t in range(q_all.shape[0]):
-        th = torch.tanh(p_feats + q_all[t].unsqueeze(1))
-        out += de_all[t].unsqueeze(2) * w * (1 - th * th)
+        qt = q_all[t].unsqueeze(1)
+        if score_mode == 2:
+            out += de_all[t].unsqueeze(2) * qt
+            continue
+        th = torch.tanh(p_feats * qt if score_mode == 1 else p_feats + qt)
+        out += de_all[t].unsqueeze(2) * w * (1 - th * th) * (qt if score_mode == 1 else 1)
     return out
 
 

@@ -21,7 +21,7 @@ path: inputs must live on the GPU.
 Supported configuration = the reference's README recipe (att_model='topdown', att_input_mode='both',
 region_attn_mode='mix', transfer_mode='cls', t_attn_mode='bigru', seq_per_img=1, enable_BUTD=False) and the other option
 values the reference itself can run: att_input_mode 'featmap' / 'region', region_attn_mode 'mix_mul' /
-'dp', transfer_mode 'none' - all but t_attn_mode='bilstm'.
+'dp', transfer_mode 'none', t_attn_mode 'bilstm'.
 """
 import math
 import os
@@ -111,12 +111,12 @@ class TopDownModel(nn.Module):
         super().__init__()
         for k, want in (('att_model', ('topdown',)), ('att_input_mode', ('both', 'featmap', 'region')),
                         ('region_attn_mode', ('mix', 'mix_mul', 'dp')),
-                        ('transfer_mode', ('cls', 'none')), ('t_attn_mode', ('bigru',)), ('seq_per_img', (1,)),
+                        ('transfer_mode', ('cls', 'none')), ('t_attn_mode', ('bigru', 'bilstm')), ('seq_per_img', (1,)),
                         ('enable_BUTD', (False,))):
             if getattr(opt, k) not in want:
                 # (profiles/r05/reference_option_survey.json: which other values the REFERENCE itself can run at its README
                 # dimensions - region_attn_mode add / cat, att_input_mode dual_region, transfer_mode glove / both raise inside
-                # misc/model.py / misc/AttModel.py; bilstm runs there and is not built here)
+                # misc/model.py / misc/AttModel.py; every value the reference runs is built here)
                 raise NotImplementedError('%s=%r: the HIP path is built for %s (the reference README recipe is the first)'
                                           % (k, getattr(opt, k), ' / '.join(repr(w) for w in want)))
         self.transfer_mode = opt.transfer_mode
@@ -175,7 +175,11 @@ class TopDownModel(nn.Module):
         self.has_obj_interact = bool(opt.obj_interact)
         if self.has_obj_interact:
             self.obj_interact = _build_obj_interact(H, H // 2, 2)
-        self.context_enc = nn.GRU(H, H // 2, 2, dropout=0.2, bidirectional=True, batch_first=True)
+        # frame-wise context encoder (opts.py:60 `--t_attn_mode`, model.py:145-154): 'bigru' (README) or 'bilstm'; the module only
+        # holds the parameters (reference names weight_ih_l0, ..._reverse) - the recurrences run in csrc/gru.hip / lstm_seq.hip
+        self.t_attn_mode = opt.t_attn_mode
+        rnn = nn.LSTM if self.t_attn_mode == 'bilstm' else nn.GRU
+        self.context_enc = rnn(H, H // 2, 2, dropout=0.2, bidirectional=True, batch_first=True)
         self.ctx2pool_grd = nn.Sequential(nn.Linear(self.att_feat_size, self.vis_encoding_size), nn.ReLU(),
                                           nn.Dropout(p))
         self._knowledge_transfer(opt)
@@ -693,8 +697,12 @@ class TopDownModel(nn.Module):
             else:
                 c = self.att_embed_aux(c.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
         if not torch.is_grad_enabled():
-            # inference: persistent cooperative HIP GRU (one launch per layer instead of ~6 per step/direction)
-            c = ops.gru_bidir_2layer(c, self.context_enc, flags=self._flags(), packed=self._packed)
+            # inference: persistent HIP recurrence (one launch per layer instead of ~6 per step/direction)
+            rnn = ops.lstm_bidir_2layer if self.t_attn_mode == 'bilstm' else ops.gru_bidir_2layer
+            c = rnn(c, self.context_enc, flags=self._flags(), packed=self._packed)
+        elif self.t_attn_mode == 'bilstm':
+            from . import lstm_fn
+            c = lstm_fn.lstm_bidir_2layer_train(c, self.context_enc, flags=self._flags())
         else:
             # training: persistent-kernel forward + hand-scheduled BPTT (gru_fn.py) instead of the library RNN
             from . import gru_fn

@@ -163,6 +163,8 @@ _SIG = {
     'gvd_grid_sync_words': (C.c_int, []),
     'gvd_gru_bidir_layer': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p]),
+    'gvd_lstm_bidir_layer': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
+                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'gvd_gru_bwd_step': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'gvd_lstm_cell_bwd': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p,

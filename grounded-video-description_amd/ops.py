@@ -989,6 +989,52 @@ def gru_layer(gi, w_f, b_f, w_b, b_b, B, T, Hh, flags=None, barrier=None):
     return out
 
 
+def lstm_seq_layer(gi, w_f, b_f, w_b, b_b, B, T, Hh, flags=None, save=False):
+    """The recurrence of one bidirectional LSTM layer as ONE persistent kernel (gvd_lstm_bidir_layer; `--t_attn_mode bilstm`,
+    model.py:145-149).  gi [B*T, 2*4*Hh] input projections of both directions (incl. b_ih) -> out [B,T,2*Hh]; save=True also
+    returns the post-activation gates [B,T,2,4*Hh] and the cell states [B,T,2,Hh] of every step (training).  `flags` receives
+    the launch's barrier-timeout words like gru_layer."""
+    require_cuda_f32(gi, w_f, b_f, w_b, b_b)
+    assert gi.is_contiguous() and w_f.is_contiguous() and w_b.is_contiguous() and b_f.is_contiguous() and b_b.is_contiguous()
+    dev = gi.device
+    out = torch.empty(B, T, 2 * Hh, device=dev, dtype=torch.float32)
+    c_state = torch.empty(B, 2, Hh, device=dev, dtype=torch.float32)
+    gates = torch.empty(B, T, 2, 4 * Hh, device=dev, dtype=torch.float32) if save else None
+    c_seq = torch.empty(B, T, 2, Hh, device=dev, dtype=torch.float32) if save else None
+    sync = torch.zeros(lib().gvd_grid_sync_words() * ((B + 255) // 256), dtype=torch.int32, device=dev)
+    if _spin_limit_env():
+        sync.view(-1, lib().gvd_grid_sync_words())[:, 33] = _spin_limit_env()
+    check(lib().gvd_lstm_bidir_layer(ptr(gi), ptr(w_f), ptr(b_f), ptr(w_b), ptr(b_b), ptr(out), ptr(c_state), ptr(gates),
+                                     ptr(c_seq), B, T, Hh, ptr(sync), stream_ptr()), 'gvd_lstm_bidir_layer')
+    lstm_seq_layer.last_sync = sync
+    if flags is not None:
+        flags.append(sync.view(-1, lib().gvd_grid_sync_words())[:, 32])
+    return (out, gates, c_seq) if save else out
+
+
+def lstm_bidir_2layer(x, lstm, flags=None, packed=None):
+    """Inference forward of the frame encoder nn.LSTM(1024, 512, 2, bidirectional, batch_first) (model.py:145-149,399): per
+    layer one MFMA GEMM for both directions' input projections + one persistent kernel for the recurrence.
+    x [B,T,1024] -> [B,T,1024].  packed: see gru_bidir_2layer."""
+    require_cuda_f32(x)
+    B, T, _ = x.shape
+    Hh = lstm.hidden_size
+    inp = x.contiguous()
+    for l in range(lstm.num_layers):
+        g = lambda n: getattr(lstm, '%s_l%d' % (n, l)).detach()
+        gr = lambda n: getattr(lstm, '%s_l%d_reverse' % (n, l)).detach()
+        stack = lambda n: (lambda: torch.cat([g(n), gr(n)], 0))
+        if packed is None:
+            w_ih, b_ih = stack('weight_ih')(), stack('bias_ih')()
+        else:
+            w_ih = packed(('lstm_w_ih', l), (g('weight_ih'), gr('weight_ih')), stack('weight_ih'))
+            b_ih = packed(('lstm_b_ih', l), (g('bias_ih'), gr('bias_ih')), stack('bias_ih'))
+        gi = gemm_nt(inp.view(B * T, -1), w_ih, b_ih)                      # [B*T, 8*Hh]
+        inp = lstm_seq_layer(gi, g('weight_hh').contiguous(), g('bias_hh').contiguous(), gr('weight_hh').contiguous(),
+                             gr('bias_hh').contiguous(), B, T, Hh, flags=flags)
+    return inp
+
+
 def gru_bwd_step(dout, gi, gh, out, carry_mm, carry_z, d_gi, d_gh, B, T, Hh, t_fw, t_bw, first):
     """One reverse step of a GRU layer's BPTT for both directions (gvd_gru_bwd_step); all tensors contiguous."""
     require_cuda_f32(dout, gi, gh, out, carry_mm, carry_z, d_gi, d_gh)

@@ -73,13 +73,14 @@ def init_state_dict(opt, seed=0, profile='default'):
             sd[p + 'feedforward.layernorm.gamma'] = 1.0 + 0.05 * torch.randn(H, generator=g)
             sd[p + 'feedforward.layernorm.beta'] = 0.05 * torch.randn(H, generator=g)
     hh = H // 2
+    ng = 4 if getattr(opt, 't_attn_mode', 'bigru') == 'bilstm' else 3      # gates per unit: nn.LSTM (model.py:145-149) / nn.GRU
     for l in range(2):
         for sfx in ('', '_reverse'):
             b = 1.0 / math.sqrt(hh)
-            sd['context_enc.weight_ih_l%d%s' % (l, sfx)] = _uniform(g, (3 * hh, H), b)
-            sd['context_enc.weight_hh_l%d%s' % (l, sfx)] = _uniform(g, (3 * hh, hh), b)
-            sd['context_enc.bias_ih_l%d%s' % (l, sfx)] = _uniform(g, (3 * hh,), b)
-            sd['context_enc.bias_hh_l%d%s' % (l, sfx)] = _uniform(g, (3 * hh,), b)
+            sd['context_enc.weight_ih_l%d%s' % (l, sfx)] = _uniform(g, (ng * hh, H), b)
+            sd['context_enc.weight_hh_l%d%s' % (l, sfx)] = _uniform(g, (ng * hh, hh), b)
+            sd['context_enc.bias_ih_l%d%s' % (l, sfx)] = _uniform(g, (ng * hh,), b)
+            sd['context_enc.bias_hh_l%d%s' % (l, sfx)] = _uniform(g, (ng * hh,), b)
     sd['ctx2pool_grd.0.weight'] = 0.01 * torch.randn(venc, F6, generator=g)
     sd['ctx2pool_grd.0.bias'] = 0.01 * torch.randn(venc, generator=g)
     b = 1.0 / math.sqrt(H)

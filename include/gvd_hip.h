@@ -326,6 +326,17 @@ int gvd_gru_bidir_layer(const float* gi, const float* w_hh_fw, const float* b_hh
                         const float* b_hh_bw, float* out, int B, int T, int Hh, void* sync_ws,
                         gvd_stream_t stream);
 
+/* `--t_attn_mode bilstm` (opts.py:60; model.py:145-149,399): one bidirectional LSTM layer of the frame-wise context encoder
+ * nn.LSTM(1024, 512, 2, bidirectional, batch_first) as a persistent kernel (csrc/lstm_seq.hip; gate order i,f,g,o).
+ * gi [B,T,2,4*Hh] = X [W_ih_fw ; W_ih_bw]^T + [b_ih_fw ; b_ih_bw] (one gvd_gemm_nt_f32 call, N = 8*Hh); out [B,T,2*Hh] =
+ * [h_fw | h_bw]; c_state [B,2,Hh]: scratch for the running cell state (any content).  Training: gates_seq [B,T,2,4*Hh]
+ * (post-activation i,f,g,o of every step) and c_seq [B,T,2*Hh] (cell state after every step, laid out like out) for the
+ * BPTT through gvd_lstm_cell_bwd; NULL at inference.  sync_ws: as gvd_gru_bidir_layer (required; zeroed by the caller;
+ * word [32] != 0 after the call = barrier timeout, results invalid).  Hh must be 512. */
+int gvd_lstm_bidir_layer(const float* gi, const float* w_hh_fw, const float* b_hh_fw, const float* w_hh_bw,
+                         const float* b_hh_bw, float* out, float* c_state, float* gates_seq, float* c_seq, int B, int T,
+                         int Hh, void* sync_ws, gvd_stream_t stream);
+
 /* One reverse step of a layer's BPTT, both directions at once (training backward of nn.GRU, model.py:150-154,399).
  * Direction 0 is at time t_fw (walking T-1..0), direction 1 at t_bw (walking 0..T-1).  gi / gh / d_gi / d_gh are
  * [B,T,2,3*Hh] (gh = h_{t-1} W_hh^T + b_hh for every step, formed by one GEMM per direction from the layer output),

@@ -101,6 +101,14 @@ CASES = {
                                        opt=dict(region_attn_mode='mix_mul')),
     'beam3_b4_v1000_ft10_dp': dict(mode='beam', B=4, V=1000, Ft=10, K=3, seed=36, profile='trained_like',
                                    opt=dict(region_attn_mode='dp')),
+    # t_attn_mode='bilstm' (opts.py:60; model.py:145-149): the frame-wise context encoder as a 2-layer bidirectional LSTM;
+    # B = 40 at the reference-default 480 frames runs two batch tiles on two workgroup groups of the persistent kernel
+    'greedy_b8_v1000_ft10_bilstm': dict(mode='sample', B=8, V=1000, Ft=10, seed=37, profile='trained_like',
+                                        opt=dict(t_attn_mode='bilstm')),
+    'greedy_b40_v1000_ft480_bilstm': dict(mode='sample', B=40, V=1000, Ft=480, seed=38, profile='trained_like',
+                                          opt=dict(t_attn_mode='bilstm')),
+    'mle_b4_v1000_ft10_bilstm': dict(mode='MLE', B=4, V=1000, Ft=10, seed=39, profile='trained_like',
+                                     opt=dict(t_attn_mode='bilstm')),
     'grd_b4_v1000_ft10_l40': dict(mode='GRD', B=4, V=1000, Ft=10, seed=18, profile='trained_like',
                                   opt=dict(seq_length=40)),
     # BASELINE configs[4]'s region count under GREEDY decode: 20 sampled frames x 100 proposals = 2000 regions (the beam

@@ -109,6 +109,41 @@ def gru_bidir_2layer(x, W, prefix='context_enc'):
                          True, 2, 0.0, False, True, True)[0]
 
 
+def lstm_bidir_2layer_loop(x, W, prefix='context_enc'):
+    """`--t_attn_mode bilstm` (opts.py:60): the explicit 2-layer bidirectional LSTM nn.LSTM(H, H/2, 2, bidirectional,
+    batch_first) of model.py:145-149,399 (zero initial state), gate order i,f,g,o; eval (no inter-layer dropout)."""
+    B, T, _ = x.shape
+    inp = x
+    for layer in range(2):
+        outs = []
+        for sfx, order in (('', range(T)), ('_reverse', range(T - 1, -1, -1))):
+            w_ih = W['%s.weight_ih_l%d%s' % (prefix, layer, sfx)]
+            w_hh = W['%s.weight_hh_l%d%s' % (prefix, layer, sfx)]
+            b_ih = W['%s.bias_ih_l%d%s' % (prefix, layer, sfx)]
+            b_hh = W['%s.bias_hh_l%d%s' % (prefix, layer, sfx)]
+            hid = w_hh.shape[1]
+            h, c = x.new_zeros(B, hid), x.new_zeros(B, hid)
+            seq = [None] * T
+            gi_all = F.linear(inp, w_ih, b_ih)
+            for t in order:
+                i, f, g, o = (gi_all[:, t] + F.linear(h, w_hh, b_hh)).chunk(4, 1)
+                c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+                h = torch.sigmoid(o) * torch.tanh(c)
+                seq[t] = h
+            outs.append(torch.stack(seq, 1))
+        inp = torch.cat(outs, 2)
+    return inp
+
+
+def lstm_bidir_2layer(x, W, prefix='context_enc'):
+    """Same function through torch's fused CPU LSTM (library op, eval mode) - used for speed at Ft = 480."""
+    hid = W[prefix + '.weight_hh_l0'].shape[1]
+    names = ['%s_l%d%s' % (n, l, sfx) for l in range(2) for sfx in ('', '_reverse')
+             for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+    z = x.new_zeros(4, x.shape[0], hid)
+    return torch._VF.lstm(x, (z, z), [W[prefix + '.' + n] for n in names], True, 2, 0.0, False, True, True)[0]
+
+
 def custom_layernorm(x, gamma, beta, eps=1e-6):
     """transformer.py:66-77: unbiased std, eps added to std (not variance)."""
     mean = x.mean(-1, keepdim=True)
@@ -262,7 +297,10 @@ def preamble(W, opt, segs_feat, num, ppls, ppls_feat, sample_idx, pnt_mask, fast
     c = F.batch_norm(c.permute(0, 2, 1).contiguous(), rm, rv, W['att_embed_aux.0.weight'],
                      W['att_embed_aux.0.bias'], bool(bn_train), 0.1, 1e-5)
     c = F.relu(c).permute(0, 2, 1).contiguous()
-    c = gru_bidir_2layer(c, W) if fast_gru else gru_bidir_2layer_loop(c, W)
+    if getattr(opt, 't_attn_mode', 'bigru') == 'bilstm':               # model.py:145-149
+        c = lstm_bidir_2layer(c, W) if fast_gru else lstm_bidir_2layer_loop(c, W)
+    else:
+        c = gru_bidir_2layer(c, W) if fast_gru else gru_bidir_2layer_loop(c, W)
     idx_mask = torch.ones(B, Ft, 1, dtype=torch.bool)
     for b in range(B):
         idx_mask[b, int(sample_idx[b, 0]):int(sample_idx[b, 1])] = False     # model.py:303-305

@@ -346,6 +346,56 @@ def test_gru_result_does_not_depend_on_the_batch_tiling():
     assert torch.equal(full, parts)
 
 
+@pytest.mark.parametrize('B,T', [(3, 10), (2, 480), (40, 37), (70, 12), (200, 9), (257, 5)])
+def test_lstm_persistent_kernel(B, T):
+    """`--t_attn_mode bilstm` (model.py:145-149): the persistent bidirectional LSTM (2 layers, csrc/lstm_seq.hip) vs the
+    oracle's explicit time-loop LSTM - one / two workgroup groups, 1 ... 8 batch tiles, a second 256-row slice; repeated
+    launches bitwise repeatable; a sample's hidden sequence does not depend on the batch it travels in."""
+    opt = gvd_amd.opts.default_opt(vocab_size=10, t_attn_mode='bilstm')
+    sd = gvd_amd.synth.init_state_dict(opt, seed=5)
+    lstm = torch.nn.LSTM(1024, 512, 2, dropout=0.2, bidirectional=True, batch_first=True)
+    lstm.load_state_dict({k[len('context_enc.'):]: v for k, v in sd.items() if k.startswith('context_enc.')})
+    x = torch.randn(B, T, 1024, generator=_g(B * T + 1))
+    with torch.no_grad():
+        ref = O.lstm_bidir_2layer_loop(x, sd)
+        lstm = lstm.cuda().eval()
+        xc = x.cuda()
+        outs, flags = [], []
+        for _ in range(3):
+            outs.append(ops.lstm_bidir_2layer(xc, lstm, flags=flags))
+        head = ops.lstm_bidir_2layer(xc[:min(B, 5)].contiguous(), lstm, flags=flags)
+        torch.cuda.synchronize()
+    assert all(int(f.sum()) == 0 for f in flags)          # no barrier timed out
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(head, outs[0][:min(B, 5)])
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize('B,T', [(4, 10), (37, 6)])
+def test_lstm_layer_autograd_matches_nn_lstm(B, T):
+    """lstm_fn.lstm_bidir_2layer_train (persistent-kernel forward that keeps gates + cell states, hand-scheduled BPTT) against
+    autograd through torch.nn.LSTM on the CPU in fp64: output, d input and every parameter gradient."""
+    from gvd_amd import lstm_fn
+    torch.manual_seed(3)
+    ref = torch.nn.LSTM(1024, 512, 2, dropout=0.0, bidirectional=True, batch_first=True)
+    mine = torch.nn.LSTM(1024, 512, 2, dropout=0.0, bidirectional=True, batch_first=True)
+    mine.load_state_dict(ref.state_dict())
+    ref, mine = ref.double(), mine.cuda()
+    x = torch.randn(B, T, 1024, generator=_g(5))
+    G = torch.randn(B, T, 1024, generator=_g(6))
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)[0]
+    (yr * G.double()).sum().backward()
+    xm = x.cuda().requires_grad_(True)
+    ym = lstm_fn.lstm_bidir_2layer_train(xm, mine)
+    (ym * G.cuda()).sum().backward()
+    np.testing.assert_allclose(ym.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=2e-5)
+    rel = lambda a, b: float((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-12))
+    assert rel(xm.grad, xr.grad) < 1e-4
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel(p.grad, q.grad) < 1e-4, (n, rel(p.grad, q.grad))
+
+
 def test_add_layernorm_unbiased():
     g = _g(11)
     x, y = torch.randn(777, 1024, generator=g), torch.randn(777, 1024, generator=g) * 0.3

@@ -162,6 +162,26 @@ def gru_layer(gi, w_f, b_f, w_b, b_b, B, T, Hh, flags=None, barrier=None):
     return out
 
 
+def lstm_seq_layer(gi, w_f, b_f, w_b, b_b, B, T, Hh, flags=None, save=False):
+    """Time loop of one bidirectional LSTM layer; gi [B*T, 2*4*Hh] -> out [B,T,2*Hh] (gate order i,f,g,o) and, with save,
+    the post-activation gates [B,T,2,4*Hh] + cell states [B,T,2,Hh]."""
+    gi = gi.view(B, T, 2, 4 * Hh)
+    out = torch.zeros(B, T, 2 * Hh, dtype=gi.dtype)
+    gates = torch.zeros(B, T, 2, 4 * Hh, dtype=gi.dtype)
+    c_seq = torch.zeros(B, T, 2, Hh, dtype=gi.dtype)
+    for d, (w, b) in enumerate(((w_f, b_f), (w_b, b_b))):
+        h, c = torch.zeros(B, Hh, dtype=gi.dtype), torch.zeros(B, Hh, dtype=gi.dtype)
+        for t in (range(T) if d == 0 else range(T - 1, -1, -1)):
+            i, f, g, o = (gi[:, t, d] + h @ w.t() + b).chunk(4, 1)
+            i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+            c = f * c + i * g
+            h = o * torch.tanh(c)
+            out[:, t, d * Hh:(d + 1) * Hh] = h
+            gates[:, t, d] = torch.cat([i, f, g, o], 1)
+            c_seq[:, t, d] = c
+    return (out, gates, c_seq) if save else out
+
+
 def gru_bwd_step(dout, gi, gh, out, carry_mm, carry_z, d_gi, d_gh, B, T, Hh, t_fw, t_bw, first):
     gi, gh = gi.view(B, T, 2, 3 * Hh), gh.view(B, T, 2, 3 * Hh)
     for d, t in ((0, t_fw), (1, t_bw)):

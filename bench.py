@@ -426,9 +426,11 @@ def _grounding_stream(ops, dev, B, M, R, K, reps=20):
                 4 * (B * R * K + B * M * K + 2 * B * M * R + B * M) + B * M * R, 'grounder_fwd')
     dm, _, dmt = ops.masked_copy_rowsum(dout, mask, want_sum=False, want_t=True)
     out['backward_d_words'] = entry('rows_contract_kernel (one read of the region tensor)',
-                                    timed(lambda: ops.rows_contract(dm, feats, S_t=dmt)), 4 * (B * R * K + B * R * 32 + B * M * K))
+                                    timed(lambda: ops.rows_contract(dm, feats, S_t=dmt)), 4 * (B * R * K + B * R * 32 + B * M * K),
+                                    'grounder_d_words')
     out['backward_d_regions'] = entry('rank_update_kernel<3> (one write of the region tensor\'s gradient)',
-                                      timed(lambda: ops.rank_update(dm, xt)), 4 * (B * R * K + B * M * R + B * M * K))
+                                      timed(lambda: ops.rank_update(dm, xt)), 4 * (B * R * K + B * M * R + B * M * K),
+                                      'grounder_d_regions')
     return out
 
 

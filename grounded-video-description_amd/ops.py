@@ -66,6 +66,30 @@ def gemm_dx(dY, W):
     return out
 
 
+def gemm_dx_small(dY, W):
+    """dX[M,K] = dY[M,N] @ W[N,K] for the shapes gemm_dx leaves (fewer than 256 output tiles: the token loop's [Lc B, .]
+    products, e.g. the vocabulary head's [1280, 5000] x [5000, 1024]) on the grouped small-M kernel (csrc/gemm_dxs.hip).  Its
+    contraction runs in 128-deep slices: N is cut into the leading multiple of 128, consumed in place, and a tail (V = 5000:
+    8 columns) copied into zero-padded [M, 128] / [128, K] operands whose product enters the main launch as its addend.
+    None = shape not taken (K not a multiple of 128, strides)."""
+    M, N = dY.shape
+    K = W.shape[1]
+    if K % 128 or N < 128 or dY.stride(1) != 1 or W.stride(1) != 1 or M < 1:
+        return None
+    N0 = N - N % 128
+    out = torch.empty(M, K, device=dY.device, dtype=torch.float32)
+    tail = None
+    if N0 < N:
+        a = dY.new_zeros(M, 128)
+        a[:, :N - N0] = dY[:, N0:]
+        w = W.new_zeros(128, K)
+        w[:N - N0] = W[N0:]
+        tail = torch.empty(M, K, device=dY.device, dtype=torch.float32)
+        dx_products([dict(A=a, W=w, out=tail)], M)
+    dx_products([dict(A=dY[:, :N0], W=W[:N0], out=out, addend=tail)], M)
+    return out
+
+
 def gemm_dw(dY, X, split=None):
     """dW[N,K] = dY[M,N]^T @ X[M,K] (backward of y = x W^T w.r.t. W): both operands K-strided; the long contraction over
     the M = B*R rows is cut into S chunks run as a batch (deterministic split-K), partial slabs summed.  None = shape not
@@ -641,6 +665,8 @@ class _LinearFn(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = gemm_dx(dy2, w.detach())                       # MFMA kernel, W in place (K-strided operand)
+            if dx is None:
+                dx = gemm_dx_small(dy2, w.detach())             # few output tiles: the grouped small-M kernel
             dx = (dy2 @ w if dx is None else dx).view_as(x)
         if ctx.needs_input_grad[1]:
             dw = gemm_dw(dy2, x2.detach()) if x2.is_contiguous() else None

@@ -111,8 +111,28 @@ def test_constructor_rejects_dimensions_the_kernels_are_not_built_for():
     for kw in (dict(rnn_size=512), dict(att_hid_size=256), dict(input_encoding_size=300), dict(seq_length=100)):
         with pytest.raises(NotImplementedError):
             att_model.TopDownModel(gvd_amd.opts.default_opt(vocab_size=50, **kw))
-    with pytest.raises(NotImplementedError):
-        att_model.TopDownModel(gvd_amd.opts.default_opt(vocab_size=50, att_input_mode='region'))
+    # option values the REFERENCE itself cannot run (profiles/r05/reference_option_survey.json) are rejected ...
+    for kw in (dict(att_input_mode='dual_region'), dict(region_attn_mode='add'), dict(region_attn_mode='cat'),
+               dict(transfer_mode='glove'), dict(transfer_mode='both'), dict(t_attn_mode='gru')):
+        with pytest.raises(NotImplementedError):
+            att_model.TopDownModel(gvd_amd.opts.default_opt(vocab_size=50, **kw))
+
+
+def test_every_option_value_the_reference_runs_constructs_with_the_reference_state_dict_layout():
+    """... and every value it CAN run is built: the module's state_dict has exactly the keys / shapes synth.init_state_dict
+    draws for that option (= the reference's layout: no alpha_net under 'dp', 4-gate recurrent weights under 'bilstm', no
+    vis_classifiers_bias under transfer_mode='none')."""
+    from gvd_amd import synth
+    for kw in (dict(att_input_mode='featmap'), dict(att_input_mode='region'), dict(region_attn_mode='mix_mul'),
+               dict(region_attn_mode='dp'), dict(t_attn_mode='bilstm'), dict(transfer_mode='none')):
+        opt = gvd_amd.opts.default_opt(vocab_size=50, **kw)
+        m = att_model.TopDownModel(opt)
+        want = synth.init_state_dict(opt, seed=1)
+        have = m.state_dict()
+        assert set(have) == set(want), (kw, set(have) ^ set(want))
+        for k in want:
+            assert have[k].shape == want[k].shape, (kw, k)
+        m.load_state_dict(want)
 
 
 def test_gt_grounding_results_and_class_accuracy():

@@ -186,6 +186,24 @@ def test_dx_products_share_one_workspace_across_shapes():
         _close(o32, want_big[:32], what='M = 32, round %d' % rnd)
 
 
+@pytest.mark.parametrize('M,N', [(1280, 5000), (80, 1000), (1280, 1024), (37, 200)])
+def test_gemm_dx_small_with_a_contraction_tail(M, N):
+    """ops.gemm_dx_small: dX = dY W for the token loop's [Lc B, .] shapes, the contraction cut into its leading multiple of 128
+    (in place) + a zero-padded tail (vocabulary head: 5000 = 39 x 128 + 8) that enters the main launch as its addend; and
+    through the nn.Linear autograd Function (ops.linear), which takes this path when the product has fewer than 256 tiles."""
+    g = _g(M + N)
+    dY = torch.randn(M, N, generator=g).cuda()
+    W = (torch.randn(N, 1024, generator=g) * 0.05).cuda()
+    got = ops.gemm_dx_small(dY, W)
+    assert got is not None
+    _close(got, (dY.double() @ W.double()).cpu(), what='dX [%d,%d]x[%d,1024]' % (M, N, N))
+    x = torch.randn(M, 1024, generator=g).cuda().requires_grad_(True)
+    w = W.clone().requires_grad_(True)
+    y = ops.linear(x, w)
+    y.backward(dY)
+    _close(x.grad, (dY.double() @ W.double()).cpu(), what='ops.linear d x')
+
+
 def test_softmax_rows_and_loss_backwards():
     g = _g(3)
     x = (torch.randn(6, 20, 1000, generator=g) * 4)

@@ -43,5 +43,17 @@ if f and w and 'FETCH_SIZE' in f and 'WRITE_SIZE' in w:
                            'traffic_over_algorithmic': round((2 * f['FETCH_SIZE'] * 1024 + w['WRITE_SIZE'] * 1024) / alg, 4),
                            'avg_duration_us_under_pmc': f.get('avg_duration_us'),
                            'source': 'separate rocprofv3 --pmc passes of tools/stream_mm_bench.py 64 5 grounder_fwd'}
+# the two backward streams of the grounder at the same shape (stream_mm_bench.py filters 'transposed S' / 'N=2048'): labels
+# gdw_fetch / gdw_write (rows_contract_kernel: d words) and gdr_fetch / gdr_write (rank_update_kernel: d regions)
+for key, lab, kernel, alg, flt in (
+        ('grounder_d_words', 'gdw', 'rows_contract_kernel', 4 * (64 * 1000 * 2048 + 64 * 1000 * 32 + 64 * 20 * 2048), 'transposed'),
+        ('grounder_d_regions', 'gdr', 'rank_update_kernel<3>', 4 * (64 * 1000 * 2048 + 64 * 20 * 1000 + 64 * 20 * 2048), 'N=2048')):
+    f, w = pmc.get(lab + '_fetch'), pmc.get(lab + '_write')
+    if f and w and 'FETCH_SIZE' in f and 'WRITE_SIZE' in w:
+        hbm = int(2 * f['FETCH_SIZE'] * 1024 + w['WRITE_SIZE'] * 1024)
+        out[key] = {'kernel': kernel, 'shape': [64, 20, 1000, 2048], 'FETCH_SIZE_KB_mean': f['FETCH_SIZE'],
+                    'WRITE_SIZE_KB_mean': w['WRITE_SIZE'], 'hbm_bytes_per_launch': hbm, 'algorithmic_bytes_per_launch': alg,
+                    'traffic_over_algorithmic': round(hbm / alg, 4), 'avg_duration_us_under_pmc': f.get('avg_duration_us'),
+                    'source': 'separate rocprofv3 --pmc passes of tools/stream_mm_bench.py 64 5 ' + flt}
 json.dump(out, open(sys.argv[2], 'w'), indent=1)
 print(json.dumps(out, indent=1))

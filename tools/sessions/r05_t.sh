@@ -22,12 +22,16 @@ pmc beam_fetch FETCH_SIZE -- python $R/tools/profile_attn.py 64 10 3 2000 5
 pmc beam_write WRITE_SIZE -- python $R/tools/profile_attn.py 64 10 3 2000 5
 pmc gfwd_fetch FETCH_SIZE -- python $R/tools/stream_mm_bench.py 64 5 grounder_fwd
 pmc gfwd_write WRITE_SIZE -- python $R/tools/stream_mm_bench.py 64 5 grounder_fwd
-python $R/tools/pmc_summary.py $O/r05t_attn_pmc.json gfwd_fetch=/tmp/pmc_gfwd_fetch:grounder_fwd_kernel gfwd_write=/tmp/pmc_gfwd_write:grounder_fwd_kernel greedy_sq=/tmp/pmc_attn_sq:attn_partial greedy_fetch=/tmp/pmc_attn_fetch:attn_partial greedy_write=/tmp/pmc_attn_write:attn_partial beam_sq=/tmp/pmc_beam_sq:attn_partial_group beam_fetch=/tmp/pmc_beam_fetch:attn_partial_group beam_write=/tmp/pmc_beam_write:attn_partial_group > /dev/null
+pmc gdw_fetch FETCH_SIZE -- python $R/tools/stream_mm_bench.py 64 5 transposed
+pmc gdw_write WRITE_SIZE -- python $R/tools/stream_mm_bench.py 64 5 transposed
+pmc gdr_fetch FETCH_SIZE -- python $R/tools/stream_mm_bench.py 64 5 N=2048
+pmc gdr_write WRITE_SIZE -- python $R/tools/stream_mm_bench.py 64 5 N=2048
+python $R/tools/pmc_summary.py $O/r05t_attn_pmc.json gdw_fetch=/tmp/pmc_gdw_fetch:rows_contract_kernel gdw_write=/tmp/pmc_gdw_write:rows_contract_kernel gdr_fetch=/tmp/pmc_gdr_fetch:rank_update_kernel gdr_write=/tmp/pmc_gdr_write:rank_update_kernel gfwd_fetch=/tmp/pmc_gfwd_fetch:grounder_fwd_kernel gfwd_write=/tmp/pmc_gfwd_write:grounder_fwd_kernel greedy_sq=/tmp/pmc_attn_sq:attn_partial greedy_fetch=/tmp/pmc_attn_fetch:attn_partial greedy_write=/tmp/pmc_attn_write:attn_partial beam_sq=/tmp/pmc_beam_sq:attn_partial_group beam_fetch=/tmp/pmc_beam_fetch:attn_partial_group beam_write=/tmp/pmc_beam_write:attn_partial_group > /dev/null
 python $R/tools/make_attn_traffic.py $O/r05t_attn_pmc.json $O/attn_traffic.json session-T > /dev/null && cp $O/attn_traffic.json $R/profiles/attn_traffic.json
 python - <<PY
 import json
 j = json.load(open('$O/attn_traffic.json'))
-for k in ('greedy', 'beam', 'grounder_fwd'):
+for k in ('greedy', 'beam', 'grounder_fwd', 'grounder_d_words', 'grounder_d_regions'):
     print(k, {a: j[k][a] for a in ('hbm_bytes_per_launch', 'traffic_over_algorithmic', 'avg_duration_us_under_pmc')})
 print('srchash', j['lib_srchash'][:12])
 PY

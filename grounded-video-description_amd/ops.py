@@ -74,8 +74,9 @@ def gemm_dx_small(dY, W):
     None = shape not taken (K not a multiple of 128, strides)."""
     M, N = dY.shape
     K = W.shape[1]
-    if K % 128 or N < 128 or dY.stride(1) != 1 or W.stride(1) != 1 or M < 1:
-        return None
+    if (K % 128 or N < 128 or dY.stride(1) != 1 or W.stride(1) != 1 or M < 1 or dY.stride(0) % 4 or W.stride(0) % 4
+            or dY.data_ptr() % 16 or W.data_ptr() % 16):
+        return None                       # (16-byte row starts: e.g. an odd vocabulary size leaves this to the library)
     N0 = N - N % 128
     out = torch.empty(M, K, device=dY.device, dtype=torch.float32)
     tail = None

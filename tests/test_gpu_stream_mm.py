@@ -202,6 +202,12 @@ def test_gemm_dx_small_with_a_contraction_tail(M, N):
     y = ops.linear(x, w)
     y.backward(dY)
     _close(x.grad, (dY.double() @ W.double()).cpu(), what='ops.linear d x')
+    # a row pitch that is not a multiple of 16 bytes (odd vocabulary size) is not this kernel's: None, and ops.linear's
+    # backward still returns the right product
+    assert ops.gemm_dx_small(dY[:, :N - 1].contiguous(), W[:N - 1]) is None
+    x2 = x.detach().clone().requires_grad_(True)
+    ops.linear(x2, w[:N - 1].detach().contiguous().requires_grad_(True)).backward(dY[:, :N - 1].contiguous())
+    _close(x2.grad, (dY[:, :N - 1].double() @ W[:N - 1].double()).cpu(), what='ops.linear d x, odd width')
 
 
 def test_softmax_rows_and_loss_backwards():

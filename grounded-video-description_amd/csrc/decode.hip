@@ -87,7 +87,9 @@ extern "C" int gvd_greedy_decode(const gvd_greedy_args* a, gvd_stream_t stream) 
   const int mode = a->att_input_mode;
   if (mode != GVD_ATT_INPUT_BOTH && mode != GVD_ATT_INPUT_FEATMAP && mode != GVD_ATT_INPUT_REGION) return GVD_EINVAL;
   const bool use_temporal = mode != GVD_ATT_INPUT_REGION;          // AttModel.py:140-141
-  const int score_mode = a->region_attn_mode;                      // AttModel.py:82-95 (checked by gvd_attn_fwd)
+  const int score_mode = a->region_attn_mode;                      // AttModel.py:82-95
+  if (score_mode < GVD_SCORE_ADD || score_mode > GVD_SCORE_DOT) return GVD_EINVAL;
+  if (score_mode != GVD_SCORE_DOT && (!a->att2_alpha_w || !a->att2_alpha_b)) return GVD_EINVAL;
   const int B = a->B, H = a->H, A = a->A, E = a->E, V = a->V, R = a->R, Ft = use_temporal ? a->Ft : 0, L = a->L;
   hipStream_t st = gvd_s(stream);
   Ws w = carve(a->workspace, B, Ft, R, H, A, E, V);

@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -159,6 +160,7 @@ static int64_t npy_read_rows(const char* path, void* dst, int64_t max_rows, int6
   }
   if (!rc) {
     const int64_t rows = rows_file < max_rows ? rows_file : max_rows;
+    bool copied = false;
     if (rows > 0 && mode == GVD_READ_MAPPED) {
       const int64_t off = hoff + hlen, len = off + rows * D * 4;
       struct stat st;
@@ -166,13 +168,14 @@ static int64_t npy_read_rows(const char* path, void* dst, int64_t max_rows, int6
       else if ((int64_t)st.st_size < len) rc = -1007;          // the header promises more rows than the file holds
       else {
         void* m = mmap(nullptr, (size_t)len, PROT_READ, MAP_SHARED, fd, 0);
-        if (m == MAP_FAILED) rc = -errno;
-        else {
+        if (m != MAP_FAILED) {            // (a file system that cannot map - ENODEV - is read with pread below)
           copy_rows(static_cast<char*>(dst), static_cast<const char*>(m) + off, rows, D * 4, dst_stride);
           munmap(m, (size_t)len);
+          copied = true;
         }
       }
-    } else if (rows > 0) {
+    }
+    if (rows > 0 && !rc && !copied) {
       const int64_t n = gvd_pread_rows(fd, hoff + hlen, dst, rows, D * 4, dst_stride);
       if (n < 0) rc = n;
       else if (n != rows * D * 4) rc = -1007;
@@ -244,7 +247,20 @@ class ReaderPool {
   uint64_t gen_ = 0;
   bool stop_ = false;
 };
-ReaderPool& reader_pool() { static ReaderPool* p = new ReaderPool(); return *p; }     // (never destroyed: no join at exit)
+// One pool per process, never destroyed (no join at exit).  A fork()ed child inherits the object but none of its threads: the
+// atfork handler drops the pointer, and the child's first batch builds a pool of its own (the parent's object is leaked there).
+std::atomic<ReaderPool*> g_pool{nullptr};
+std::once_flag g_atfork_once;
+ReaderPool& reader_pool() {
+  std::call_once(g_atfork_once, [] { pthread_atfork(nullptr, nullptr, [] { g_pool.store(nullptr, std::memory_order_relaxed); }); });
+  ReaderPool* p = g_pool.load(std::memory_order_acquire);
+  if (!p) {
+    ReaderPool* fresh = new ReaderPool();
+    if (g_pool.compare_exchange_strong(p, fresh, std::memory_order_acq_rel)) p = fresh;
+    else delete fresh;                  // another caller installed one first (that pool has no threads yet either way)
+  }
+  return *p;
+}
 }  // namespace
 
 // All feature files of ONE batch in one native call: n (path, destination) jobs handed to `n_threads` native threads that

@@ -1025,9 +1025,24 @@ def lstm_seq_layer(gi, w_f, b_f, w_b, b_b, B, T, Hh, flags=None, save=False):
     assert gi.is_contiguous() and w_f.is_contiguous() and w_b.is_contiguous() and b_f.is_contiguous() and b_b.is_contiguous()
     dev = gi.device
     out = torch.empty(B, T, 2 * Hh, device=dev, dtype=torch.float32)
-    c_state = torch.empty(B, 2, Hh, device=dev, dtype=torch.float32)
     gates = torch.empty(B, T, 2, 4 * Hh, device=dev, dtype=torch.float32) if save else None
     c_seq = torch.empty(B, T, 2, Hh, device=dev, dtype=torch.float32) if save else None
+    if not _persistent['on']:
+        # the process switched its persistent kernels off (a grid barrier timed out on a shared GPU): one fused LSTM-cell
+        # launch per (step, direction) - the decoder's cell kernel with the step's input projection as its row bias
+        gi4 = gi.view(B, T, 2, 4 * Hh)
+        zero = torch.zeros(B, Hh, device=dev, dtype=torch.float32)
+        for d, (w, b) in enumerate(((w_f, b_f), (w_b, b_b))):
+            h_prev, c_prev = zero, zero
+            cbuf = [torch.empty(B, Hh, device=dev, dtype=torch.float32) for _ in range(2)]
+            for i in range(T):
+                t = i if d == 0 else T - 1 - i
+                h_prev, c_prev = lstm_cell([], [], h_prev, w, None, b, c_prev, rowbias=gi4[:, t, d],
+                                           gates_out=gates[:, t, d] if save else None, h_out=out[:, t, d * Hh:(d + 1) * Hh],
+                                           c_out=c_seq[:, t, d] if save else cbuf[i & 1])
+        lstm_seq_layer.last_sync = None
+        return (out, gates, c_seq) if save else out
+    c_state = torch.empty(B, 2, Hh, device=dev, dtype=torch.float32)
     sync = torch.zeros(lib().gvd_grid_sync_words() * ((B + 255) // 256), dtype=torch.int32, device=dev)
     if _spin_limit_env():
         sync.view(-1, lib().gvd_grid_sync_words())[:, 33] = _spin_limit_env()

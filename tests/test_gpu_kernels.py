@@ -371,6 +371,26 @@ def test_lstm_persistent_kernel(B, T):
     np.testing.assert_allclose(outs[0].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=5e-5)
 
 
+def test_lstm_layer_without_the_persistent_kernel(monkeypatch):
+    """After a grid-barrier timeout the process runs without its persistent kernels (ops._persistent): the bilstm layer is then
+    one fused LSTM-cell launch per (step, direction) - same outputs, saved gates and cell states as the persistent kernel
+    within fp32 summation-order noise."""
+    opt = gvd_amd.opts.default_opt(vocab_size=10, t_attn_mode='bilstm')
+    sd = gvd_amd.synth.init_state_dict(opt, seed=5)
+    g = lambda n: sd['context_enc.' + n].cuda().contiguous()
+    B, T, Hh = 37, 9, 512
+    gi = (torch.randn(B * T, 8 * Hh, generator=_g(9)) * 0.5).cuda()
+    args = (gi, g('weight_hh_l0'), g('bias_hh_l0'), g('weight_hh_l0_reverse'), g('bias_hh_l0_reverse'), B, T, Hh)
+    a = ops.lstm_seq_layer(*args, save=True)
+    monkeypatch.setitem(ops._persistent, 'on', False)
+    b = ops.lstm_seq_layer(*args, save=True)
+    c = ops.lstm_seq_layer(*args)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=1e-4, atol=2e-5)
+    assert torch.equal(c, b[0])
+
+
 @pytest.mark.parametrize('B,T', [(4, 10), (37, 6)])
 def test_lstm_layer_autograd_matches_nn_lstm(B, T):
     """lstm_fn.lstm_bidir_2layer_train (persistent-kernel forward that keeps gates + cell states, hand-scheduled BPTT) against

@@ -191,3 +191,40 @@ def test_default_reader_threads_follow_the_cpu_budget(monkeypatch):
     assert ingest.cpu_budget() == 16.0 and ingest.default_workers() == 12
     monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(4)))
     assert ingest.cpu_budget() == 4.0 and ingest.default_workers() == 2
+
+
+def test_reader_pool_survives_a_fork(tmp_path):
+    """The native reader threads are created once per process; a fork()ed child inherits the pool object but none of its
+    threads.  The child's first batch must build its own pool instead of waiting for helpers that do not exist there."""
+    import ctypes
+    from gvd_amd import hip
+    a = np.arange(64 * 8, dtype=np.float32).reshape(64, 8)
+    n = 6
+    for i in range(n):
+        np.save(tmp_path / ('f%d.npy' % i), a + i)
+
+    def read_batch():
+        lib = hip.lib()
+        dst = [np.zeros((64, 8), np.float32) for _ in range(n)]
+        paths = (ctypes.c_char_p * n)(*[str(tmp_path / ('f%d.npy' % i)).encode() for i in range(n)])
+        dsts = (ctypes.c_void_p * n)(*[d.ctypes.data for d in dst])
+        caps = (ctypes.c_int64 * n)(*([64] * n))
+        Ds = (ctypes.c_int64 * n)(*([8] * n))
+        strides = (ctypes.c_int64 * n)(*([32] * n))
+        rr, rf = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)()
+        failed = lib.gvd_npy_read_batch_f32(paths, dsts, caps, Ds, strides, n, 4, 1, rr, rf, None)
+        return failed == 0 and all(np.array_equal(d, a + i) for i, d in enumerate(dst))
+
+    assert read_batch()                       # the parent's pool now has threads
+    pid = os.fork()
+    if pid == 0:
+        ok = False
+        try:
+            import signal
+            signal.alarm(30)                  # a child that waits for threads it does not have must not hang the suite
+            ok = read_batch()
+        finally:
+            os._exit(0 if ok else 1)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+    assert read_batch()                       # and the parent's pool is untouched

@@ -210,7 +210,8 @@ class TopDownModel(nn.Module):
         reference (which raises FileNotFoundError) a missing directory leaves the default initialisation in place —
         checkpoints overwrite these tensors anyway — and says so once."""
         d = os.path.join('data', 'detectron_weights')
-        names = ('fc7_w', 'fc7_b', 'cls_score_w', 'cls_score_b')
+        # transfer_mode='none' reads only the fc7 pair (model.py:173-180,214-215); the class-score pair belongs to 'cls'
+        names = ('fc7_w', 'fc7_b') + (('cls_score_w', 'cls_score_b') if self.transfer_mode == 'cls' else ())
         if not all(os.path.exists(os.path.join(d, n + '.pkl')) for n in names):
             if not getattr(TopDownModel, '_warned_no_transfer', False):
                 print('TopDownModel: %s/*.pkl not found - no Detectron knowledge transfer (model.py:173-216); '

@@ -200,6 +200,7 @@ class ReaderPool {
  public:
   template <typename F> void run(int helpers, F& work) {
     std::unique_lock<std::mutex> call(call_mu_);              // one batch at a time
+    if (helpers < 0) helpers = 0;                             // (done_ counts up from 0: a negative target would never be met)
     if (helpers > (int)threads_.size()) grow(helpers);
     {
       std::lock_guard<std::mutex> g(mu_);
@@ -275,6 +276,7 @@ extern "C" int gvd_npy_read_batch_f32(const char* const* paths, void* const* dst
                                       const int64_t* dst_stride, int n, int n_threads, int mode, int64_t* rows_read,
                                       int64_t* rows_file, int64_t* job_ns) {
   if (!paths || !dsts || !max_rows || !D || !dst_stride || !rows_read || !rows_file || n < 0 || (mode != GVD_READ_PREAD && mode != GVD_READ_MAPPED)) return -EINVAL;
+  if (n == 0) return 0;                     // empty batch: nothing to read (and no pooled thread to wait for)
   std::atomic<int> next(0), failed(0);
   auto work = [&]() {
     for (;;) {

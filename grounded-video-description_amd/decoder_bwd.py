@@ -70,7 +70,7 @@ class DecoderLoopFn(torch.autograd.Function):
         H = fc.shape[1]
         A = p_pool.shape[2]
         # att_input_mode (AttModel.py:140-151).  'region': no frame-wise side - its scores, queries and parameters get no
-        # gradient (zeros where the reference leaves .grad = None).  'featmap': the region context is not an input of the
+        # gradient (None, like the reference's .grad = None).  'featmap': the region context is not an input of the
         # language LSTM - the region side's d_ctx is zero (its scores still carry the grounding losses' gradient) and the
         # region features get a gradient through the projection only
         mode, region_mode = ctx.mode if isinstance(ctx.mode, tuple) else (ctx.mode, 'mix')
@@ -190,6 +190,11 @@ class DecoderLoopFn(torch.autograd.Function):
         g['conv'] = ru(alpha_t, dctx_b) if use_t else None
         g['p_pool'] = K.attn_bwd_pfeats(p_pool, S['q12'][:, :, A:], de_r_all, a2_aw, score_mode=sm)
         g['p_conv'] = K.attn_bwd_pfeats(p_conv, S['q12'][:, :, :A], de_t_all, a1_aw) if use_t else None
+        if not use_t:
+            # 'region': the frame-wise attention module is never called - the reference leaves its parameters' .grad = None (an
+            # optimiser with weight decay skips them, its state holds no entry for them): None here too, not zeros
+            for k in ('a1_w', 'a1_b', 'a1_aw', 'a1_ab'):
+                g[k] = None
         ctx.save = None
         names = ['fc', 'conv', 'p_conv', 'pool', 'p_pool', 'xt_all'] + list(ctx.keys)
         out = [None, None, None]

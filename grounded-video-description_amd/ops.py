@@ -381,7 +381,8 @@ def attention_step(region, temporal, want_separate=False, out=None, cr_out=None,
     if want_separate:
         cr = torch.empty(B, H, device=f.device, dtype=torch.float32) if cr_out is None else cr_out
         if st is not None:
-            ct = torch.empty(B, H, device=f.device, dtype=torch.float32) if ct_out is None else ct_out
+            # ('featmap': `out` IS the frame-wise context - a separate copy only where the caller asked for one by name)
+            ct = ct_out if (ct_out is not None or not sum_region) else torch.empty(B, H, device=f.device, dtype=torch.float32)
     assert out.stride(-1) == 1 and out.shape == (B, H) and all(t is None or t.is_contiguous() for t in (cr, ct))
     prof = _kernel_timer.h if _kernel_timer is not None else None
     if not sum_region:

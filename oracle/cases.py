@@ -74,6 +74,13 @@ CASES = {
     # profiles/r05/reference_grad_noise.txt)
     'mle_b4_v1000_ft10_tnone': dict(mode='MLE', B=4, V=1000, Ft=10, seed=25, profile='trained_like',
                                     opt=dict(transfer_mode='none')),
+    # ... and the seed-24 case ITSELF stays under test: next to the reference's fp32 gradient the fixture holds
+    # the fp64 gradient of the same graph (`f64_grads`: the oracle in double precision - the oracle is pinned bit for bit
+    # against the reference in fp32, tests/test_oracle_vs_reference.py).  The test holds every parameter to the fp32
+    # reference; where that fails it demands agreement with the fp64 value AND that the fp32 reference itself is as far
+    # from fp64 as the observed miss (the reference's own rounding, not a routing error)
+    'mle_b4_v1000_ft10_tnone_s24': dict(mode='MLE', B=4, V=1000, Ft=10, seed=24, profile='trained_like',
+                                        opt=dict(transfer_mode='none'), f64_grads=True),
     # att_input_mode (opts.py:58; AttModel.py:140-151): what the language LSTM is fed - 'featmap' the frame-wise context
     # alone (the region attention still produces the grounding logits), 'region' the region context alone (no frame-wise
     # encoder / attention at all, model.py:393,406-409)
@@ -121,6 +128,8 @@ CASES = {
     # a TRAJECTORY of main.train: four optimisation steps (clip 0.1, Adam with the two learning-rate groups, eval-mode
     # arithmetic) on four different batches - the losses and the pre-clip gradient norm of every step (steps 2.. see the
     # parameters the earlier steps produced) and the direction of the accumulated parameter change
+    # (+ the optimiser STATE after the last step, straight from the reference's torch.optim.Adam: state['step'], norms and
+    # seeded projections of exp_avg / exp_avg_sq per parameter, the per-step update norms)
     'traj4_b4_v1000_ft10_trained': dict(mode='traj', B=4, V=1000, Ft=10, seed=21, profile='trained_like', steps=4),
 }
 

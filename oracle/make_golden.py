@@ -108,6 +108,22 @@ def run_case(name):
                     projs.append(cases.grad_projections(n, p.grad))
             out.update(grad_names=np.array(names), grad_norms=np.array(norms, dtype=np.float64),
                        grad_proj=np.array(projs, dtype=np.float64))
+            if spec.get('f64_grads'):
+                # the fp64 value of the same gradient (the oracle in double precision; tools/reference_grad_noise.py): lets a
+                # consumer tell the reference's own fp32 rounding (a ReLU unit on the other side of zero) from an error
+                from oracle import gvd_oracle as O
+                torch.set_default_dtype(torch.float64)
+                try:
+                    W = {k: (v.double().clone().requires_grad_('running' not in k) if v.is_floating_point() else v)
+                         for k, v in sd.items()}
+                    a64 = [inp[k].double() if inp[k].is_floating_point() else inp[k] for k in pkg.synth.FORWARD_ORDER]
+                    l64 = O.forward_train(W, opt, *a64)
+                    (l64[0] + w['w_att2'] * l64[1] + w['w_grd'] * l64[2] + w['w_cls'] * l64[3]).backward()
+                finally:
+                    torch.set_default_dtype(torch.float32)
+                out.update(grad_norms_f64=np.array([float(W[n].grad.norm()) for n in names], dtype=np.float64),
+                           grad_proj_f64=np.array([cases.grad_projections(n, W[n].grad.float()) for n in names], dtype=np.float64),
+                           losses_f64=np.array([float(x) for x in l64[:4]], dtype=np.float64))
             if spec.get('bn_train'):     # the batch-statistics pass also moved the running statistics (momentum 0.1)
                 bn = dict(ref.named_buffers())
                 out.update(bn_running_mean=bn['att_embed_aux.0.running_mean'].numpy().copy(),
@@ -182,25 +198,39 @@ def run_case(name):
                             'weight_decay': 0, 'betas': (0.9, 0.999)}]
         optimizer = torch.optim.Adam(params)
         before = {n: p.detach().clone() for n, p in ref.named_parameters()}
-        losses, norms = [], []
+        losses, norms, step_dn = [], [], []
         for batch in cases.traj_batches(name):
             lm, a2, gl, cl = ref(*pkg.synth.as_args(batch), 'MLE')
             loss = (lm.sum() + w['w_att2'] * a2.sum() + w['w_grd'] * gl.sum() + w['w_cls'] * cl.sum()) / lm.numel()
             ref.zero_grad()
             loss.backward()
             norms.append(float(torch.nn.utils.clip_grad_norm_(ref.parameters(), clip)))
+            prev = {n: p.detach().clone() for n, p in ref.named_parameters() if p.grad is not None}
             optimizer.step()
+            # norm of THIS step's whole update (all parameters): the bias-corrected step size of every step, not only their sum
+            step_dn.append(float(torch.sqrt(sum(((p.detach() - prev[n]).double() ** 2).sum() for n, p in ref.named_parameters()
+                                                 if n in prev))))
             losses.append([lm.item(), a2.item(), gl.item(), cl.item()])
             print('   step %d  %.1fs  losses %s  |grad| %.5f' % (len(losses), time.time() - t0, losses[-1], norms[-1]), flush=True)
         names, dn, dp = [], [], []
+        mn, mp, vn, vp, st = [], [], [], [], []
         for n, p in ref.named_parameters():
             if p.grad is None:
                 continue
             names.append(n)
             dn.append(float((p.detach() - before[n]).double().norm()))
             dp.append(cases.grad_projections(n, p.detach() - before[n]))
+            # the optimiser state after the last step (main.py:660-677's torch.optim.Adam): step count, first / second moment
+            s_ = optimizer.state[p]
+            st.append(float(s_['step']))
+            mn.append(float(s_['exp_avg'].double().norm())); mp.append(cases.grad_projections(n, s_['exp_avg']))
+            vn.append(float(s_['exp_avg_sq'].double().norm())); vp.append(cases.grad_projections(n, s_['exp_avg_sq']))
         out.update(step_losses=np.array(losses, dtype=np.float32), step_grad_norms=np.array(norms, dtype=np.float64),
                    step_names=np.array(names), delta_norms=np.array(dn), delta_proj=np.array(dp, dtype=np.float64),
+                   step_delta_norms=np.array(step_dn, dtype=np.float64),
+                   state_steps=np.array(st, dtype=np.float64), exp_avg_norms=np.array(mn, dtype=np.float64),
+                   exp_avg_proj=np.array(mp, dtype=np.float64), exp_avg_sq_norms=np.array(vn, dtype=np.float64),
+                   exp_avg_sq_proj=np.array(vp, dtype=np.float64),
                    losses=np.array(losses[0], dtype=np.float32))
     elif spec['mode'] == 'GRD':
         with torch.no_grad():

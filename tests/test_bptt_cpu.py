@@ -85,7 +85,8 @@ def test_bptt_matches_autograd_through_oracle(fake_kernels, per_step):
 def test_bptt_att_input_modes_match_autograd_through_oracle(fake_kernels, mode):
     """att_input_mode (opts.py:58, AttModel.py:140-151): 'featmap' feeds the frame-wise context alone to the language LSTM
     (the region attention still produces the grounding logits, so the region side gets a gradient through its scores only),
-    'region' has no frame-wise side at all (its parameters: zero gradient here, None in autograd)."""
+    'region' has no frame-wise side at all (its parameters: no gradient - None here as in autograd, so that an optimiser with
+    weight decay skips them like the reference's does)."""
     W, pre, xt_all, att_mask, pnt_masks, Gh, Ga = _problem(5, per_step=True)
     B, Lc = xt_all.shape[:2]
     H = pre['fc'].shape[1]
@@ -121,7 +122,7 @@ def test_bptt_att_input_modes_match_autograd_through_oracle(fake_kernels, mode):
     for k, p in zip(keys, Pm):
         want = Wr[KEYMAP[k]].grad
         if want is None:                                    # the frame-wise attention's parameters under 'region'
-            assert mode == 'region' and k.startswith('a1_') and zero(p.grad), k
+            assert mode == 'region' and k.startswith('a1_') and p.grad is None, k        # None like the reference, not zeros
         else:
             assert torch.allclose(p.grad, want, rtol=1e-8, atol=1e-10), k
 

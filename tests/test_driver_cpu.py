@@ -107,6 +107,33 @@ def test_constructor_equals_reference_constructor_under_the_same_seed():
     assert float(osd['ctx2pool_grd.0.weight'].abs().max()) < 0.1 and float(osd['vis_embed.0.weight'].abs().max()) < 0.1
 
 
+def test_transfer_mode_none_needs_only_the_fc7_pickles(tmp_path):
+    """model.py:173-180,214-215: under transfer_mode='none' the reference reads fc7_w / fc7_b and nothing else - a setup that
+    ships only that pair must still initialise `ctx2pool_grd` from it (it used to be skipped without all four pickles)."""
+    import pickle
+    import numpy as np
+    d = tmp_path / 'data' / 'detectron_weights'
+    d.mkdir(parents=True)
+    rng = np.random.default_rng(2)
+    fc7_w = (rng.standard_normal((2048, 2048)) * 0.01).astype(np.float32)
+    fc7_b = (rng.standard_normal(2048) * 0.01).astype(np.float32)
+    for n, a in (('fc7_w', fc7_w), ('fc7_b', fc7_b)):
+        with open(d / (n + '.pkl'), 'wb') as f:
+            pickle.dump(a, f)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        m = att_model.TopDownModel(gvd_amd.opts.default_opt(vocab_size=50, transfer_mode='none'))
+        # 'cls' still needs the class-score pair: without it the default initialisation stays
+        att_model.TopDownModel._warned_no_transfer = True
+        c = att_model.TopDownModel(gvd_amd.opts.default_opt(vocab_size=50, transfer_mode='cls'))
+    finally:
+        os.chdir(cwd)
+    assert np.array_equal(m.ctx2pool_grd[0].weight.detach().numpy(), fc7_w)
+    assert np.array_equal(m.ctx2pool_grd[0].bias.detach().numpy(), fc7_b)
+    assert m.matched_cls is None and not np.array_equal(c.ctx2pool_grd[0].weight.detach().numpy(), fc7_w)
+
+
 def test_constructor_rejects_dimensions_the_kernels_are_not_built_for():
     for kw in (dict(rnn_size=512), dict(att_hid_size=256), dict(input_encoding_size=300), dict(seq_length=100)):
         with pytest.raises(NotImplementedError):

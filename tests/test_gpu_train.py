@@ -89,18 +89,33 @@ ELEM_TOL = 3e-3
 NOISE = 1e-6
 
 
-def _check_projections(named_grads, names, norms, projs, what='grad'):
+def _check_projections(named_grads, names, norms, projs, what='grad', f64=None):
+    """f64 = (norms, projections) of the fp64 value of the same gradients (cases with `f64_grads`): a parameter that misses the
+    fp32 reference must then (i) agree with the fp64 value within the same bound and (ii) be explained by the reference's OWN
+    distance from fp64 (its fp32 rounding - a ReLU pre-activation on the other side of zero - not a routing error); the
+    exceptions are returned so that the caller can assert which ones it expects."""
     gmax = float(max(norms))
     worst = (0.0, None)
-    for n, want_norm, want_proj in zip(names, norms, projs):
+    excused = {}
+    for i, (n, want_norm, want_proj) in enumerate(zip(names, norms, projs)):
         g = named_grads[n]
         assert g is not None, n
         if want_norm <= NOISE * gmax:
             continue
         err = cases.projection_error(n, g, want_proj, want_norm)
+        if err >= PROJ_TOL and f64 is not None:
+            err64 = cases.projection_error(n, g, f64[1][i], f64[0][i])
+            ref_vs_64 = float(np.sqrt(((np.asarray(f64[1][i]) - np.asarray(want_proj)) ** 2).mean())) / float(want_norm)
+            assert err64 < PROJ_TOL, '%s: %s off the fp32 reference by %.3g AND off the fp64 value by %.3g' % (n, what, err, err64)
+            assert ref_vs_64 > 0.5 * err, '%s: %s off the fp32 reference by %.3g, which itself is only %.3g from fp64' % (n, what, err, ref_vs_64)
+            excused[n] = (err, err64, ref_vs_64)
+            continue
         worst = max(worst, (err, n))
         assert err < PROJ_TOL, '%s: %s projections off by %.3g x |reference| (direction / routing error?)' % (n, what, err)
     print('worst %s projection error %.3g (%s)' % (what, worst[0], worst[1]))
+    for n, e in excused.items():
+        print('%s: %.3g from the fp32 reference, %.3g from fp64; the fp32 reference itself is %.3g from fp64' % ((n,) + e))
+    return excused
 
 
 @pytest.mark.parametrize('name', GRAD_CASES)
@@ -141,7 +156,11 @@ def test_mle_gradients_match_reference(name, golden_dir):
         rel = abs(got - want) / max(want, 1e-3)
         worst = max(worst, rel)
         assert rel < 2e-3, '%s: |grad| %.6g vs reference %.6g' % (n, got, want)
-    _check_projections({n: params[n].grad for n in names}, names, g['grad_norms'], g['grad_proj'])
+    f64 = (g['grad_norms_f64'], g['grad_proj_f64']) if spec.get('f64_grads') else None
+    excused = _check_projections({n: params[n].grad for n in names}, names, g['grad_norms'], g['grad_proj'], f64=f64)
+    # (seed 24 of the transfer_mode='none' case: the reference's fp32 gradient of the fc7 layer is 0.93 % from its fp64 value;
+    # nothing else may need the fp64 excuse)
+    assert set(excused) <= {'ctx2pool_grd.0.weight', 'ctx2pool_grd.0.bias'}, excused
     for n in ('core.i2h_2.weight', 'core.h2h_2.weight'):
         assert params[n].grad is None or float(params[n].grad.abs().sum()) == 0.0
     if 'att_input_mode' in spec.get('opt', {}):
@@ -273,6 +292,10 @@ def test_one_optimisation_step_matches_reference(name, golden_dir):
 
 
 TRAJ_CASES = [n for n, s in cases.CASES.items() if s['mode'] == 'traj']
+# bounds of the optimiser-state pins after step 4 (measured values: see the test's printout in profiles/r06/)
+M_NORM_TOL, M_PROJ_TOL = 2e-2, 3e-2
+V_NORM_TOL, V_PROJ_TOL = 3e-2, 3e-2
+STEP_DN_TOL = 2e-2
 
 
 @pytest.mark.parametrize('name', TRAJ_CASES)
@@ -304,8 +327,11 @@ def test_optimisation_trajectory_matches_reference(name, golden_dir):
     tr = train.Trainer(model, opt)
     before = {n: p.detach().clone() for n, p in model.named_parameters()}
     worst = 0.0
+    step_dn = []
     for i, batch in enumerate(cases.traj_batches(name)):
+        prev = [p.detach().clone() for p in model.parameters()]
         losses = tr.step(synth.as_args(batch, 'cuda')).cpu().numpy()
+        step_dn.append(float(torch.sqrt(sum(((p.detach() - q).double() ** 2).sum() for p, q in zip(model.parameters(), prev)))))
         d = float(np.abs(losses - g['step_losses'][i]).max())
         worst = max(worst, d)
         print('step %d: |loss - reference| %s' % (i + 1, ['%.2e' % x for x in np.abs(losses - g['step_losses'][i])]))
@@ -322,6 +348,33 @@ def test_optimisation_trajectory_matches_reference(name, golden_dir):
             continue                      # (parameters whose gradient is rounding noise: Adam moves them by +-lr either way)
         err = cases.projection_error(n, params[n].detach() - before[n], g['delta_proj'][i], dn)
         assert err < 0.1, '%s: accumulated update off by %.3g x |reference update|' % (n, err)
+    # ---- the optimiser STATE after step 4, against the reference's own torch.optim.Adam (main.py:660-677): the step count of
+    # every parameter (exact), the first moment (linear in the four clipped gradients: carries their direction error, ~1e-3
+    # at step 1, and the drift of steps 2..4) and the second moment (quadratic: dominated by the large entries, the most
+    # robust of the three) as norm + seeded projections; and the norm of EVERY step's whole update (the bias-corrected step
+    # size lr * m_hat / (sqrt(v_hat) + eps) of steps 1..4 - a wrong bias-correction count at step t changes it by
+    # (1 - b1^t') / (1 - b1^t) * sqrt((1 - b2^t) / (1 - b2^t')): 23 % between t = 2 and t' = 1, 12 % between 4 and 3)
+    st = tr.optimizer.state
+    big_m, big_v = float(max(g['exp_avg_norms'])), float(max(g['exp_avg_sq_norms']))
+    worst_m = worst_v = (0.0, None)
+    for i, n in enumerate(names):
+        s_ = st[params[n]]
+        assert float(s_['step']) == float(g['state_steps'][i]) == 4.0, (n, float(s_['step']))
+        mn, vn = float(g['exp_avg_norms'][i]), float(g['exp_avg_sq_norms'][i])
+        if mn > 1e-3 * big_m:
+            em = cases.projection_error(n, s_['exp_avg'], g['exp_avg_proj'][i], mn)
+            worst_m = max(worst_m, (em, n))
+            assert abs(float(s_['exp_avg'].double().norm()) - mn) <= M_NORM_TOL * mn, (n, float(s_['exp_avg'].double().norm()), mn)
+            assert em < M_PROJ_TOL, '%s: exp_avg off by %.3g x |reference exp_avg|' % (n, em)
+        if vn > 1e-6 * big_v:
+            ev = cases.projection_error(n, s_['exp_avg_sq'], g['exp_avg_sq_proj'][i], vn)
+            worst_v = max(worst_v, (ev, n))
+            assert abs(float(s_['exp_avg_sq'].double().norm()) - vn) <= V_NORM_TOL * vn, (n, float(s_['exp_avg_sq'].double().norm()), vn)
+            assert ev < V_PROJ_TOL, '%s: exp_avg_sq off by %.3g x |reference exp_avg_sq|' % (n, ev)
+    print('optimiser state after step 4: worst exp_avg projection error %.3g (%s), exp_avg_sq %.3g (%s)' % (worst_m + worst_v))
+    for i, (got, want) in enumerate(zip(step_dn, g['step_delta_norms'])):
+        print('step %d: |update| %.6g vs reference %.6g (%.3g)' % (i + 1, got, want, abs(got - want) / want))
+        assert abs(got - want) <= STEP_DN_TOL * want, (i, got, want)
 
 
 def test_train_steps_reduce_loss():

@@ -162,6 +162,11 @@ def test_native_batch_reader_modes(tmp_path, mode):
             assert np.array_equal(dst[i][:k, :D], a[:k])
             assert np.all(dst[i][:k, D:] == -7.0) and np.all(dst[i][k:] == -7.0)      # nothing outside the rows it was given
     assert lib.gvd_npy_read_batch_f32(paths, dsts, caps, Ds, strides, n, 2, 7, rows_read, rows_file, None) == -errno.EINVAL
+    # the empty batch returns at once (it used to wait for -1 pooled threads forever, holding the pool's call lock) and
+    # leaves the pool usable
+    for n_threads in (0, 1, 4):
+        assert lib.gvd_npy_read_batch_f32(paths, dsts, caps, Ds, strides, 0, n_threads, mode, rows_read, rows_file, None) == 0
+    assert lib.gvd_npy_read_batch_f32(paths, dsts, caps, Ds, strides, n, 2, mode, rows_read, rows_file, None) == len(bad)
 
 
 def test_read_mode_selection(dataset, monkeypatch):

@@ -185,6 +185,19 @@ def test_optimisation_trajectory_matches_reference(name, golden_dir):
         got = np.array([float(lm), float(a2), float(gl), float(cl)])
         np.testing.assert_allclose(got, g['step_losses'][i], atol=1e-4)
         assert abs(total - float(g['step_grad_norms'][i])) / float(g['step_grad_norms'][i]) < 1e-3
+    # the optimiser STATE after the last step against the reference's own torch.optim.Adam (main.py:660-677): step counts,
+    # first and second moments (norm + seeded projections)
+    big_m, big_v = float(max(g['exp_avg_norms'])), float(max(g['exp_avg_sq_norms']))
+    for k, n in enumerate(str(x) for x in g['step_names']):
+        st = optim.state[W[n]]
+        assert float(st['step']) == float(g['state_steps'][k]) == len(g['step_losses']), n
+        mn, vn = float(g['exp_avg_norms'][k]), float(g['exp_avg_sq_norms'][k])
+        if mn > 1e-6 * big_m:
+            assert abs(float(st['exp_avg'].double().norm()) - mn) <= 2e-3 * mn, n
+            assert cases.projection_error(n, st['exp_avg'], g['exp_avg_proj'][k], mn) < 2e-3, n
+        if vn > 1e-9 * big_v:
+            assert abs(float(st['exp_avg_sq'].double().norm()) - vn) <= 4e-3 * vn, n
+            assert cases.projection_error(n, st['exp_avg_sq'], g['exp_avg_sq_proj'][k], vn) < 4e-3, n
 
 
 def test_gru_loop_matches_fused():

@@ -30,6 +30,9 @@ sys.path.insert(0, ROOT)
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL / tensor sharing fail with the legacy mode); the driver's
 # environment exports it already - keep it for any environment this script is launched from
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+# every product / softmax of the path that would leave libgvd_hip.so for a torch library op raises instead of running
+# (ops.library_fallback); the line reports the count of such calls as "library_gemms" (0, or the run would have failed)
+os.environ.setdefault('GVD_STRICT', '1')
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -332,10 +335,14 @@ def _roofline_mfma(hip, run, steps, label):
     if not n or ms <= 0:
         return None
     ach = flops / (ms * 1e-3) / 1e12
+    # per shape (live rows, N, K, batch, forward / dX / dW): which products pull the aggregate down
+    table = prof.table(MFMA_F32_PEAK_TFS)
+    for r in table:
+        r['launches'] //= steps
     return {'bound': 'mfma', 'kernel': 'gemm_pipe_kernel (every fp32-MFMA product with >= 256 tiles: %s)' % label,
             'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TFS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_F32_PEAK_TFS, 4),
             'traffic': None, 'flops_per_step': flops / steps, 'gemm_ms_per_step': round(ms / steps, 3),
-            'launches_per_step': n // steps, 'steps_measured': steps}
+            'launches_per_step': n // steps, 'steps_measured': steps, 'per_shape': table}
 
 
 def section_train_b64(dev, n_steps=4, cpu_seconds=0.0):
@@ -791,6 +798,8 @@ def bench_train(args, opt, sd, model, B, rank, world, dev):
                                             'attn_partial_kernel (forward region+temporal attention of the teacher-forced loop)',
                                             fetched_bytes=_attn_fetched_bytes(inp['pnt_mask'][:, 1:], Ft, A, H)),
             'cpu_baseline': _cpu_baseline_or_pointer(args, world, lambda: cpu_baseline_train(opt, sd, args.cpu_seconds))}
+        out['library_gemms'] = ops.library_call_count()     # calls that left libgvd_hip.so for a torch library op (GVD_STRICT: 0)
+        out['config']['strict'] = bool(ops.STRICT)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
@@ -855,9 +864,18 @@ def main():
         if use_dist:
             dist.barrier()
 
+    # the timed region goes through the PUBLIC entry point main.py calls (main.py:353-358): model(segs_feat, seq, gt_seq, num,
+    # ppls, gt_boxes, mask_boxes, ppls_feat, frm_mask, sample_idx, pnt_mask, 'sample', eval_opt) with the [B] dummies of
+    # main.py:353 - it includes the call's one device->host read of the kernel status words
+    dummy = torch.zeros(B, dtype=torch.uint8, device=dev)
+
+    def fwd_args(d, beam=None):
+        return (d[0], dummy, dummy, d[2], d[1], dummy, dummy, d[3], dummy, d[4], d[5], 'sample',
+                {'sample_max': 1, 'beam_size': args.beam if beam is None else beam})
+
     with torch.no_grad():
         for _ in range(args.warmup):
-            model._sample(*dinp, {'beam_size': args.beam})
+            model(*fwd_args(dinp))
         torch.cuda.synchronize()
         barrier()
         model.kernel_timer = timer
@@ -890,21 +908,21 @@ def main():
                 if i + 1 < args.steps:
                     start_copy(k ^ 1)
                 comp.wait_event(ready[k])
-                seq, lps, att2, sim = model._sample(*dev_sets[k])
+                seq, att2, sim = model(*fwd_args(dev_sets[k]))
                 done[k].record(comp)
-        elif args.beam > 1:
-            for _ in range(args.steps):
-                seq, lps, att2, sim = model._sample(*dinp, {'beam_size': args.beam})
         elif not args.overlap:
             for _ in range(args.steps):
-                seq, lps, att2, sim = model._sample(*dinp)
+                seq, att2, sim = model(*fwd_args(dinp))
         else:
             # all K steps are enqueued on two streams (preamble | token loop) and fully completed before the clock stops
             outs = model.sample_pipelined([dinp] * args.steps)
-            seq, lps, att2, sim = outs[-1]
+            seq, _lps, att2, sim = outs[-1]
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
+        lps = None
+        if golden is not None:           # (forward() does not return the log-probs: one more, untimed, call for the parity block)
+            lps = model._sample(*dinp)[1]
     ops.set_kernel_timer(None)
     model.check_kernel_status()          # outside the timed region: no persistent-kernel barrier timed out
     elapsed, per_rank = _max_and_per_rank(elapsed, dev, use_dist, args.dist_backend == 'gloo')
@@ -925,7 +943,8 @@ def main():
             'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic', 'per_rank_seconds': per_rank,
-            'config': {'workload': "%s 'sample' (preamble + 20-token loop), %d segments/GPU/step, L=20, "
+            'library_gemms': None,        # filled in at the end: calls that left libgvd_hip.so for a torch library op
+            'config': {'workload': "%s forward(..., 'sample') (preamble + 20-token loop), %d segments/GPU/step, L=20, "
                                    "T x P = %d x 100 regions [B,%d,2048] fc6 + [B,%d,3072] frame feats, V=%d, "
                                    "obj_interact on; random-init weights (trained_like profile)"
                                    % ('greedy' if args.beam == 1 else 'beam=%d' % args.beam, B, args.frames, R, Ft, args.vocab),
@@ -957,7 +976,8 @@ def main():
             out['parity'] = {'golden': 'tests/golden/greedy_b256_v5000_ft10_trained.npz (reference CPU output, '
                                        'oracle/make_golden.py)', 'token_ids_equal': ids_ok,
                              'attended_region_indices_equal': idx_ok,
-                             'max_abs_logprob_diff': float(abs(lps.cpu().numpy() - golden['seqLogprobs']).max())}
+                             'max_abs_logprob_diff': float(abs(lps.cpu().numpy() - golden['seqLogprobs']).max()),
+                             'note': 'ids / regions: the output of the TIMED forward() calls; log-probs: one more untimed call'}
         if args.beam == 1 and B != 4 and not args.h2d:
             # BASELINE configs[1] shape (batch_size=4 eval) next to the headline batch: the latency-bound case (rank 0)
             model.kernel_timer = None
@@ -965,8 +985,8 @@ def main():
             # ppls_feat, frm_mask, sample_idx, pnt_mask, 'sample', eval_opt) with the [B] dummies of main.py:353 - it
             # includes the call's one device->host read of the kernel status words
             s4 = {k: t[:4].contiguous() for k, t in zip(keys, dinp)}
-            dummy = torch.zeros(4, dtype=torch.uint8, device=dev)
-            fwd = (s4['segs_feat'], dummy, dummy, s4['num'], s4['ppls'], dummy, dummy, s4['ppls_feat'], dummy,
+            dummy4 = dummy[:4]
+            fwd = (s4['segs_feat'], dummy4, dummy4, s4['num'], s4['ppls'], dummy4, dummy4, s4['ppls_feat'], dummy4,
                    s4['sample_idx'], s4['pnt_mask'], 'sample', {'sample_max': 1, 'beam_size': 1})
             del seq, lps, att2, sim
             torch.cuda.empty_cache()     # a separate measurement: do not carve 32 MB tensors out of cached multi-GB blocks
@@ -1013,6 +1033,8 @@ def main():
             dp = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     if rank == 0:
         out['config']['configs3_dp_train'] = dp
+        out['library_gemms'] = ops.library_call_count()
+        out['config']['strict'] = bool(ops.STRICT)
         print(json.dumps(out))
     barrier()                    # (rank 0's extra measurement passes are over before any rank tears the group down)
     if use_dist:

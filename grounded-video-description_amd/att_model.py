@@ -411,36 +411,20 @@ class TopDownModel(nn.Module):
         return ln(x + (F.dropout(y, p_drop, True) if p_drop > 0 else y))
 
     def _obj_interact_train(self, x, scale, key_bias=None):
-        """Training path of the region encoder (transformer.py:39-117) with every product on the fp32-MFMA GEMM: the
-        region axis is zero-padded to Rp (a multiple of 32) for the whole stack, q | k | v come from ONE packed projection
-        with every head in its own 176-column slot (the packing is an index_copy of the parameters: gradients flow back to
-        wq / wk / wv / wo), the attention core is ops.enc_attn_core (flash-style forward, maps only inside the backward) and
-        the residual LayerNorms are fused row kernels forward and backward.  Pad rows never reach the loss (their gradients
-        are exactly zero) and are masked out of every softmax."""
+        """Training path of the region encoder (transformer.py:39-117): every layer is ONE autograd function
+        (ops._EncLayerFn: packed q | k | v projection with every head in its own 176-column slot, flash-style attention core
+        with the backward maps only inside the backward, fused residual LayerNorms, feed-forward; hand-scheduled backward
+        with the residual gradients folded into the dX products) over the region rows of the batch packed back to back -
+        no pad rows when R % 4 == 0 and B R % 32 == 0 (the README shapes), else the region axis zero-padded to a multiple of
+        32 for the whole stack (pad rows never reach the loss: their gradients are exactly zero, and they are masked out of
+        every softmax)."""
         B, R, d = x.shape
-        Rp = -(-R // 32) * 32
-        nh, HP = 6, ops.HEAD_PAD
-        sizes = [t.shape[-1] for t in x.reshape(-1, d)[:1].chunk(nh, -1)]
-        starts = [sum(sizes[:i]) for i in range(nh)]
-        idx = torch.cat([torch.arange(sizes[h]) + h * HP for h in range(nh)]).to(x.device)
-        idx3 = torch.cat([idx + j * nh * HP for j in range(3)])
-        xp = F.pad(x, (0, 0, 0, Rp - R)).reshape(B * Rp, d)
-        # compacted training layout (train_compact.py): per-sample key weights [B, R] (-inf on the pad rows up to Rp)
-        kb = None if key_bias is None else F.pad(key_bias.float(), (0, Rp - R), value=float('-inf')).contiguous()
+        Rs = ops.enc_layer_rows(B, R)
+        xp = (x if Rs == R else F.pad(x, (0, 0, 0, Rs - R))).reshape(B * Rs, d).contiguous()
         for lay in self.obj_interact.encoder.layers:
-            sa = lay.selfattn.layer
-            p_drop = sa.attention.dropout.p if self.training else 0.0
-            w_qkv = torch.zeros(3 * nh * HP, d, device=x.device, dtype=torch.float32).index_copy(
-                0, idx3, torch.cat([sa.wq.weight, sa.wk.weight, sa.wv.weight], 0))
-            w_o = torch.zeros(d, nh * HP, device=x.device, dtype=torch.float32).index_copy(1, idx, sa.wo.weight)
-            qkv = ops.linear(xp, w_qkv).view(B, Rp, 3 * nh * HP)
-            o = ops.enc_attn_core(qkv, R, nh, 1.0 / scale, p_drop, kb)
-            att = ops.linear(o.view(B * Rp, nh * HP), w_o)
-            ff = lay.feedforward.layer
-            xp = self._add_ln(xp, att, lay.selfattn.layernorm, lay.selfattn.dropout.p if self.training else 0.0)
-            y = self._lin(self._lin(xp, ff.linear1, act=1), ff.linear2)
-            xp = self._add_ln(xp, y, lay.feedforward.layernorm, lay.feedforward.dropout.p if self.training else 0.0)
-        return xp.view(B, Rp, d)[:, :R]
+            xp = ops.enc_layer(xp, lay, B, R, scale, self.training, key_bias)
+        xp = xp.view(B, Rs, d)
+        return xp if Rs == R else xp[:, :R]
 
     def _obj_interact_fused(self, x, ci=None):
         """Inference path of the encoder on the HIP kernels only (transformer.py:107-190): per layer ONE projection GEMM
@@ -544,17 +528,19 @@ class TopDownModel(nn.Module):
 
     def _obj_interact(self, x, key_bias=None):
         """transformer.py:135-190,244-254 as built at model.py:126-135 (6 uneven heads, scale sqrt(d_model), no padding
-        mask, custom LayerNorm): the flash-style kernels without autograd, the MFMA training core with it.  Region counts
-        the training core is not built for (R % 4 != 0, more than 2048 padded rows) take the elementwise formulation
-        below: projections / feed-forward on the MFMA GEMM, the attention maps through torch."""
+        mask, custom LayerNorm): the flash-style kernels without autograd, the fused MFMA training layers with it (any region
+        count up to 2048 padded rows per sample).  Beyond that - and on CPU tensors (the control-flow tests) - the elementwise
+        formulation below: projections / feed-forward on the MFMA GEMM, the attention maps through torch (counted by
+        ops.library_fallback; an error under GVD_STRICT)."""
         d = x.shape[-1]
         scale = math.sqrt(d)
         if not torch.is_grad_enabled() and not self.training and self._fused_encoder_ok(d):
             return self._obj_interact_fused(x)
-        if (torch.is_grad_enabled() and x.is_cuda and scale == 2.0 ** round(math.log2(scale)) and d % 32 == 0
-                and -(-d // 6) <= ops.HEAD_PAD and x.shape[1] % 4 == 0 and x.shape[1] >= 4
-                and -(-x.shape[1] // 32) * 32 <= 2048):
+        if ((torch.is_grad_enabled() or self.training) and x.is_cuda and scale == 2.0 ** round(math.log2(scale))
+                and ops.enc_layer_ok(x.shape[1], d)):
             return self._obj_interact_train(x, scale, key_bias)
+        if x.is_cuda:
+            ops.library_fallback('encoder attention maps', 'R = %d, d_model = %d' % (x.shape[1], d))
         for lay in self.obj_interact.encoder.layers:
             sa = lay.selfattn.layer
             q, k, v = self._lin(x, sa.wq), self._lin(x, sa.wk), self._lin(x, sa.wv)

@@ -39,7 +39,7 @@ struct MapParams {
   const float* delta;                      // [B * nh, Rp]
   const float* kbias;                      // nullable [B, Rp] (natural-log units)
   float* Pd; float* dS;                    // [B * nh, Rp, Rp]
-  int B, Rp, R, nh, HP;
+  int B, Rp, R, Rs, nh, HP;                // Rs: rows between consecutive samples in qkv / dO (>= R; Rp on the padded layout)
   float scale, c2, keep_scale;
   uint32_t thresh, seed_lo, seed_hi;
   int ntk;
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapPara
 
   const int srow = tid >> 3, kq = tid & 7;
   const int kq_sw = kq ^ (srow & 7);
-  const float* base = p.qkv + (int64_t)b * p.Rp * p.ld + (int64_t)h * HP;
-  const float* dob = p.dO + (int64_t)b * p.Rp * p.ldo + (int64_t)h * HP;
+  const float* base = p.qkv + (int64_t)b * p.Rs * p.ld + (int64_t)h * HP;
+  const float* dob = p.dO + (int64_t)b * p.Rs * p.ldo + (int64_t)h * HP;
   const unsigned ld4 = (unsigned)p.ld * 4u, ldo4 = (unsigned)p.ldo * 4u;
   unsigned vq[NLD], vk[NLD], vd[NLD];      // row offsets: Q / dO rows (queries), K / V rows (keys); edge rows clamped
 #pragma unroll
@@ -234,13 +234,14 @@ __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapPara
 // delta[map, q] = sum_d dO[b, q, h, d] * O[b, q, h, d]: one wave per (b, q) row, head after head (44 lanes x 16 bytes)
 __global__ __launch_bounds__(256) void enc_attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O,
                                                              int64_t ld, float* __restrict__ delta, int B, int Rp, int R,
-                                                             int nh, int HP) {
+                                                             int Rs, int nh, int HP) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (int64_t)B * Rp) return;
   const int b = (int)(row / Rp), q = (int)(row - (int64_t)b * Rp);
-  const float* d = dO + row * ld;
-  const float* o = O + row * ld;
+  const int64_t drow = (int64_t)b * Rs + min(q, R - 1);          // (rows q >= R are not read: their delta is 0)
+  const float* d = dO + drow * ld;
+  const float* o = O + drow * ld;
   for (int h = 0; h < nh; ++h) {
     float acc = 0.f;
     if (q < R)
@@ -265,9 +266,9 @@ __global__ void enc_dropout_mask_kernel(uint8_t* out, int64_t n, int Rp, uint32_
 
 extern "C" int gvd_enc_attn_bwd_maps(const float* qkv, int64_t ld, const float* dO, const float* O, int64_t ldo,
                                      const float* lse2, const float* key_bias, float* delta, float* Pd, float* dS, int B,
-                                     int Rp, int R, int n_heads, int head_pad, float scale, float p_drop, uint64_t seed,
-                                     gvd_stream_t stream) {
-  if (!qkv || !dO || !O || !lse2 || !delta || !Pd || !dS || B <= 0 || R <= 0 || Rp < R || (Rp % 32) != 0 || n_heads <= 0 ||
+                                     int Rp, int R, int sample_rows, int n_heads, int head_pad, float scale, float p_drop,
+                                     uint64_t seed, gvd_stream_t stream) {
+  if (!qkv || !dO || !O || !lse2 || !delta || !Pd || !dS || B <= 0 || R <= 0 || Rp < R || sample_rows < R || (Rp % 32) != 0 || n_heads <= 0 ||
       head_pad < 32 || (head_pad % 16) != 0 || (ld % 4) != 0 || (ldo % 4) != 0 || ld < (int64_t)3 * n_heads * head_pad ||
       ldo < (int64_t)n_heads * head_pad || !gvd_aligned16(qkv) || !gvd_aligned16(dO) || !gvd_aligned16(O) ||
       !gvd_aligned16(Pd) || !gvd_aligned16(dS) || !(p_drop >= 0.f) || !(p_drop < 1.f) ||
@@ -276,11 +277,11 @@ extern "C" int gvd_enc_attn_bwd_maps(const float* qkv, int64_t ld, const float* 
     return GVD_EINVAL;
   hipStream_t st = gvd_s(stream);
   hipLaunchKernelGGL(enc_attn_delta_kernel, dim3((unsigned)(((int64_t)B * Rp + 3) / 4)), dim3(256), 0, st, dO, O, ldo, delta,
-                     B, Rp, R, n_heads, head_pad);
+                     B, Rp, R, sample_rows, n_heads, head_pad);
   GVD_CHECK_LAUNCH();
   MapParams p = {};
   p.qkv = qkv; p.ld = ld; p.dO = dO; p.ldo = ldo; p.lse2 = lse2; p.delta = delta; p.kbias = key_bias; p.Pd = Pd; p.dS = dS;
-  p.B = B; p.Rp = Rp; p.R = R; p.nh = n_heads; p.HP = head_pad;
+  p.B = B; p.Rp = Rp; p.R = R; p.Rs = sample_rows; p.nh = n_heads; p.HP = head_pad;
   p.scale = scale; p.c2 = scale * 1.4426950408889634f; p.keep_scale = 1.0f / (1.0f - p_drop);
   p.thresh = p_drop > 0.f ? gvd_drop_thresh(p_drop) : 0u;
   p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);

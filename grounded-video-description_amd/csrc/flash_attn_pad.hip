@@ -96,7 +96,9 @@ struct PParams {
   const float* q; const float* k; const float* v; float* o;
   int64_t ld, ldo;       // row strides (floats) of q/k/v and of o
   int B, R, n_heads;
-  int rstride;           // rows between consecutive samples (R at inference; Rp >= R on the padded training layout)
+  int rstride;           // rows between consecutive samples in q / k / v / o (R at inference; TRAIN: `sample_rows`)
+  int mstride;           // TRAIN: entries per (sample, head) of lse / per sample of kbias, and the row pitch of the dropout
+                         // hash = the padded query count Rp of the backward maps (csrc/enc_attn_bwd.hip)
   float qscale;          // 1/sqrt(d_model) (a power of two in the reference configuration) times log2(e)
   // ragged (compacted) batches: sample b owns rows off[b] .. off[b+1]-1 of q/k/v/o (at most R of them); its LAST row
   // stands for n identical rows: as a key its score gets + key_w[b] = log2(n) (-inf: no such rows, key ignored)
@@ -106,8 +108,8 @@ struct PParams {
   // the first ones of the grid, in (sample, head, query tile) order; the grid is sized for the longest possible sample.
   const int* tmap;
   // TRAIN only
-  const float* kbias;    // nullable [B, rstride]: added to the SCALED scores of a key (natural-log units; -inf = no such key)
-  float* lse;            // [B * n_heads, rstride]: log2-domain logsumexp of every query's (scaled, biased) scores
+  const float* kbias;    // nullable [B, mstride]: added to the SCALED scores of a key (natural-log units; -inf = no such key)
+  float* lse;            // [B * n_heads, mstride]: log2-domain logsumexp of every query's (scaled, biased) scores
   uint32_t thresh, seed_lo, seed_hi;   // dropout: element dropped iff its draw < thresh (0 = no dropout)
   float keep_scale;      // 1 / (1 - p)
 };
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pad_kernel(const PParams p)
   fetch(0, 0);
   float* kb_s = smem + 3 * BUFSZ;           // TRAIN: the sample's key bias in log2 units (0 without one)
   if (TRAIN) {
-    const float* kb = p.kbias ? p.kbias + (int64_t)b * p.rstride : nullptr;
+    const float* kb = p.kbias ? p.kbias + (int64_t)b * p.mstride : nullptr;
     for (int i = tid; i < ntiles * TK; i += NT) kb_s[i] = (kb && i < R) ? kb[i] * 1.4426950408889634f : 0.f;
   }
   __syncthreads();
@@ -226,8 +228,8 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pad_kernel(const PParams p)
     return;
   }
   const bool skew = NW == 8 && wave >= NW / 2;     // wave-uniform (4-wave shape: the SIMD partner is another workgroup)
-  // TRAIN: this lane's query in the dropout hash (enc_dropout.h): row id = (sample * heads + head) * rstride + query
-  const gvd_encdrop_key dkey = TRAIN ? gvd_encdrop_row((uint32_t)(b * p.n_heads + h) * (uint32_t)p.rstride + (uint32_t)qrow, p.seed_lo, p.seed_hi) : gvd_encdrop_key{0u, 0u};
+  // TRAIN: this lane's query in the dropout hash (enc_dropout.h): row id = (sample * heads + head) * mstride + query
+  const gvd_encdrop_key dkey = TRAIN ? gvd_encdrop_row((uint32_t)(b * p.n_heads + h) * (uint32_t)p.mstride + (uint32_t)qrow, p.seed_lo, p.seed_hi) : gvd_encdrop_key{0u, 0u};
   const bool drop = TRAIN && p.thresh != 0u;       // wave-uniform
   const bool biased = TRAIN && p.kbias != nullptr;
   // first K fragments of the next tile, read right after the barrier that publishes it (under the last 44 MFMAs)
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pad_kernel(const PParams p)
   const float l_tot = rows_sum(l_run);
   const float inv = 1.0f / l_tot;
   if (TRAIN && qrow < R && g == 0)
-    p.lse[(int64_t)(b * p.n_heads + h) * p.rstride + qrow] = m_run + __builtin_amdgcn_logf(l_tot);   // (v_log_f32 = log2)
+    p.lse[(int64_t)(b * p.n_heads + h) * p.mstride + qrow] = m_run + __builtin_amdgcn_logf(l_tot);   // (v_log_f32 = log2)
   if (qrow < R) {
     float* orow = p.o + (row0 + qrow) * p.ldo + h * DP + 4 * g;
 #pragma unroll
@@ -402,7 +404,7 @@ extern "C" int gvd_flash_attn_padded_f32(const float* q, const float* k, const f
       (row_off && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 3u))))
     return GVD_EINVAL;
   PParams p = {};
-  p.q = q; p.k = k; p.v = v; p.o = o; p.ld = ld; p.ldo = ldo; p.B = B; p.R = R; p.n_heads = n_heads; p.rstride = R;
+  p.q = q; p.k = k; p.v = v; p.o = o; p.ld = ld; p.ldo = ldo; p.B = B; p.R = R; p.n_heads = n_heads; p.rstride = R; p.mstride = R;
   p.qscale = 1.4426950408889634f * scale;
   p.off = row_off; p.key_w = last_key_log2_weight;
   if (row_off) {
@@ -419,9 +421,9 @@ extern "C" int gvd_flash_attn_padded_f32(const float* q, const float* k, const f
 }
 
 extern "C" int gvd_flash_attn_train_fwd_f32(const float* qkv, int64_t ld, float* o, int64_t ldo, float* lse, int B, int Rp,
-                                            int R, int n_heads, int head_pad, float scale, const float* key_bias,
-                                            float p_drop, uint64_t seed, gvd_stream_t stream) {
-  if (!qkv || !o || !lse || B <= 0 || R <= 0 || Rp < R || Rp > MAX_TRAIN_KEYS || (Rp % 32) != 0 || n_heads <= 0 ||
+                                            int R, int sample_rows, int n_heads, int head_pad, float scale,
+                                            const float* key_bias, float p_drop, uint64_t seed, gvd_stream_t stream) {
+  if (!qkv || !o || !lse || B <= 0 || R <= 0 || Rp < R || sample_rows < R || Rp > MAX_TRAIN_KEYS || (Rp % 32) != 0 || n_heads <= 0 ||
       head_pad != DP || (ld % 4) != 0 || (ldo % 4) != 0 || !gvd_aligned16(qkv) || !gvd_aligned16(o) ||
       ld < (int64_t)3 * n_heads * DP || ldo < (int64_t)n_heads * DP || (int64_t)R * ld * 4 >= (int64_t)1 << 31 ||
       !(p_drop >= 0.f) || !(p_drop < 1.f) || (key_bias && !gvd_aligned16(key_bias)) ||
@@ -429,7 +431,7 @@ extern "C" int gvd_flash_attn_train_fwd_f32(const float* qkv, int64_t ld, float*
     return GVD_EINVAL;
   PParams p = {};
   p.q = qkv; p.k = qkv + (int64_t)n_heads * DP; p.v = qkv + (int64_t)2 * n_heads * DP; p.o = o;
-  p.ld = ld; p.ldo = ldo; p.B = B; p.R = R; p.n_heads = n_heads; p.rstride = Rp;
+  p.ld = ld; p.ldo = ldo; p.B = B; p.R = R; p.n_heads = n_heads; p.rstride = sample_rows; p.mstride = Rp;
   p.qscale = 1.4426950408889634f * scale;
   p.kbias = key_bias; p.lse = lse;
   p.thresh = p_drop > 0.f ? gvd_drop_thresh(p_drop) : 0u;

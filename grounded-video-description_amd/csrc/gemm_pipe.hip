@@ -355,6 +355,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
     if (p.nbias2) nb += *reinterpret_cast<const f32x4*>(p.nbias2 + gn);
   }
   float* Cb = p.C + gvd_boff(p, bz, p.cbs, p.cbs2);
+  // [M, N] addend (16-byte aligned rows; the launcher checked): dX = dY W + the gradient the same tensor receives through
+  // its other consumer (residual branches of the encoder, decoder_bwd) - one 16-byte read per store instead of a separate
+  // elementwise pass over both
+  const float* Rb = p.rowbias ? p.rowbias + (int64_t)bz * p.rowbias_bs : nullptr;
   const bool relu = p.act == 1;
   // (DS operations of one wave execute in order: its reads below see its own writes above)
 #pragma unroll
@@ -362,8 +366,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const KParams p) {
     const int row = it * 4 + rsub;
     const int gm = (narrow && row >= 32) ? M : m0 + rb + row;        // narrow tiles: 32 rows per wave
     f32x4 v = *reinterpret_cast<const f32x4*>(&T[row * EPI_LD + c4]) + nb;
+    const bool live = gm < M && gn < p.N;
+    if (Rb && live) v += *reinterpret_cast<const f32x4*>(Rb + (int64_t)gm * p.rowbias_ld + gn);
     if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-    if (gm < M && gn < p.N) *reinterpret_cast<f32x4*>(Cb + (int64_t)gm * p.ldc + gn) = v;
+    if (live) *reinterpret_cast<f32x4*>(Cb + (int64_t)gm * p.ldc + gn) = v;
   }
 }
 
@@ -396,16 +402,21 @@ bool gvd_gemm_pipe_takes_ktail() { return true; }
 namespace {
 gvd_prof* g_gemm_prof = nullptr;
 double* g_gemm_flops = nullptr;
+int* g_gemm_rows = nullptr;            // optional [n_rows]: live row count of launch i (the device-side count where it has one)
+int g_gemm_nrows = 0;
 
-__global__ void gemm_flops_kernel(double* acc, const int* m_dev, int M, double per_row) {
+__global__ void gemm_flops_kernel(double* acc, const int* m_dev, int M, double per_row, int* rows_out) {
   const int m = m_dev ? min(*m_dev, M) : M;
   *acc += per_row * (double)m;
+  if (rows_out) *rows_out = m;
 }
 }  // namespace
 
-extern "C" int gvd_gemm_prof_set(gvd_prof* prof, double* dev_flops) {
+extern "C" int gvd_gemm_prof_set(gvd_prof* prof, double* dev_flops, int* dev_rows, int n_rows) {
   g_gemm_prof = prof;
   g_gemm_flops = prof ? dev_flops : nullptr;
+  g_gemm_rows = (prof && dev_rows && n_rows > 0) ? dev_rows : nullptr;
+  g_gemm_nrows = g_gemm_rows ? n_rows : 0;
   return 0;
 }
 
@@ -413,7 +424,8 @@ int gvd_gemm_pipe_launch(KParams& p, int batch, hipStream_t st) {
   p.ntm = (p.M + BM - 1) / BM;
   p.ntn = (p.N + BN - 1) / BN;
   dim3 grid((unsigned)(p.ntm * p.ntn), (unsigned)batch);
-  const bool lds_epi = !p.mbias && !p.rowbias && !p.mask && (p.N % 4) == 0 && (p.ldc % 4) == 0 && (p.cbs % 4) == 0 &&
+  const bool rb_vec = !p.rowbias || (gvd_aligned16(p.rowbias) && (p.rowbias_ld % 4) == 0 && (p.rowbias_bs % 4) == 0);
+  const bool lds_epi = !p.mbias && rb_vec && !p.mask && (p.N % 4) == 0 && (p.ldc % 4) == 0 && (p.cbs % 4) == 0 &&
                        gvd_aligned16(p.C) && (!p.nbias || gvd_aligned16(p.nbias)) && (!p.nbias2 || gvd_aligned16(p.nbias2));
   if (p.a_t || p.w_t) {
     // backward products: one segment, 16-byte aligned K-strided operands, whole 4-column chunks, no device row count
@@ -428,9 +440,14 @@ int gvd_gemm_pipe_launch(KParams& p, int batch, hipStream_t st) {
   if (prof) {
     double ktot = 0.0;
     for (int s = 0; s < p.nseg; ++s) ktot += (double)p.K[s];
+    const int pair = gvd_prof_next(prof);
     if (g_gemm_flops)
       hipLaunchKernelGGL(gemm_flops_kernel, dim3(1), dim3(1), 0, st, g_gemm_flops, p.m_dev, p.M,
-                         2.0 * (double)p.N * ktot * (double)batch);
+                         2.0 * (double)p.N * ktot * (double)batch,
+                         (g_gemm_rows && pair >= 0 && pair < g_gemm_nrows) ? g_gemm_rows + pair : (int*)nullptr);
+    // what this pair times: rows (upper bound; the live count is in dev_rows), columns, contraction, batch, operand forms
+    const int64_t words[GVD_PROF_TAG_WORDS] = {p.M, p.N, (int64_t)ktot, batch, p.a_t, p.w_t, p.m_dev ? 1 : 0, p.rowbias ? 1 : 0};
+    gvd_prof_tag(prof, words);
     gvd_prof_begin(prof, st);
   }
   const int rc = edge ? pipe_launch_t<true>(p, grid, lds_epi, st) : pipe_launch_t<false>(p, grid, lds_epi, st);

@@ -267,3 +267,6 @@ static inline unsigned gvd_spin_limit_env() {
 // event-pair recorder (prof.hip); no-ops when p == nullptr
 void gvd_prof_begin(gvd_prof* p, hipStream_t st);
 void gvd_prof_end(gvd_prof* p, hipStream_t st);
+constexpr int GVD_PROF_TAG_WORDS = 8;
+int gvd_prof_next(gvd_prof* p);
+void gvd_prof_tag(gvd_prof* p, const int64_t (&words)[GVD_PROF_TAG_WORDS]);

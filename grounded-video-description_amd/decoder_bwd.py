@@ -27,7 +27,10 @@ def _tn(dY, X):
     if pad:
         dY, X = F.pad(dY, (0, 0, 0, pad)), F.pad(X, (0, 0, 0, pad))
     r = f(dY.contiguous(), X.contiguous())
-    return dY.t() @ X if r is None else r
+    if r is None:
+        decoder_fn.K.library_fallback('token-loop dW', '%s^T x %s' % (tuple(dY.shape), tuple(X.shape)))
+        return dY.t() @ X
+    return r
 
 
 def _dx(K, groups, M):
@@ -37,6 +40,8 @@ def _dx(K, groups, M):
     if f is not None and all(K.dx_ok(M, g['W'].shape[0], g['W'].shape[1]) for g in groups):
         f(groups, M)
         return
+    if f is not None:
+        K.library_fallback('token-loop dX', ', '.join(str(tuple(g['W'].shape)) for g in groups))
     for g in groups:
         if g.get('addend') is not None:
             torch.addmm(g['addend'], g['A'], g['W'], out=g['out'])
@@ -182,8 +187,10 @@ class DecoderLoopFn(torch.autograd.Function):
         g['a1_aw'], g['a2_aw'] = dw_t.view(1, A), dw_r.view(1, A)      # (a2_*: not among ctx.keys under 'dp' - no alpha_net)
         g['a1_ab'], g['a2_ab'] = dab_t, dab_r
         dctx_b = dctx_all.transpose(0, 1)                        # [B,Lc,H] view of dX_all[:, :, :H]
-        ru = getattr(K, 'rank_update', None)
-        if ru is None or Lc > 32 or H % 128 != 0:
+        ru = getattr(K, 'rank_update_any', None)
+        if ru is None or H % 128 != 0:
+            if ru is not None:
+                K.library_fallback('alpha^T d_ctx', 'H = %d' % H)
             ru = lambda alpha, d: torch.bmm(alpha.transpose(1, 2), d)            # noqa: E731
         # alpha^T d_ctx over all steps: one streaming write of [B,R,H] / [B,Ft,H] (csrc/stream_mm.hip)
         g['pool'] = ru(alpha_r, dctx_b) if sum_r else torch.zeros_like(pool)     # [B,R,H]

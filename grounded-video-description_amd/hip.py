@@ -119,7 +119,8 @@ _SIG = {
     'gvd_attn_fwd_prof': (C.c_int, [C.POINTER(AttnSide), C.POINTER(AttnSide), C.c_int, C.c_int, C.c_int,
                                     c_f32p, C.c_int64, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'gvd_gemm_nt_f32': (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
-    'gvd_gemm_prof_set': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'gvd_gemm_prof_set': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    'gvd_prof_read_pairs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     'gvd_lstm_cell_fwd': (C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),
     'gvd_tanh_fast_f32': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     'gvd_attn_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -135,10 +136,11 @@ _SIG = {
     'gvd_add_layernorm_unbiased_drop_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64,
                                                       C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
     'gvd_flash_attn_train_fwd_f32': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int, C.c_int, C.c_int,
-                                               C.c_int, C.c_int, C.c_float, c_f32p, C.c_float, C.c_uint64, C.c_void_p]),
+                                               C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, C.c_float, C.c_uint64,
+                                               C.c_void_p]),
     'gvd_enc_attn_bwd_maps': (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64,
-                                        C.c_void_p]),
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                        C.c_uint64, C.c_void_p]),
     'gvd_enc_dropout_mask': (C.c_int, [c_u8p, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_void_p]),
     'gvd_region_feature_rows': (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int64, c_u8p, C.c_int64, C.c_int64,
                                           c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_void_p, C.c_int, C.c_float,
@@ -231,7 +233,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 18        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 19        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 
@@ -305,23 +307,51 @@ class GemmProfile:
     .read() -> (total_ms, launches, flops).  Measurement only (bench.py roofline_mfma); process-global."""
 
     def __init__(self, max_pairs=8192):
+        self.max_pairs = max_pairs
         self.timer = KernelTimer(max_pairs)
         self.flops = torch.zeros(1, dtype=torch.float64, device='cuda')
+        self.rows = torch.zeros(max_pairs, dtype=torch.int32, device='cuda')
 
     def __enter__(self):
         self.timer.reset()
         self.flops.zero_()
-        check(lib().gvd_gemm_prof_set(self.timer.h, ptr(self.flops)), 'gvd_gemm_prof_set')
+        check(lib().gvd_gemm_prof_set(self.timer.h, ptr(self.flops), ptr(self.rows), self.max_pairs), 'gvd_gemm_prof_set')
         return self
 
     def __exit__(self, *exc):
-        lib().gvd_gemm_prof_set(None, None)
+        lib().gvd_gemm_prof_set(None, None, None, 0)
         return False
 
     def read(self):
         torch.cuda.synchronize()
         ms, n = self.timer.read()
         return ms, n, float(self.flops.item())
+
+    def table(self, peak_tflops):
+        """Per shape (live rows M, N, K, batch, operand forms): launches, mean microseconds, TFLOP/s and the fraction of
+        `peak_tflops` - which products pull the aggregate down.  Call after read()."""
+        n = self.max_pairs
+        ms = (C.c_float * n)()
+        tags = (C.c_int64 * (8 * n))()
+        got = lib().gvd_prof_read_pairs(self.timer.h, ms, tags, n)
+        if got < 0:
+            raise GvdHipError('gvd_prof_read_pairs -> %d' % got)
+        rows = self.rows[:got].tolist()
+        agg = {}
+        for i in range(got):
+            M, N, K, batch, a_t, w_t, has_mdev, has_add = tags[8 * i:8 * i + 8]
+            key = (rows[i] if has_mdev else M, N, K, batch, 'dW' if a_t else ('dX' if w_t else 'fwd'), bool(has_add))
+            r = agg.setdefault(key, [0, 0.0])
+            r[0] += 1
+            r[1] += ms[i]
+        out = []
+        for (M, N, K, batch, form, add), (cnt, tot) in agg.items():
+            fl = 2.0 * M * N * K * batch
+            tf = fl * cnt / (tot * 1e-3) / 1e12 if tot > 0 else 0.0
+            out.append({'M': M, 'N': N, 'K': K, 'batch': batch, 'form': form + ('+addend' if add else ''), 'launches': cnt,
+                        'us': round(1e3 * tot / cnt, 1), 'tflops': round(tf, 1), 'frac': round(tf / peak_tflops, 3)})
+        out.sort(key=lambda r: -r['us'] * r['launches'])
+        return out
 
 
 class KernelTimer:

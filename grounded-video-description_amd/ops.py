@@ -7,7 +7,34 @@ import os
 
 import torch
 
-from .hip import AttnSide, DxGroup, GemmArgs, GemmSeg, GreedyArgs, LstmArgs, check, lib, ptr, require_cuda_f32, stream_ptr
+from .hip import (AttnSide, DxGroup, GemmArgs, GemmSeg, GreedyArgs, GvdHipError, LstmArgs, check, lib, ptr, require_cuda_f32,
+                  stream_ptr)
+
+# ---------------------------------------------------------------------------------------------------------------------
+# "No library GEMM on the hot path" as an invariant.  Every place where a product or softmax of the path would leave
+# libgvd_hip.so for an ATen / rocBLAS op - a shape one of the kernels does not take - goes through library_fallback()
+# first: it is COUNTED always (`library_calls`; bench.py prints the total as "library_gemms") and RAISES under GVD_STRICT=1
+# (tests/conftest.py and bench.py switch that on), so a silent fallback cannot survive a test run or a benchmark.
+# Without GVD_STRICT the fallback computes the reference's arithmetic through torch, as before.
+# ---------------------------------------------------------------------------------------------------------------------
+STRICT = os.environ.get('GVD_STRICT', '0') == '1'
+library_calls = {}
+
+
+def set_strict(on):
+    global STRICT
+    STRICT = bool(on)
+
+
+def library_fallback(site, detail=''):
+    library_calls[site] = library_calls.get(site, 0) + 1
+    if STRICT:
+        raise GvdHipError('GVD_STRICT: %s would run on a torch library op instead of a kernel of libgvd_hip.so%s'
+                          % (site, (' (%s)' % detail) if detail else ''))
+
+
+def library_call_count():
+    return sum(library_calls.values())
 
 
 def _seg(A, W, K=None, a_bs=0, w_bs=0):
@@ -47,26 +74,33 @@ def gemm_nt(A, W, bias=None, act=0, out=None, m_dev=None, a_row_map=None):
     return out.view(*lead, N)
 
 
-def gemm_dx(dY, W):
-    """dX[M,K] = dY[M,N] @ W[N,K] (backward of y = x W^T w.r.t. x) on the pipelined MFMA kernel: W is consumed in place
-    as a K-strided operand.  Falls back (returns None) when the shape is outside what the kernel takes."""
+def gemm_dx(dY, W, addend=None, out=None):
+    """dX[M,K] = dY[M,N] @ W[N,K] (+ addend[M,K]) (backward of y = x W^T w.r.t. x) on the pipelined MFMA kernel: W is
+    consumed in place as a K-strided operand; `addend` (contiguous: the gradient the same tensor receives through its other
+    consumer - a residual connection) enters the product's epilogue as 16-byte reads instead of a separate elementwise
+    pass.  Falls back (returns None) when the shape is outside what the kernel takes."""
     M, N = dY.shape
     K = W.shape[1]
     tiles = ((M + 127) // 128) * ((K + 127) // 128)
     if N % 32 or K % 4 or tiles < 256 or not (dY.is_contiguous() and W.is_contiguous()):
         return None
-    out = torch.empty(M, K, device=dY.device, dtype=torch.float32)
+    if addend is not None and not (addend.is_contiguous() and addend.shape == (M, K) and addend.data_ptr() % 16 == 0):
+        return None
+    out = torch.empty(M, K, device=dY.device, dtype=torch.float32) if out is None else out
+    assert out.shape == (M, K) and out.is_contiguous()
     g = GemmArgs()
     g.nseg = 1
     g.seg[0] = GemmSeg(ptr(dY), N, 0, ptr(W), K, 0, N)
     g.C = ptr(out); g.ldc = K
     g.M, g.N, g.batch, g.act = M, K, 1, 0
     g.w_kstrided = 1
+    if addend is not None:
+        g.rowbias = ptr(addend); g.rowbias_ld = K
     check(lib().gvd_gemm_nt_f32(C.byref(g), stream_ptr()), 'gvd_gemm_nt_f32(dX)')
     return out
 
 
-def gemm_dx_small(dY, W):
+def gemm_dx_small(dY, W, addend=None, out=None):
     """dX[M,K] = dY[M,N] @ W[N,K] for the shapes gemm_dx leaves (fewer than 256 output tiles: the token loop's [Lc B, .]
     products, e.g. the vocabulary head's [1280, 5000] x [5000, 1024]) on the grouped small-M kernel (csrc/gemm_dxs.hip).  Its
     contraction runs in 128-deep slices: N is cut into the leading multiple of 128, consumed in place, and a tail (V = 5000:
@@ -74,21 +108,58 @@ def gemm_dx_small(dY, W):
     None = shape not taken (K not a multiple of 128, strides)."""
     M, N = dY.shape
     K = W.shape[1]
-    if (K % 128 or N < 128 or dY.stride(1) != 1 or W.stride(1) != 1 or M < 1 or dY.stride(0) % 4 or W.stride(0) % 4
+    if (N < 128 or dY.stride(1) != 1 or W.stride(1) != 1 or M < 1 or dY.stride(0) % 4 or W.stride(0) % 4
             or dY.data_ptr() % 16 or W.data_ptr() % 16):
         return None                       # (16-byte row starts: e.g. an odd vocabulary size leaves this to the library)
+    if addend is not None and not (addend.shape == (M, K) and addend.stride(1) == 1):
+        return None
+    if K % 128:
+        # an output width that is not a multiple of the kernel's 128-column wave tile (the packed wo of the encoder: 1056; the
+        # zero-padded fc_embed: 3136 - both only at batch sizes too small for the pipelined kernel): product against the weight
+        # zero-padded to the next multiple, the live columns copied out
+        Kp = -(-K // 128) * 128
+        Wp = W.new_zeros(N, Kp)
+        Wp[:, :K] = W
+        full = gemm_dx_small(dY, Wp)
+        if full is None:
+            return None
+        r = full[:, :K] if addend is None else full[:, :K] + addend
+        return r.contiguous() if out is None else out.copy_(r)
     N0 = N - N % 128
-    out = torch.empty(M, K, device=dY.device, dtype=torch.float32)
-    tail = None
+    out = torch.empty(M, K, device=dY.device, dtype=torch.float32) if out is None else out
+    tail = addend                          # (`addend` [M,K]: a further term of the result, e.g. a residual path's gradient)
     if N0 < N:
         a = dY.new_zeros(M, 128)
         a[:, :N - N0] = dY[:, N0:]
         w = W.new_zeros(128, K)
         w[:N - N0] = W[N0:]
         tail = torch.empty(M, K, device=dY.device, dtype=torch.float32)
-        dx_products([dict(A=a, W=w, out=tail)], M)
+        dx_products([dict(A=a, W=w, out=tail, addend=addend)], M)
     dx_products([dict(A=dY[:, :N0], W=W[:N0], out=out, addend=tail)], M)
     return out
+
+
+def dx_any(dY, W, addend=None, out=None, what='dX'):
+    """dY @ W (+ addend) on whichever kernel takes the shape: the pipelined K-strided product (>= 256 output tiles), the
+    grouped small-M kernel, else - counted, and an error under GVD_STRICT - the library."""
+    r = gemm_dx(dY, W, addend, out)
+    if r is None:
+        r = gemm_dx_small(dY, W, addend, out)
+    if r is None:
+        library_fallback(what, '%s x %s' % (tuple(dY.shape), tuple(W.shape)))
+        r = dY @ W if addend is None else torch.addmm(addend, dY, W)
+        if out is not None:
+            r = out.copy_(r)
+    return r
+
+
+def dw_any(dY, X, what='dW'):
+    """dY^T @ X on the K-strided MFMA kernel, else - counted, an error under GVD_STRICT - the library."""
+    r = gemm_dw(dY, X)
+    if r is None:
+        library_fallback(what, '%s^T x %s, strides %s' % (tuple(dY.shape), tuple(X.shape), X.stride()))
+        r = dY.t() @ X
+    return r
 
 
 def gemm_dw(dY, X, split=None):
@@ -97,7 +168,9 @@ def gemm_dw(dY, X, split=None):
     taken.  split: force S (tools/dw_split_sweep.py)."""
     M, N = dY.shape
     K = X.shape[1]
-    if N % 4 or K % 4 or not (dY.is_contiguous() and X.is_contiguous()):
+    ldx = X.stride(0)           # X may be a column block of a wider tensor (att_embed reads segs_feat[:, :, :2048] in place)
+    if (N % 4 or K % 4 or not dY.is_contiguous() or X.stride(1) != 1 or ldx < K or ldx % 4 or X.data_ptr() % 16
+            or X.shape[0] != M):
         return None
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     S = 1
@@ -123,7 +196,7 @@ def gemm_dw(dY, X, split=None):
     part = torch.empty(S, N, K, device=dY.device, dtype=torch.float32)
     g = GemmArgs()
     g.nseg = 1
-    g.seg[0] = GemmSeg(ptr(dY), N, Mc * N, ptr(X), K, Mc * K, Mc)
+    g.seg[0] = GemmSeg(ptr(dY), N, Mc * N, ptr(X), ldx, Mc * ldx, Mc)
     g.C = ptr(part); g.ldc = K; g.c_batch_stride = N * K
     g.M, g.N, g.batch, g.act = N, K, S, 0
     g.a_kstrided = g.w_kstrided = 1
@@ -194,6 +267,16 @@ def grounder_stream(xt, feats, mask, mbias=None, rowbias=None):
     return out
 
 
+def grounder_stream_any(xt, feats, mask, mbias=None, rowbias=None):
+    """grounder_stream for any number of words M (32-word chunks above 32: `--seq_length 40`, README.md:115)."""
+    M = xt.shape[1]
+    if M <= 32:
+        return grounder_stream(xt, feats, mask, mbias, rowbias)
+    c = lambda t: None if t is None else t.contiguous()
+    return torch.cat([grounder_stream(c(xt[:, m0:m1]), feats, _mchunk(mask, m0, m1, True), c(_mchunk(mbias, m0, m1)),
+                                      c(_mchunk(rowbias, m0, m1))) for m0, m1 in _m_chunks(M)], 1)
+
+
 def rows_contract(S, F, mask=None, S_t=None):
     """out[b,m,:] = sum_r S[b,m,r] F[b,r,:] (entries of S under `mask` count as 0).  S [B,M,R] (M <= 32, unit inner stride),
     F [B,R,N] contiguous (N % 128 == 0) -> [B,M,N]: one streaming pass over F (gvd_rows_contract_f32).  S_t: the transposed,
@@ -221,6 +304,21 @@ def rank_update(S, X, mask=None):
     mp, mld, mbs = _mask_strides(mask, M)
     check(lib().gvd_rank_update_f32(ptr(S), S.stride(1), S.stride(0), mp, mld, mbs, ptr(X), X.stride(1), X.stride(0),
                                     ptr(out), N, R * N, B, M, R, N, stream_ptr()), 'gvd_rank_update_f32')
+    return out
+
+
+def rank_update_any(S, X, mask=None):
+    """rank_update for any number of rows M: the kernel holds <= 32 rows of X in registers, longer operands (teacher-forced
+    captions above 32 tokens, `--seq_length 40`) are cut into 32-row chunks - one more stream of the output per chunk, still
+    no library GEMM."""
+    M = S.shape[1]
+    if M <= 32:
+        return rank_update(S, X, mask)
+    out = None
+    for m0 in range(0, M, 32):
+        mk = mask if (mask is None or mask.dim() == 2) else mask[:, m0:m0 + 32]
+        part = rank_update(S[:, m0:m0 + 32], X[:, m0:m0 + 32], mk)
+        out = part if out is None else out.add_(part)
     return out
 
 
@@ -666,14 +764,10 @@ class _LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = gemm_dx(dy2, w.detach())                       # MFMA kernel, W in place (K-strided operand)
-            if dx is None:
-                dx = gemm_dx_small(dy2, w.detach())             # few output tiles: the grouped small-M kernel
-            dx = (dy2 @ w if dx is None else dx).view_as(x)
+            # MFMA kernel with W in place as the K-strided operand; few output tiles: the grouped small-M kernel
+            dx = dx_any(dy2, w.detach(), what='linear dX').view_as(x)
         if ctx.needs_input_grad[1]:
-            dw = gemm_dw(dy2, x2.detach()) if x2.is_contiguous() else None
-            if dw is None:
-                dw = dy2.t() @ x2
+            dw = dw_any(dy2, x2.detach(), what='linear dW')
         if not (ctx.has_bias and ctx.needs_input_grad[2]):
             db = None
         elif db is None:
@@ -695,8 +789,19 @@ def linear(x, w, b=None, act=0, p_drop=0.0):
 
 
 def _stream_grounder_ok(xt, feats, xt_shared):
-    return (not xt_shared and xt.dim() == 3 and xt.shape[1] <= 32 and feats.shape[2] % 128 == 0 and xt.is_contiguous()
-            and feats.is_contiguous())
+    """The per-caption form (any number of words: above 32 the streaming kernels run once per 32-word chunk)."""
+    return (not xt_shared and xt.dim() == 3 and feats.shape[2] % 128 == 0 and xt.is_contiguous() and feats.is_contiguous())
+
+
+def _m_chunks(M):
+    return [(m0, min(M, m0 + 32)) for m0 in range(0, M, 32)]
+
+
+def _mchunk(t, m0, m1, dim3_only=False):
+    """Rows m0..m1 of a per-word operand ([B,M,.] or [B,M]); a [B,R] mask (same for every word) passes through."""
+    if t is None or (dim3_only and t.dim() == 2):
+        return t
+    return t[:, m0:m1]
 
 
 class _GrounderFn(torch.autograd.Function):
@@ -709,7 +814,7 @@ class _GrounderFn(torch.autograd.Function):
     def forward(ctx, xt, feats, mask, mbias, rowbias, xt_shared):
         ctx.stream = _stream_grounder_ok(xt, feats, xt_shared) and (mbias is None or mbias.dim() == 2)
         if ctx.stream:
-            out = grounder_stream(xt, feats, mask, mbias, rowbias)
+            out = grounder_stream_any(xt, feats, mask, mbias, rowbias)
         else:
             out = grounder_dot(xt, feats, mask, mbias, rowbias, xt_shared)
         ctx.xt_shared = xt_shared
@@ -726,16 +831,35 @@ class _GrounderFn(torch.autograd.Function):
             need_sum = ctx.mbias_dim is not None and ctx.needs_input_grad[3]
             # the masked gradient IS an output (the gradient of `rowbias` = the region-attention logits): one pass writes it and
             # its row sums (the gradient of the class bias); both products below read it
-            dm, rs, dmt = masked_copy_rowsum(dout, mask, want_sum=need_sum, want_t=True)
-            if ctx.needs_input_grad[0]:
-                g[0] = rows_contract(dm, feats, S_t=dmt)
-            if ctx.needs_input_grad[1]:
-                g[1] = rank_update(dm, xt)
+            if M <= 32:
+                dm, rs, dmt = masked_copy_rowsum(dout, mask, want_sum=need_sum, want_t=True)
+                if ctx.needs_input_grad[0]:
+                    g[0] = rows_contract(dm, feats, S_t=dmt)
+                if ctx.needs_input_grad[1]:
+                    g[1] = rank_update(dm, xt)
+            else:
+                # captions above 32 words (`--seq_length 40`): the same kernels per 32-word chunk
+                dms, rss, g0 = [], [], []
+                for m0, m1 in _m_chunks(M):
+                    dm_c, rs_c, dmt_c = masked_copy_rowsum(dout[:, m0:m1], _mchunk(mask, m0, m1, True), want_sum=need_sum,
+                                                           want_t=True)
+                    dms.append(dm_c); rss.append(rs_c)
+                    if ctx.needs_input_grad[0]:
+                        g0.append(rows_contract(dm_c, feats, S_t=dmt_c))
+                    if ctx.needs_input_grad[1]:
+                        part = rank_update(dm_c, xt[:, m0:m1])
+                        g[1] = part if g[1] is None else g[1].add_(part)
+                dm = torch.cat(dms, 1)
+                rs = torch.cat(rss, 1) if need_sum else None
+                if ctx.needs_input_grad[0]:
+                    g[0] = torch.cat(g0, 1)
             if need_sum:
                 g[3] = rs
             if ctx.needs_input_grad[4]:
                 g[4] = dm
             return tuple(g)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            library_fallback('grounder backward', 'xt %s, feats %s' % (tuple(xt.shape), tuple(feats.shape)))
         if mask is not None:
             m = mask.bool()
             if m.dim() == 2:
@@ -776,7 +900,7 @@ def grounder(xt, feats, mask, mbias=None, rowbias=None, xt_shared=False):
         return _GrounderFn.apply(xt, feats, mask, mbias, rowbias, xt_shared)
     d = lambda t: None if t is None else t.detach()
     if _stream_grounder_ok(xt, feats, xt_shared) and (mbias is None or mbias.dim() == 2):
-        return grounder_stream(d(xt), d(feats), mask, d(mbias), d(rowbias))
+        return grounder_stream_any(d(xt), d(feats), mask, d(mbias), d(rowbias))
     return grounder_dot(d(xt), d(feats), mask, d(mbias), d(rowbias), xt_shared)
 
 
@@ -1232,6 +1356,39 @@ def enc_dropout_mask(n_maps, Rp, p_drop, seed, device='cuda'):
     return out
 
 
+def _enc_core_fwd(qkv, O, lse, B, Rp, R, Rs, nh, scale, p_drop, seed, key_bias):
+    """Flash-style forward of the training attention core (csrc/flash_attn_pad.hip, TRAIN form).  qkv [>= B*Rs, 3*nh*HP] /
+    O [>= B*Rs, nh*HP] row arrays with Rs rows between consecutive samples; lse [B*nh, Rp]."""
+    W3 = qkv.shape[-1]
+    check(lib().gvd_flash_attn_train_fwd_f32(ptr(qkv), W3, ptr(O), O.shape[-1], ptr(lse), B, Rp, R, Rs, nh, HEAD_PAD, scale,
+                                             ptr(key_bias), p_drop, seed, stream_ptr()), 'gvd_flash_attn_train_fwd_f32')
+
+
+def _enc_core_bwd(qkv, O, lse, key_bias, dO, dqkv, B, Rp, R, Rs, nh, scale, p_drop, seed):
+    """Backward of the core: the maps kernel (csrc/enc_attn_bwd.hip) + the three one-head-slot products (csrc/gemm_n192.hip)
+    into dqkv (rows < R of every sample; the caller zeroes pad rows where the layout has them).  The K-strided operands
+    (dO, qkv) are read Rp rows deep per sample: with Rs < Rp the rows past a sample's last belong to the next sample (or to
+    the caller's slack after the last one) and meet exact zeros of the maps."""
+    dev = qkv.device
+    HP, W3 = HEAD_PAD, qkv.shape[-1]
+    ko, vo = nh * HP, 2 * nh * HP
+    delta = torch.empty(B * nh, Rp, device=dev, dtype=torch.float32)
+    Pd = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
+    dS = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
+    check(lib().gvd_enc_attn_bwd_maps(ptr(qkv), W3, ptr(dO), ptr(O), nh * HP, ptr(lse), ptr(key_bias), ptr(delta),
+                                      ptr(Pd), ptr(dS), B, Rp, R, Rs, nh, HP, scale, p_drop, seed, stream_ptr()),
+          'gvd_enc_attn_bwd_maps')
+    mb, ms = nh * Rp * Rp, Rp * Rp
+    # dV_h = Pd_h^T dO_h   (both operands K-strided; pad rows of Pd are zero)
+    _heads_bgemm(nh, Pd, 0, Rp, mb, ms, dO, 0, nh * HP, Rs * nh * HP, HP, Rp, dqkv, vo, W3, Rs * W3, HP, R, HP, B,
+                 a_t=1, w_t=1, what='P^T dO')
+    # dQ_h = dS_h K_h ;  dK_h = dS_h^T Q_h
+    _heads_bgemm(nh, dS, 0, Rp, mb, ms, qkv, ko, W3, Rs * W3, HP, Rp, dqkv, 0, W3, Rs * W3, HP, R, HP, B, w_t=1,
+                 what='dS K')
+    _heads_bgemm(nh, dS, 0, Rp, mb, ms, qkv, 0, W3, Rs * W3, HP, Rp, dqkv, ko, W3, Rs * W3, HP, R, HP, B, a_t=1, w_t=1,
+                 what='dS^T Q')
+
+
 class _EncAttnCoreFn(torch.autograd.Function):
     """Self-attention core of one encoder layer on the training path (transformer.py:90-117): per head
     softmax(Q K^T / sqrt(d)) -> dropout -> @ V.
@@ -1240,10 +1397,11 @@ class _EncAttnCoreFn(torch.autograd.Function):
     probabilities in registers, per-key bias, logsumexp written out) - no [B, heads, Rp, Rp] map is written or kept.
     Backward: ONE kernel recomputes the probabilities tile by tile from Q K^T and the saved logsumexp next to dO V^T and
     writes the two maps the remaining products need (csrc/enc_attn_bwd.hip: Pd for dV = Pd^T dO, dS for dQ = dS K and
-    dK = dS^T Q, on the pipelined fp32-MFMA GEMM with K-strided operands); the maps live for the duration of this call.
+    dK = dS^T Q, on the one-head-slot MFMA GEMM with K-strided operands); the maps live for the duration of this call.
 
     qkv: [B, Rp, 3 * nh * HP] (packed q | k | v, heads padded to HP = 176 columns, Rp % 32 == 0; the pad rows R..Rp-1 may
-    hold anything finite).  Returns O [B, Rp, nh * HP] (pad rows zero)."""
+    hold anything finite).  Returns O [B, Rp, nh * HP] (pad rows zero).  (The stand-alone form on the padded layout: the
+    training step itself runs the whole encoder layer as ONE autograd function, _EncLayerFn below, on the unpadded rows.)"""
 
     @staticmethod
     def forward(ctx, qkv, R, nh, scale, p_drop, seed, key_bias=None):
@@ -1260,8 +1418,7 @@ class _EncAttnCoreFn(torch.autograd.Function):
         if Rp > R:
             O[:, R:].zero_()
         lse = torch.empty(B * nh, Rp, device=dev, dtype=torch.float32)
-        check(lib().gvd_flash_attn_train_fwd_f32(ptr(qkv), W3, ptr(O), nh * HP, ptr(lse), B, Rp, R, nh, HP, scale,
-                                                 ptr(key_bias), p_drop, seed, stream_ptr()), 'gvd_flash_attn_train_fwd_f32')
+        _enc_core_fwd(qkv, O, lse, B, Rp, R, Rp, nh, scale, p_drop, seed, key_bias)
         ctx.save_for_backward(qkv, O, lse, key_bias)
         ctx.cfg = (R, nh, scale, p_drop, seed)
         return O
@@ -1271,29 +1428,12 @@ class _EncAttnCoreFn(torch.autograd.Function):
         qkv, O, lse, key_bias = ctx.saved_tensors
         R, nh, scale, p_drop, seed = ctx.cfg
         B, Rp, W3 = qkv.shape
-        HP = W3 // (3 * nh)
         dO = dO.contiguous()
-        dev = qkv.device
-        ko, vo = nh * HP, 2 * nh * HP
-        delta = torch.empty(B * nh, Rp, device=dev, dtype=torch.float32)
-        Pd = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
-        dS = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
-        check(lib().gvd_enc_attn_bwd_maps(ptr(qkv), W3, ptr(dO), ptr(O), nh * HP, ptr(lse), ptr(key_bias), ptr(delta),
-                                          ptr(Pd), ptr(dS), B, Rp, R, nh, HP, scale, p_drop, seed, stream_ptr()),
-              'gvd_enc_attn_bwd_maps')
-        # (the dQ / dK / dV products below write all 3 * nh * HP columns of the R live rows: only the pad rows need zeros)
+        # (the dQ / dK / dV products write all 3 * nh * HP columns of the R live rows: only the pad rows need zeros)
         dqkv = torch.empty_like(qkv)
         if Rp > R:
             dqkv[:, R:].zero_()
-        mb, ms = nh * Rp * Rp, Rp * Rp
-        # dV_h = Pd_h^T dO_h   (both operands K-strided; pad rows of Pd are zero)
-        _heads_bgemm(nh, Pd, 0, Rp, mb, ms, dO, 0, nh * HP, Rp * nh * HP, HP, Rp, dqkv, vo, W3, Rp * W3, HP, R, HP, B,
-                     a_t=1, w_t=1, what='P^T dO')
-        # dQ_h = dS_h K_h ;  dK_h = dS_h^T Q_h
-        _heads_bgemm(nh, dS, 0, Rp, mb, ms, qkv, ko, W3, Rp * W3, HP, Rp, dqkv, 0, W3, Rp * W3, HP, R, HP, B, w_t=1,
-                     what='dS K')
-        _heads_bgemm(nh, dS, 0, Rp, mb, ms, qkv, 0, W3, Rp * W3, HP, Rp, dqkv, ko, W3, Rp * W3, HP, R, HP, B, a_t=1, w_t=1,
-                     what='dS^T Q')
+        _enc_core_bwd(qkv, O, lse, key_bias, dO, dqkv, B, Rp, R, Rp, nh, scale, p_drop, seed)
         return dqkv, None, None, None, None, None, None
 
 
@@ -1304,6 +1444,158 @@ def enc_attn_core(qkv, R, n_heads, scale, p_drop=0.0, key_bias=None, seed=None):
     if seed is None:
         seed = draw_seed() if p_drop > 0 else 0
     return _EncAttnCoreFn.apply(qkv, R, n_heads, scale, float(p_drop), seed, key_bias)
+
+
+def _add_ln_fwd(x, y, gamma, beta, eps, p_drop, seed):
+    if p_drop > 0:
+        out = torch.empty_like(x)
+        check(lib().gvd_add_layernorm_unbiased_drop(ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(out), x.shape[0], x.shape[1],
+                                                    eps, p_drop, seed, stream_ptr()), 'gvd_add_layernorm_unbiased_drop')
+        return out
+    return add_layernorm_unbiased(x, y, gamma, beta, eps)
+
+
+def _add_ln_bwd(x, y, dout, gamma, eps, p_drop, seed):
+    """-> ds (gradient of x), dy (gradient of the branch y: ds itself without dropout), dgamma, dbeta."""
+    rows, D = x.shape
+    ds = torch.empty_like(x)
+    parts = torch.empty(lib().gvd_add_layernorm_unbiased_bwd_parts(rows), 2, D, device=x.device, dtype=torch.float32)
+    if p_drop > 0:
+        dy = torch.empty_like(x)
+        check(lib().gvd_add_layernorm_unbiased_drop_bwd(ptr(x), ptr(y), ptr(dout), ptr(gamma), ptr(ds), ptr(dy), ptr(parts),
+                                                        rows, D, eps, p_drop, seed, stream_ptr()),
+              'gvd_add_layernorm_unbiased_drop_bwd')
+    else:
+        check(lib().gvd_add_layernorm_unbiased_bwd(ptr(x), ptr(y), ptr(dout), ptr(gamma), ptr(ds), ptr(parts), rows, D, eps,
+                                                   stream_ptr()), 'gvd_add_layernorm_unbiased_bwd')
+        dy = ds
+    ps = parts.sum(0)
+    return ds, dy, ps[0], ps[1]
+
+
+class _EncLayerFn(torch.autograd.Function):
+    """ONE encoder layer of the region encoder on the training path (transformer.py:39-133: multi-head self-attention ->
+    ResidualBlock -> feed-forward -> ResidualBlock) as ONE autograd function over the region rows of the batch packed back to
+    back, x [B * Rs, d]:
+
+      forward   qkv = x W_qkv^T (heads in 176-column slots) -> flash-style core -> att = O W_o^T -> x1 = LN(x + drop(att))
+                -> h = relu(x1 W_1^T + b_1) -> y = h W_2^T + b_2 -> x2 = LN(x1 + drop(y))
+      backward  hand-scheduled: every dX product takes the gradient its input also receives through the residual connection
+                as the ADDEND of its epilogue (dx1 = dz W_1 + ds2, dx = dqkv W_qkv + ds1 - autograd's two [B R, 1024] adds per
+                layer are gone), ReLU mask + bias gradient in one pass, the packed-weight gradients sliced back to
+                wq / wk / wv / wo by index.
+
+    Rs = rows between samples: R itself when R % 4 == 0 (no pad rows anywhere: the Linear layers work on exactly the live
+    rows - 2.3 % fewer flops than on the 32-row-padded layout at R = 1000 and no pad / unpad copies; only the core's maps
+    and statistics keep the padded pitch Rp), else Rp with the rows R .. R4-1 masked as keys (R4 = R rounded up to 4)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, wo, g1, be1, w1, b1, w2, b2, g2, be2, cfg):
+        B, R, Rs, Rp, nh, scale, key_bias, idx, idx3, eps1, eps2, p_att, p_res1, p_res2, seeds = cfg
+        HP = HEAD_PAD
+        dev = x.device
+        d = x.shape[1]
+        rows = B * Rs
+        assert x.shape == (rows, d) and x.is_contiguous()
+        w_qkv = torch.zeros(3 * nh * HP, d, device=dev, dtype=torch.float32).index_copy_(0, idx3, torch.cat([wq, wk, wv], 0))
+        w_o = torch.zeros(d, nh * HP, device=dev, dtype=torch.float32).index_copy_(1, idx, wo)
+        slack = Rp - Rs if Rs < Rp else 0             # rows the K-strided backward products read past the last sample
+        qkv_buf = torch.empty(rows + slack, 3 * nh * HP, device=dev, dtype=torch.float32)
+        if slack:
+            qkv_buf[rows:].zero_()
+        qkv = gemm_nt(x, w_qkv, out=qkv_buf[:rows])
+        O = torch.empty(rows, nh * HP, device=dev, dtype=torch.float32)
+        if Rs > R:
+            O.view(B, Rs, -1)[:, R:].zero_()
+        lse = torch.empty(B * nh, Rp, device=dev, dtype=torch.float32)
+        _enc_core_fwd(qkv_buf, O, lse, B, Rp, R, Rs, nh, scale, p_att, seeds[0], key_bias)
+        att = gemm_nt(O, w_o)
+        x1 = _add_ln_fwd(x, att, g1, be1, eps1, p_res1, seeds[1])
+        h = gemm_nt(x1, w1, b1, 1)
+        y = gemm_nt(h, w2, b2)
+        x2 = _add_ln_fwd(x1, y, g2, be2, eps2, p_res2, seeds[2])
+        ctx.save_for_backward(x, qkv_buf, O, lse, att, x1, h, y, w_qkv, w_o, g1, w1, w2, g2)
+        ctx.cfg = cfg
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        x, qkv_buf, O, lse, att, x1, h, y, w_qkv, w_o, g1, w1, w2, g2 = ctx.saved_tensors
+        B, R, Rs, Rp, nh, scale, key_bias, idx, idx3, eps1, eps2, p_att, p_res1, p_res2, seeds = ctx.cfg
+        HP = HEAD_PAD
+        dev = x.device
+        rows, d = x.shape
+        need = ctx.needs_input_grad
+        dx2 = dx2.contiguous()
+        # ---- feed-forward ResidualBlock
+        ds2, dy, dg2, dbe2 = _add_ln_bwd(x1, y, dx2, g2, eps2, p_res2, seeds[2])
+        db2 = dy.sum(0)
+        dw2 = dw_any(dy, h, 'encoder dW (linear2)')
+        dh = dx_any(dy, w2, what='encoder dX (linear2)')
+        dz, db1 = relu_dropout_bwd(dh, h, 0.0)                     # ReLU mask + bias gradient in one pass
+        dw1 = dw_any(dz, x1, 'encoder dW (linear1)')
+        dx1 = dx_any(dz, w1, addend=ds2, what='encoder dX (linear1)')        # + the residual path's gradient
+        # ---- self-attention ResidualBlock
+        ds1, datt, dg1, dbe1 = _add_ln_bwd(x, att, dx1, g1, eps1, p_res1, seeds[1])
+        dw_o = dw_any(datt, O, 'encoder dW (wo)')                            # [d, nh * HP]
+        slack = Rp - Rs if Rs < Rp else 0
+        dO_buf = torch.empty(rows + slack, nh * HP, device=dev, dtype=torch.float32)
+        if slack:
+            dO_buf[rows:].zero_()
+        dx_any(datt, w_o, out=dO_buf[:rows], what='encoder dX (wo)')
+        dqkv = torch.empty(rows, 3 * nh * HP, device=dev, dtype=torch.float32)
+        if Rs > R:
+            dqkv.view(B, Rs, -1)[:, R:].zero_()
+        _enc_core_bwd(qkv_buf, O, lse, key_bias, dO_buf, dqkv, B, Rp, R, Rs, nh, scale, p_att, seeds[0])
+        dw_qkv = dw_any(dqkv, x, 'encoder dW (q|k|v)')                       # [3 * nh * HP, d]
+        dx = dx_any(dqkv, w_qkv, addend=ds1, what='encoder dX (q|k|v)') if need[0] else None
+        dq, dk, dv = dw_qkv.index_select(0, idx3).chunk(3, 0)
+        dwo = dw_o.index_select(1, idx)
+        return dx, dq, dk, dv, dwo, dg1, dbe1, dw1, db1, dw2, db2, dg2, dbe2, None
+
+
+def enc_layer_ok(R, d, n_heads=6):
+    """Shapes the fused training layer takes: d_model 1024 (the row kernels), heads of <= 176 columns, at most 2048 padded
+    rows per sample (the core's staged key bias)."""
+    return d == 1024 and -(-d // n_heads) <= HEAD_PAD and -(-R // 32) * 32 <= 2048 and R >= 1
+
+
+def enc_layer_rows(B, R):
+    """Rows between consecutive samples of the fused training layer's row arrays: R itself (the region rows of the batch
+    packed back to back, no pad rows) when the kernels take it - R % 4 == 0 (16-byte head slots of the K-strided products) and
+    B * R a multiple of the K-strided weight-gradient kernel's 32-deep tile - else R rounded up to 32."""
+    return R if (R % 4 == 0 and (B * R) % 32 == 0) else -(-R // 32) * 32
+
+
+def enc_layer(x, lay, B, R, scale, training, key_bias=None, n_heads=6):
+    """x [B * Rs, d] -> [B * Rs, d]: one encoder layer (see _EncLayerFn); `lay` = the reference's EncoderLayer parameter tree
+    (att_model._build_obj_interact).  Rs = enc_layer_rows(B, R): R, or R rounded up to 32 (the caller pads; pad rows hold
+    anything finite).  key_bias: optional [B, R] per-sample key weights (the compacted training layout)."""
+    d = x.shape[1]
+    dev = x.device
+    Rp = -(-R // 32) * 32
+    R4 = -(-R // 4) * 4
+    Rs = enc_layer_rows(B, R)
+    assert x.shape[0] == B * Rs
+    sizes = [len(c) for c in torch.arange(d).chunk(n_heads)]              # torch.chunk's head widths (transformer.py:103)
+    idx = torch.cat([torch.arange(sizes[h]) + h * HEAD_PAD for h in range(n_heads)]).to(dev)
+    idx3 = torch.cat([idx + j * n_heads * HEAD_PAD for j in range(3)])
+    kb = None
+    if key_bias is not None or R4 != R:
+        kb = torch.full((B, Rp), float('-inf'), device=dev, dtype=torch.float32)
+        kb[:, :R] = 0.0 if key_bias is None else key_bias.float()
+        if R4 != R:
+            kb[:, R:R4] = -1e30                  # the rows R .. R4-1 travel as queries / keys of the kernels: no such key
+    sa, ff = lay.selfattn.layer, lay.feedforward.layer
+    p_att = float(sa.attention.dropout.p) if training else 0.0
+    p1 = float(lay.selfattn.dropout.p) if training else 0.0
+    p2 = float(lay.feedforward.dropout.p) if training else 0.0
+    seeds = tuple(draw_seed() if p > 0 else 0 for p in (p_att, p1, p2))
+    cfg = (B, R4, Rs, Rp, n_heads, 1.0 / scale, kb, idx, idx3, lay.selfattn.layernorm.eps, lay.feedforward.layernorm.eps,
+           p_att, p1, p2, seeds)
+    ln1, ln2 = lay.selfattn.layernorm, lay.feedforward.layernorm
+    return _EncLayerFn.apply(x, sa.wq.weight, sa.wk.weight, sa.wv.weight, sa.wo.weight, ln1.gamma, ln1.beta,
+                             ff.linear1.weight, ff.linear1.bias, ff.linear2.weight, ff.linear2.bias, ln2.gamma, ln2.beta, cfg)
 
 
 def region_feature_rows(g_pool, loc, sim_logits_t, pnt_mask, ln_eps=1e-5, pad_to=1, n_cls=None):

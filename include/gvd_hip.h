@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 18
+#define GVD_ABI_VERSION 19
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -49,6 +49,10 @@ void gvd_prof_destroy(gvd_prof* p);
 void gvd_prof_reset(gvd_prof* p);
 /* call after synchronising the stream: sum of elapsed ms over the recorded pairs, and their count */
 int gvd_prof_read(gvd_prof* p, float* total_ms, int* count);
+/* per pair: ms[i] and (tags may be NULL) the 8 int64 words the launcher attached to pair i - for the pipelined GEMM:
+ * {M, N, K, batch, a_kstrided, w_kstrided, has device row count, has addend}.  Returns the pairs written (<= max_pairs) or a
+ * negative error.  Call after synchronising the stream. */
+int gvd_prof_read_pairs(gvd_prof* p, float* ms, int64_t* tags, int max_pairs);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense projections (MFMA fp32, v_mfma_f32_32x32x2_f32: exact fp32 fma chains)
@@ -105,9 +109,10 @@ int gvd_gemm_nt_f32(const gvd_gemm_args* args, gvd_stream_t stream);
 
 /* Measurement hook (bench.py `roofline_mfma`): while `prof` is non-NULL every launch of the pipelined fp32-MFMA GEMM kernel
  * (csrc/gemm_pipe.hip) is bracketed by an event pair of `prof` on its stream, and 2 x rows x N x K x batch flops - rows read
- * from the launch's device-side row count where it has one - are added to the device double *dev_flops (may be NULL).
+ * from the launch's device-side row count where it has one - are added to the device double *dev_flops (may be NULL), and
+ * launch i's live row count is written to dev_rows[i] (i < n_rows; may be NULL) for bench.py's per-shape table.
  * Process-global, not thread-safe, off by default; pass NULL to disarm.  No reference counterpart (instrumentation). */
-int gvd_gemm_prof_set(gvd_prof* prof, double* dev_flops);
+int gvd_gemm_prof_set(gvd_prof* prof, double* dev_flops, int* dev_rows, int n_rows);
 
 /* nn.LSTMCell forward (AttModel.py:121,123,139,160): gates = sum_s X_s W_s^T + b_ih + b_hh (+ rowbias),
  * gate order i,f,g,o; c' = sig(f) c + sig(i) tanh(g); h' = sig(o) tanh(c').  The gate GEMM and the
@@ -226,13 +231,18 @@ int gvd_add_layernorm_unbiased_drop_bwd(const float* x, const float* y, const fl
  *   products S = Q K^T and dY = dO V^T in one kernel whose epilogue recomputes P = exp2(c S + bias - lse), re-evaluates the
  *   keep mask and writes Pd = P * keep / (1 - p) and dS = scale * P * (dY * keep / (1 - p) - delta), both
  *   f32 [B * n_heads, Rp, Rp] with rows / columns >= R zero - the operands of dV = Pd^T dO, dQ = dS K, dK = dS^T Q
- *   (gvd_gemm_nt_f32 with K-strided operands).  B * n_heads <= 65535. */
+ *   (gvd_gemm_nt_f32 with K-strided operands).  B * n_heads <= 65535.
+ * sample_rows (ABI 19) = rows between consecutive samples in qkv / o / dO: Rp on the padded layout, or R itself - the
+ *   region rows of the batch packed back to back ([B * R, ld], what the Linear layers around the core read and write, no pad
+ *   rows anywhere): only the per-(sample, head) statistics and the two maps keep the padded pitch Rp.  Rows past R of a
+ *   sample are never written; the K-strided products that contract over Rp rows read up to Rp - R rows past a sample's last
+ *   one (the next sample's, or - last sample - slack the caller provides: finite values, they meet exact zeros of the maps). */
 int gvd_flash_attn_train_fwd_f32(const float* qkv, int64_t ld, float* o, int64_t ldo, float* lse, int B, int Rp, int R,
-                                 int n_heads, int head_pad, float scale, const float* key_bias, float p_drop, uint64_t seed,
-                                 gvd_stream_t stream);
+                                 int sample_rows, int n_heads, int head_pad, float scale, const float* key_bias,
+                                 float p_drop, uint64_t seed, gvd_stream_t stream);
 int gvd_enc_attn_bwd_maps(const float* qkv, int64_t ld, const float* dO, const float* O, int64_t ldo, const float* lse2,
-                          const float* key_bias, float* delta, float* Pd, float* dS, int B, int Rp, int R, int n_heads,
-                          int head_pad, float scale, float p_drop, uint64_t seed, gvd_stream_t stream);
+                          const float* key_bias, float* delta, float* Pd, float* dS, int B, int Rp, int R, int sample_rows,
+                          int n_heads, int head_pad, float scale, float p_drop, uint64_t seed, gvd_stream_t stream);
 /* Test aid: the keep mask of that dropout, u8 [n_maps, Rp, Rp] (1 = kept), map row = map * Rp + query. */
 int gvd_enc_dropout_mask(uint8_t* out, int64_t n_maps, int Rp, float p_drop, uint64_t seed, gvd_stream_t stream);
 

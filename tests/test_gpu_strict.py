@@ -1,0 +1,118 @@
+"""'No library GEMM on the hot path' as a tested invariant.
+
+The product path may leave libgvd_hip.so for a torch library op only through ops.library_fallback(), which counts the
+call and - under GVD_STRICT=1, which tests/conftest.py switches on for the whole suite - raises.  Here the claim is
+checked from the OTHER side as well: one training step of the README recipe (main.py:234-266; BASELINE configs[2] shape and
+the 4-segment shape of the goldens) and one greedy decode (model.py:492-624) run under torch.profiler, and no device kernel
+may come from aten::mm / bmm / addmm / matmul / baddbmm / linear / _softmax / log_softmax, nor carry a rocBLAS / Tensile /
+hipBLASLt / MIOpen kernel name.  Reference call sites this replaces: nn.Linear / torch.matmul / F.softmax at
+model.py:311-409,464-480, AttModel.py:39-53,77-108,139,160, transformer.py:90-133."""
+import re
+
+import pytest
+import torch
+
+import gvd_amd
+from gvd_amd import att_model, ops, opts, synth, train
+
+pytestmark = pytest.mark.gpu
+
+BANNED_OPS = {'aten::mm', 'aten::bmm', 'aten::addmm', 'aten::matmul', 'aten::baddbmm', 'aten::linear', 'aten::addmv',
+              'aten::mv', 'aten::_softmax', 'aten::softmax', 'aten::_log_softmax', 'aten::log_softmax',
+              'aten::_softmax_backward_data', 'aten::_log_softmax_backward_data', 'aten::native_batch_norm', 'aten::cudnn_batch_norm',
+              'aten::miopen_batch_norm', 'aten::_scaled_dot_product_attention', 'aten::gru', 'aten::lstm', 'aten::_thnn_fused_gru_cell',
+              'aten::_thnn_fused_lstm_cell', 'aten::native_dropout', 'aten::tanh', 'aten::sigmoid'}
+BANNED_KERNELS = re.compile(r'Cijk_|rocblas|hipblas|Tensile|miopen|MIOpen|cunn_SoftMax|softmax_warp|gemv|GEMV|sgemm', re.I)
+
+
+def _profile(run):
+    from torch.profiler import ProfilerActivity, profile
+    run()                                              # warm-up (allocator, packed weights, bucket discovery)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        run()
+        torch.cuda.synchronize()
+    ops_dev, kernels, native_us, ours_us = {}, {}, 0.0, 0.0
+    for e in prof.events():
+        if e.device_type == torch.autograd.DeviceType.CPU:
+            if not e.name.startswith('aten::'):
+                continue
+            dt = sum(k.duration for k in e.kernels)
+            if dt > 0:
+                r = ops_dev.setdefault(e.name, [0, 0.0, str(e.input_shapes)[:100]])
+                r[0] += 1
+                r[1] += dt
+        else:
+            kernels[e.name] = kernels.get(e.name, 0) + 1
+    return ops_dev, kernels
+
+
+def _assert_clean(ops_dev, kernels, what):
+    bad = {k: v for k, v in ops_dev.items() if k in BANNED_OPS}
+    assert not bad, '%s: torch library ops with device kernels on the hot path: %s' % (what, bad)
+    badk = [k for k in kernels if BANNED_KERNELS.search(k) and 'anonymous namespace' not in k]
+    assert not badk, '%s: library kernels on the hot path: %s' % (what, badk)
+    ours = [k for k in kernels if 'anonymous namespace' in k or k.startswith('gvd_')]
+    assert len(ours) >= 10, (what, sorted(kernels)[:20])          # the profiler really saw the library's kernels
+    native = sum(v[1] for v in ops_dev.values())
+    print('%s: %d distinct kernels (%d of libgvd_hip.so); torch-native device time %.3f ms in %d launches; top: %s'
+          % (what, len(kernels), len(ours), native / 1e3, sum(v[0] for v in ops_dev.values()),
+             sorted(((round(v[1], 1), k, v[0]) for k, v in ops_dev.items()), reverse=True)[:8]))
+    return native
+
+
+@pytest.mark.parametrize('B', [4, 64])
+def test_train_step_runs_no_library_gemm_or_softmax(B):
+    assert ops.STRICT, 'tests run under GVD_STRICT=1 (tests/conftest.py)'
+    before = ops.library_call_count()
+    opt = opts.default_opt(vocab_size=5000, t_attn_size=10)
+    for k, v in dict(w_att2=0.05, w_grd=0.3, w_cls=0.1).items():
+        setattr(opt, k, v)
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(synth.init_state_dict(opt, seed=5, profile='trained_like'))
+    model = model.cuda().train()                       # live dropout + BatchNorm batch statistics: main.py's mode
+    tr = train.Trainer(model, opt)
+    args = synth.as_args(synth.trim_to_batch(synth.make_inputs(opt, B, seed=5, train=True)), 'cuda')
+    ops_dev, kernels = _profile(lambda: tr.step(args))
+    native = _assert_clean(ops_dev, kernels, 'train step B = %d' % B)
+    assert ops.library_call_count() == before
+    if B == 64:
+        assert native < 3.0e3, 'torch-native device time %.2f ms (r5: 3.65 ms)' % (native / 1e3)
+
+
+@pytest.mark.parametrize('B,beam', [(32, 1), (4, 1), (8, 5)])
+def test_decode_runs_no_library_gemm_or_softmax(B, beam):
+    before = ops.library_call_count()
+    opt = opts.default_opt(vocab_size=5000, t_attn_size=10)
+    model = att_model.TopDownModel(opt)
+    model.load_state_dict(synth.init_state_dict(opt, seed=1, profile='trained_like'))
+    model = model.cuda().eval()
+    inp = synth.make_inputs(opt, B, seed=1, train=False)
+    args = synth.as_args(inp, 'cuda')
+
+    def run():
+        with torch.no_grad():
+            model(*args, 'sample', {'sample_max': 1, 'beam_size': beam})
+    ops_dev, kernels = _profile(run)
+    _assert_clean(ops_dev, kernels, 'decode B = %d beam = %d' % (B, beam))
+    assert ops.library_call_count() == before
+
+
+def test_strict_mode_raises_where_a_fallback_would_run():
+    """A shape none of the kernels takes (a Linear whose output rows do not start on 16 bytes) is an error under GVD_STRICT and
+    the library product without it - counted either way."""
+    x = torch.randn(40, 64, device='cuda', requires_grad=True)
+    w = torch.randn(30, 64, device='cuda', requires_grad=True)          # N = 30: dY rows are 120 bytes apart
+    n0 = ops.library_call_count()
+    y = ops.linear(x, w)
+    with pytest.raises(gvd_amd.hip.GvdHipError, match='GVD_STRICT'):
+        y.sum().backward()
+    assert ops.library_call_count() > n0
+    ops.set_strict(False)
+    try:
+        x.grad = w.grad = None
+        ops.linear(x, w).sum().backward()
+        ref = torch.ones(40, 30, device='cuda')
+        assert torch.allclose(x.grad, ref @ w.detach(), atol=1e-5) and torch.allclose(w.grad, ref.t() @ x.detach(), atol=1e-5)
+    finally:
+        ops.set_strict(True)

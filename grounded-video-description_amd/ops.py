@@ -105,14 +105,24 @@ def gemm_dx_small(dY, W, addend=None, out=None):
     products, e.g. the vocabulary head's [1280, 5000] x [5000, 1024]) on the grouped small-M kernel (csrc/gemm_dxs.hip).  Its
     contraction runs in 128-deep slices: N is cut into the leading multiple of 128, consumed in place, and a tail (V = 5000:
     8 columns) copied into zero-padded [M, 128] / [128, K] operands whose product enters the main launch as its addend.
-    None = shape not taken (K not a multiple of 128, strides)."""
+    Operands the kernel cannot read in place (rows off 16 bytes, an output width off its 128-column tile) are copied into
+    zero-padded ones first; None only for an addend of the wrong shape."""
     M, N = dY.shape
     K = W.shape[1]
-    if (N < 128 or dY.stride(1) != 1 or W.stride(1) != 1 or M < 1 or dY.stride(0) % 4 or W.stride(0) % 4
-            or dY.data_ptr() % 16 or W.data_ptr() % 16):
-        return None                       # (16-byte row starts: e.g. an odd vocabulary size leaves this to the library)
+    if M < 1:
+        return None
     if addend is not None and not (addend.shape == (M, K) and addend.stride(1) == 1):
         return None
+    if (N < 128 or dY.stride(1) != 1 or W.stride(1) != 1 or dY.stride(0) % 4 or W.stride(0) % 4 or dY.data_ptr() % 16
+            or W.data_ptr() % 16):
+        # rows that do not start on 16 bytes (an odd vocabulary size: dY [B Lc, V]) or a contraction shorter than one 128-deep
+        # slice: zero-padded copies of both operands (the weight copy is V x 1024 floats: ~10 us) - never the library
+        Np = max(128, -(-N // 128) * 128)
+        d2 = dY.new_zeros(M, Np)
+        d2[:, :N] = dY
+        w2 = W.new_zeros(Np, K)
+        w2[:N] = W
+        return gemm_dx_small(d2, w2, addend, out)
     if K % 128:
         # an output width that is not a multiple of the kernel's 128-column wave tile (the packed wo of the encoder: 1056; the
         # zero-padded fc_embed: 3136 - both only at batch sizes too small for the pipelined kernel): product against the weight
@@ -168,10 +178,24 @@ def gemm_dw(dY, X, split=None):
     taken.  split: force S (tools/dw_split_sweep.py)."""
     M, N = dY.shape
     K = X.shape[1]
-    ldx = X.stride(0)           # X may be a column block of a wider tensor (att_embed reads segs_feat[:, :, :2048] in place)
-    if (N % 4 or K % 4 or not dY.is_contiguous() or X.stride(1) != 1 or ldx < K or ldx % 4 or X.data_ptr() % 16
-            or X.shape[0] != M):
+    if K % 4 or X.shape[0] != M or M < 1:
         return None
+    # What the kernel consumes in place: dY contiguous with N % 4 == 0, X with 16-byte rows (it may be a column block of a
+    # wider tensor: att_embed reads segs_feat[:, :, :2048] in place), a contraction length M that is a multiple of its 32-deep
+    # k tile.  Anything else (the token loop's B Lc rows at odd batch sizes, an odd vocabulary size, B R % 32 != 0) is copied
+    # into zero-padded operands first - zeros add nothing to the sums - instead of leaving the library of kernels.
+    N_real = N
+    pad_m, pad_n = (-M) % 32, (-N) % 4
+    if pad_m or pad_n or not dY.is_contiguous() or dY.data_ptr() % 16:
+        d2 = dY.new_zeros(M + pad_m, N + pad_n)
+        d2[:M, :N] = dY
+        dY, N = d2, N + pad_n
+    if pad_m or X.stride(1) != 1 or X.stride(0) < K or X.stride(0) % 4 or X.data_ptr() % 16:
+        x2 = X.new_zeros(M + pad_m, K)
+        x2[:M] = X
+        X = x2
+    M += pad_m
+    ldx = X.stride(0)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     S = 1
     while tiles * S < 1024 and M % (64 * S) == 0 and M // (2 * S) >= 2048:
@@ -201,7 +225,8 @@ def gemm_dw(dY, X, split=None):
     g.M, g.N, g.batch, g.act = N, K, S, 0
     g.a_kstrided = g.w_kstrided = 1
     check(lib().gvd_gemm_nt_f32(C.byref(g), stream_ptr()), 'gvd_gemm_nt_f32(dW)')
-    return part[0] if S == 1 else part.sum(0)
+    out = part[0] if S == 1 else part.sum(0)
+    return out if N == N_real else out[:N_real].contiguous()
 
 
 def grounder_dot(xt, feats, mask, mbias=None, rowbias=None, xt_shared=False):

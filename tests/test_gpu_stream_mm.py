@@ -202,12 +202,17 @@ def test_gemm_dx_small_with_a_contraction_tail(M, N):
     y = ops.linear(x, w)
     y.backward(dY)
     _close(x.grad, (dY.double() @ W.double()).cpu(), what='ops.linear d x')
-    # a row pitch that is not a multiple of 16 bytes (odd vocabulary size) is not this kernel's: None, and ops.linear's
-    # backward still returns the right product
-    assert ops.gemm_dx_small(dY[:, :N - 1].contiguous(), W[:N - 1]) is None
+    # a row pitch that is not a multiple of 16 bytes (odd vocabulary size): zero-padded copies of both operands, still on the
+    # kernel - ops.linear's backward (dX and dW) never reaches the library (the suite runs under GVD_STRICT)
+    n0 = ops.library_call_count()
+    _close(ops.gemm_dx_small(dY[:, :N - 1].contiguous(), W[:N - 1]), (dY[:, :N - 1].double() @ W[:N - 1].double()).cpu(),
+           what='dX, odd width')
     x2 = x.detach().clone().requires_grad_(True)
-    ops.linear(x2, w[:N - 1].detach().contiguous().requires_grad_(True)).backward(dY[:, :N - 1].contiguous())
+    w2 = w[:N - 1].detach().contiguous().requires_grad_(True)
+    ops.linear(x2, w2).backward(dY[:, :N - 1].contiguous())
     _close(x2.grad, (dY[:, :N - 1].double() @ W[:N - 1].double()).cpu(), what='ops.linear d x, odd width')
+    _close(w2.grad, (dY[:, :N - 1].double().t() @ x.detach().double()).cpu(), what='ops.linear d w, odd width')
+    assert ops.library_call_count() == n0
 
 
 def test_softmax_rows_and_loss_backwards():

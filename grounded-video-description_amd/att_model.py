@@ -578,7 +578,12 @@ class TopDownModel(nn.Module):
                                 self.seg_info_embed[0].bias.detach(), pad_to=32)
         else:
             fc = segs_feat.mean(dim=1)
-            seg_info = self._drop(F.relu(self.seg_info_embed[0](num[:, 3:7].float())))
+            # seg_info_embed (model.py:308): Linear(4, 50) + ReLU + dropout on the MFMA GEMM like every other Linear of the path
+            # (K = 4 zero-padded to the 32-deep k tile) - a [B,4] x [4,50] library product otherwise
+            if segs_feat.is_cuda:
+                seg_info = self._drop(self._lin_k32(num[:, 3:7].float().contiguous(), self.seg_info_embed[0], act=1))
+            else:
+                seg_info = self._drop(F.relu(self.seg_info_embed[0](num[:, 3:7].float())))
             fc = torch.cat([F.layer_norm(fc, [fc.shape[-1]]), F.layer_norm(seg_info, [self.seg_info_size])], dim=-1)
         compact = (allow_compact and not torch.is_grad_enabled() and not self.training
                    and os.environ.get('GVD_COMPACT', '1') == '1'

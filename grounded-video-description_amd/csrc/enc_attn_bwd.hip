@@ -22,7 +22,6 @@
 // 176 = 5 k tiles + the shifted 16-column tail tile, the second product's first tile is fetched under the first product's
 // tail.  Same ascending k order per output as every other GEMM kernel of the library.
 #include "gemm_common.h"
-#include <cstdlib>
 #include "enc_dropout.h"
 #include "philox.h"
 
@@ -44,7 +43,6 @@ struct MapParams {
   float scale, c2, keep_scale;
   uint32_t thresh, seed_lo, seed_hi;
   int ntk;
-  int skew;                                // start skew of the workgroups in odd wave slots, in s_sleep(127) units (see kernel)
 };
 
 __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapParams p) {
@@ -55,14 +53,6 @@ __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapPara
   const int wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, half = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  // PHASE SKEW of the two co-resident workgroups.  Every workgroup of this launch does the same work - 2 x 5.5 k tiles of
-  // MFMAs, then an epilogue that issues none (exp2 / dropout hash / two 64 KB transposed store passes) - and two of them
-  // share a CU (one wave of each per SIMD).  Started together they STAY in step for the whole launch: both compete for the
-  // matrix pipe, then both leave it idle.  The workgroup whose waves sit in the odd wave slot of their SIMD sleeps about
-  // half a tile period once, at its start, so that from then on one workgroup's epilogue runs under the other's products.
-  if (p.skew > 0 && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) {        // HW_REG_HW_ID.wave_id, bit 0
-    for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
   const int tk_ = lid % p.ntk, tq_ = lid / p.ntk;
   const int bh = blockIdx.y, b = bh / p.nh, h = bh - b * p.nh;
@@ -297,8 +287,6 @@ extern "C" int gvd_enc_attn_bwd_maps(const float* qkv, int64_t ld, const float* 
   p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
   const int nt = (Rp + BM - 1) / BM;
   p.ntk = nt;
-  static const int skew_env = [] { const char* e = getenv("GVD_MAPS_SKEW"); return e ? atoi(e) : -1; }();
-  p.skew = skew_env >= 0 ? skew_env : 0;
   hipLaunchKernelGGL(enc_attn_bwd_maps_kernel, dim3((unsigned)(nt * nt), (unsigned)(B * n_heads)), dim3(256), 0, st, p);
   GVD_CHECK_LAUNCH();
   return 0;

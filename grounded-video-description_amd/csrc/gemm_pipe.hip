@@ -19,7 +19,6 @@
 //     (4 rows x 256 B per instruction instead of 2 rows x 128 B of dword stores) when the output allows it.
 // Numerics are identical to gemm_f32.hip: the same v_mfma_f32_32x32x2_f32 chain in the same k order per output.
 #include "gemm_common.h"
-#include <cstdlib>
 
 // DIRECT-TO-LDS OPERANDS: operand tiles of the plain (not K-strided) products go global -> LDS by direct loads
 // (buffer_load_dwordx4 ... lds, 16 bytes per lane on gfx950), without a register round trip and its ds_write_b128 pass (6 of
@@ -436,9 +435,9 @@ int gvd_gemm_pipe_launch(KParams& p, int batch, hipStream_t st) {
   }
   // a last tile at most half full in N (few N tiles) or in M (few M tiles) is worth the sub-tile skip
   const int remn = p.N - (p.ntn - 1) * BN, remm = p.M - (p.ntm - 1) * BM;
-  static const int edge_env = [] { const char* e = getenv("GVD_GEMM_EDGE"); return e ? atoi(e) : 0; }();
-  bool edge = (remn <= BN / 2 && p.ntn <= 4) || (!p.m_dev && remm <= BM / 2 && p.ntm <= 4);
-  if (edge_env == 1) edge = edge || remn <= BN / 2 || (!p.m_dev && remm <= BM / 2);      // (experiment: any tile count)
+  // (round 6, profiles/r06/gemm_edge_b.txt: the skip at ANY tile count - N = 1056, 9 column tiles, the last 32 wide - changes
+  // nothing for dX (1237 -> 1229 us) and costs dW 10 %: the partial tile is not what holds those shapes at 0.70)
+  const bool edge = (remn <= BN / 2 && p.ntn <= 4) || (!p.m_dev && remm <= BM / 2 && p.ntm <= 4);
   gvd_prof* prof = g_gemm_prof;
   if (prof) {
     double ktot = 0.0;

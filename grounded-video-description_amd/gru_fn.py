@@ -105,6 +105,6 @@ def gru_bidir_2layer_train(x, gru, flags=None):
         b_ih = torch.cat([g('bias_ih'), gr('bias_ih')], 0)
         out = GruLayerFn.apply(inp, w_ih, b_ih, g('weight_hh'), g('bias_hh'), gr('weight_hh'), gr('bias_hh'), flags)
         if l + 1 < gru.num_layers and gru.training and gru.dropout > 0:
-            out = F.dropout(out, gru.dropout, True)
+            out = K.dropout(out, gru.dropout, True) if hasattr(K, 'dropout') and out.is_cuda else F.dropout(out, gru.dropout, True)
         inp = out
     return inp

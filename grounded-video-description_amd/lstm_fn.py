@@ -85,6 +85,6 @@ def lstm_bidir_2layer_train(x, lstm, flags=None):
         # (b_ih and b_hh enter the gates as a sum: b_hh's gradient equals the gate-gradient column sums, like b_ih's)
         out = LstmLayerFn.apply(inp, w_ih, b_ih, g('weight_hh'), g('bias_hh'), gr('weight_hh'), gr('bias_hh'), flags)
         if l + 1 < lstm.num_layers and lstm.training and lstm.dropout > 0:
-            out = F.dropout(out, lstm.dropout, True)
+            out = K.dropout(out, lstm.dropout, True) if hasattr(K, 'dropout') and out.is_cuda else F.dropout(out, lstm.dropout, True)
         inp = out
     return inp

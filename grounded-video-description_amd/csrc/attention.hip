@@ -25,6 +25,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// (experiment switches of round 6 session D - tools/with_cflags.py builds the variants; the defaults are the product)
+#ifndef GVD_GROUP_SPLIT
+#define GVD_GROUP_SPLIT 1        // 1: one exponential per projection element for all beams; 0: exponent of the sum per beam
+#endif
+#ifndef GVD_GROUP_WAVES
+#define GVD_GROUP_WAVES 5
+#endif
+#ifndef GVD_GROUP_SB
+#define GVD_GROUP_SB 1           // scheduling barrier between the beams of the score pass
+#endif
 constexpr int ATT_A = 512;
 constexpr int ATT_H = 1024;
 constexpr int MAX_CHUNK = 64;   // rows per workgroup (LDS score buffer)
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(256, 8) void attn_partial_kernel(const FwdParams p)
 // ("shared across beams in a batched redesign").  Partials are written per beam row in the layout
 // attn_combine_kernel expects.  grid = (chunks, samples).
 template <int G, bool NT, int MODE>
-__global__ __launch_bounds__(256, 5) void attn_partial_group_kernel(const FwdParams p) {   // 5 waves / SIMD: <= 96 VGPRs (no spill)
+__global__ __launch_bounds__(256, GVD_GROUP_WAVES) void attn_partial_group_kernel(const FwdParams p) {   // 5 waves / SIMD: <= 96 VGPRs (no spill)
   __shared__ float s_score[G][MAX_CHUNK];
   __shared__ float s_m[G];
   __shared__ int s_live[MAX_CHUNK];
@@ -230,6 +240,7 @@ __global__ __launch_bounds__(256, 5) void attn_partial_group_kernel(const FwdPar
   const int rows = min(S.chunk, S.N - n0);
 
   const bool addm = MODE == GVD_SCORE_ADD || sidx == 1;      // (compile-time true for the README configuration)
+  const bool split = GVD_GROUP_SPLIT && addm;
   const float qscale = (MODE == GVD_SCORE_DOT && !addm) ? 1.0f : GVD_TWO_LOG2E;
   const AttnLaneW W = lane_w_sel<MODE>(addm, S.w, lane);
   // additive score: s_q holds eq_g = 2^(C q_g) - one exponential per projection element then serves all G beams (gvd_common.h)
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(256, 5) void attn_partial_group_kernel(const FwdPar
   for (int i = tid; i < G * (ATT_A / 4); i += 256) {      // pre-scaled queries (tanh_fast, gvd_common.h)
     const int g = i / (ATT_A / 4), a4 = i % (ATT_A / 4);
     const f32x4 qv = *reinterpret_cast<const f32x4*>(S.q + (int64_t)(smp * G + g) * S.ldq + 4 * a4);
-    if (addm) {
+    if (split) {
       f32x4 ev;
       bool wide = false;
 #pragma unroll
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(256, 5) void attn_partial_group_kernel(const FwdPar
     int lz = 0;
     asm volatile("" : "+v"(lz));       // opaque 0: keeps the query reads inside the row loop (loop-invariant code motion
                                        // would put all 8 G of them back into registers)
-    if (addm) {
+    if (split) {
       // one exponential per element for all G beams: ex = 2^(C x) here, eq_g = 2^(C q_g) from LDS
       float ymax = 0.f;
 #pragma unroll
@@ -332,7 +343,9 @@ __global__ __launch_bounds__(256, 5) void attn_partial_group_kernel(const FwdPar
           }
           sc0[g] = wave_sum(a0) + ab;
           sc1[g] = wave_sum(b0) + ab;
+#if GVD_GROUP_SB
           __builtin_amdgcn_sched_barrier(0);     // one beam's 8 query values live at a time (all G x 8 at once: spills)
+#endif
         }
       }
     } else {
@@ -366,7 +379,7 @@ __global__ __launch_bounds__(256, 5) void attn_partial_group_kernel(const FwdPar
   __syncthreads();
   // exact pass for the row pairs the one-exponential form could not take (|C x| or |C q| > 63: tanh is saturated there, but
   // the exponent must be formed from the sum): the one-row form, beam after beam; normally s_wn == 0
-  if (addm && s_wn > 0) {
+  if (split && s_wn > 0) {
 #pragma unroll 1
     for (int t = wave; t < s_wn; t += 4) {
       const int i = s_wl[t];

@@ -99,7 +99,11 @@ __device__ __forceinline__ GvdExpSplit gvd_exp2_scaled(float x) {      // 2^(C x
   const float y = x * GVD_TWO_LOG2E;
   const float d = fmaf(x, GVD_TWO_LOG2E, -y);
   const float e = __builtin_amdgcn_exp2f(y);
+#ifdef GVD_GROUP_NOCORR
+  return {e, y};
+#else
   return {fmaf(e * GVD_LN2, d, e), y};
+#endif
 }
 
 // The other two score functions of the region attention (opts.py:63 `--region_attn_mode`; gvd_attn_side.score_mode):

@@ -293,8 +293,11 @@ def test_one_optimisation_step_matches_reference(name, golden_dir):
 
 TRAJ_CASES = [n for n, s in cases.CASES.items() if s['mode'] == 'traj']
 # bounds of the optimiser-state pins after step 4 (measured values: see the test's printout in profiles/r06/)
-M_NORM_TOL, M_PROJ_TOL = 6e-2, 6e-2
-V_NORM_TOL, V_PROJ_TOL = 6e-2, 6e-2
+# = 1.5 x the largest value measured over the 81 parameters (session C: exp_avg projections 0.059, norm 0.022; exp_avg_sq
+# projections 0.074, norm 0.048 - the same Adam amplification of rounding-level gradient differences that the losses show:
+# tools/adam_noise_amplification.py reproduces these sizes between two CPU oracle runs, profiles/r06/adam_noise_amplification.txt)
+M_NORM_TOL, M_PROJ_TOL = 3.3e-2, 9e-2
+V_NORM_TOL, V_PROJ_TOL = 7.3e-2, 1.1e-1
 STEP_DN_TOL = 2e-2
 
 
@@ -367,13 +370,14 @@ def test_optimisation_trajectory_matches_reference(name, golden_dir):
         if vn > 1e-6 * big_v:
             errs.append(('exp_avg_sq proj', cases.projection_error(n, s_['exp_avg_sq'], g['exp_avg_sq_proj'][i], vn), V_PROJ_TOL, n))
             errs.append(('exp_avg_sq norm', abs(float(s_['exp_avg_sq'].double().norm()) - vn) / vn, V_NORM_TOL, n))
+    for i, (got, want) in enumerate(zip(step_dn, g['step_delta_norms'])):
+        print('step %d: |update| %.6g vs reference %.6g (%.3g)' % (i + 1, got, want, abs(got - want) / want))
     for kind in ('exp_avg proj', 'exp_avg norm', 'exp_avg_sq proj', 'exp_avg_sq norm'):
         top = sorted((e for e in errs if e[0] == kind), key=lambda e: -e[1])[:4]
         print('optimiser state after step 4, largest %s errors: %s' % (kind, ['%.3g %s' % (e[1], e[3]) for e in top]))
     bad = [e for e in errs if not e[1] < e[2]]
     assert not bad, bad
     for i, (got, want) in enumerate(zip(step_dn, g['step_delta_norms'])):
-        print('step %d: |update| %.6g vs reference %.6g (%.3g)' % (i + 1, got, want, abs(got - want) / want))
         assert abs(got - want) <= STEP_DN_TOL * want, (i, got, want)
 
 

@@ -44,5 +44,16 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 nbytes = B * (R + Ft) * (A + H) * 4
+# the streaming (partial) kernel alone: HIP event pairs around its launches
+from gvd_amd import hip  # noqa: E402
+timer = hip.KernelTimer(max_pairs=iters)
+ops.set_kernel_timer(timer)
+timer.reset()
+for _ in range(iters):
+    out = ops.attention_step(region, temporal)
+torch.cuda.synchronize()
+kms, kn = timer.read()
+ops.set_kernel_timer(None)
+print('partial kernel alone: %.1f us (%d launches), %.1f GB/s algorithmic' % (1e3 * kms / kn, kn, nbytes / (kms / kn) / 1e6))
 print('attention_step (partial+combine) chunk=%s B=%d Ft=%d R=%d group=%d: %.1f us/call, %.1f GB/s algorithmic'
       % ('50', B, Ft, R, K, ms * 1e3, nbytes / ms / 1e6))

@@ -20,6 +20,9 @@ b.OBJ = os.path.join(d, 'obj')
 b.LIB = os.path.join(d, 'libgvd_hip.so')
 b.STAMP = b.LIB + '.srchash'
 b.CFLAGS = list(b.CFLAGS) + flags
+for f in os.environ.get('GVD_VARIANT_NOEXTRA', '').split(','):      # drop the per-file extra flags of build.EXTRA for these sources
+    if f:
+        b.EXTRA = {k: v for k, v in b.EXTRA.items() if k != f}
 if os.environ.get('GVD_VARIANT_CSRC'):        # build the variant from ANOTHER copy of csrc/ (e.g. `git archive` of an earlier commit)
     b.CSRC = os.path.abspath(os.environ['GVD_VARIANT_CSRC'])
 b.build_library(verbose=False)

@@ -529,7 +529,7 @@ class TopDownModel(nn.Module):
     def _obj_interact(self, x, key_bias=None):
         """transformer.py:135-190,244-254 as built at model.py:126-135 (6 uneven heads, scale sqrt(d_model), no padding
         mask, custom LayerNorm): the flash-style kernels without autograd, the fused MFMA training layers with it (any region
-        count up to 2048 padded rows per sample).  Beyond that - and on CPU tensors (the control-flow tests) - the elementwise
+        count up to 4096 padded rows per sample).  Beyond that - and on CPU tensors (the control-flow tests) - the elementwise
         formulation below: projections / feed-forward on the MFMA GEMM, the attention maps through torch (counted by
         ops.library_fallback; an error under GVD_STRICT)."""
         d = x.shape[-1]

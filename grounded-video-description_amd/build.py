@@ -21,10 +21,7 @@ HEADERS = ['gvd_common.h', 'gemm_common.h', 'gemv_f32.h', 'top2.h', 'decode_pers
 CFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
 # decode_persistent.hip keeps ~150 weight registers per lane for the whole launch; the SLP vectorizer would pair its
 # accumulators into v_pk_fma_f32 and splat every resident weight into a register PAIR (2x the footprint -> spills)
-# attention.hip: the beam-group kernel's score pass (one exponential per projection element for all G beams) keeps 16
-# exponentials + 8 weights + one beam's 8 query values per lane; SLP pairs the two rows' chains into v_pk_* ops - no faster on
-# gfx950 - and spills 110 registers at G = 5 (0 without it); the row kernel's loops are instruction for instruction the same
-EXTRA = {'decode_persistent.hip': ['-fno-slp-vectorize'], 'attention.hip': ['-fno-slp-vectorize']}
+EXTRA = {'decode_persistent.hip': ['-fno-slp-vectorize']}
 LDFLAGS = ['--offload-arch=gfx950', '-shared', '-fPIC', '-fno-gpu-rdc', '-Wl,-z,defs']     # (-z defs: an undefined symbol is a LINK error, not a dlopen failure on the GPU box)
 
 

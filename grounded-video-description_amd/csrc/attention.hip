@@ -25,16 +25,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-// (experiment switches of round 6 session D - tools/with_cflags.py builds the variants; the defaults are the product)
-#ifndef GVD_GROUP_SPLIT
-#define GVD_GROUP_SPLIT 1        // 1: one exponential per projection element for all beams; 0: exponent of the sum per beam
-#endif
-#ifndef GVD_GROUP_WAVES
-#define GVD_GROUP_WAVES 5
-#endif
-#ifndef GVD_GROUP_SB
-#define GVD_GROUP_SB 1           // scheduling barrier between the beams of the score pass
-#endif
 constexpr int ATT_A = 512;
 constexpr int ATT_H = 1024;
 constexpr int MAX_CHUNK = 64;   // rows per workgroup (LDS score buffer)
@@ -218,7 +208,7 @@ __global__ __launch_bounds__(256, 8) void attn_partial_kernel(const FwdParams p)
 // ("shared across beams in a batched redesign").  Partials are written per beam row in the layout
 // attn_combine_kernel expects.  grid = (chunks, samples).
 template <int G, bool NT, int MODE>
-__global__ __launch_bounds__(256, GVD_GROUP_WAVES) void attn_partial_group_kernel(const FwdParams p) {   // 5 waves / SIMD: <= 96 VGPRs (no spill)
+__global__ __launch_bounds__(256, 6) void attn_partial_group_kernel(const FwdParams p) {   // >= 6 waves / SIMD: <= 80 VGPRs
   __shared__ float s_score[G][MAX_CHUNK];
   __shared__ float s_m[G];
   __shared__ int s_live[MAX_CHUNK];
@@ -226,9 +216,6 @@ __global__ __launch_bounds__(256, GVD_GROUP_WAVES) void attn_partial_group_kerne
   // the G pre-scaled queries live in LDS, not in 8 G registers per lane: with them in registers the kernel needed 105
   // VGPRs at G = 5 (4 waves per SIMD; PMC: 2.9 resident on average, 70 % of the wave cycles parked on memory)
   __shared__ __attribute__((aligned(16))) float s_q[G][ATT_A];
-  __shared__ int s_wide;                         // a query outside the range of the one-exponential form (gvd_common.h)
-  __shared__ int s_wn;                           // row pairs left to the exact pass (a projection value out of that range)
-  __shared__ int s_wl[MAX_CHUNK / 2 + 1];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int smp = blockIdx.y;                    // sample; its beam rows are smp*G + g
   int c = blockIdx.x;
@@ -240,29 +227,12 @@ __global__ __launch_bounds__(256, GVD_GROUP_WAVES) void attn_partial_group_kerne
   const int rows = min(S.chunk, S.N - n0);
 
   const bool addm = MODE == GVD_SCORE_ADD || sidx == 1;      // (compile-time true for the README configuration)
-  const bool split = GVD_GROUP_SPLIT && addm;
   const float qscale = (MODE == GVD_SCORE_DOT && !addm) ? 1.0f : GVD_TWO_LOG2E;
   const AttnLaneW W = lane_w_sel<MODE>(addm, S.w, lane);
-  // additive score: s_q holds eq_g = 2^(C q_g) - one exponential per projection element then serves all G beams (gvd_common.h)
-  if (tid == 0) { s_wide = 0; s_wn = 0; }
-  __syncthreads();
   for (int i = tid; i < G * (ATT_A / 4); i += 256) {      // pre-scaled queries (tanh_fast, gvd_common.h)
     const int g = i / (ATT_A / 4), a4 = i % (ATT_A / 4);
-    const f32x4 qv = *reinterpret_cast<const f32x4*>(S.q + (int64_t)(smp * G + g) * S.ldq + 4 * a4);
-    if (split) {
-      f32x4 ev;
-      bool wide = false;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const GvdExpSplit t = gvd_exp2_scaled(qv[k]);
-        ev[k] = t.e;
-        wide = wide || !(fabsf(t.y) <= GVD_EXP_SPLIT_LIMIT);        // (NaN counts as wide: the one-row form propagates it)
-      }
-      *reinterpret_cast<f32x4*>(&s_q[g][4 * a4]) = ev;
-      if (wide) s_wide = 1;
-    } else {
-      *reinterpret_cast<f32x4*>(&s_q[g][4 * a4]) = qscale * qv;
-    }
+    *reinterpret_cast<f32x4*>(&s_q[g][4 * a4]) =
+        qscale * *reinterpret_cast<const f32x4*>(S.q + (int64_t)(smp * G + g) * S.ldq + 4 * a4);
   }
   const float ab = (MODE == GVD_SCORE_DOT && !addm) ? 0.f : *S.alpha_bias;
   const float* pf = S.p_feats + ((int64_t)smp * S.N + n0) * ATT_A;
@@ -295,67 +265,26 @@ __global__ __launch_bounds__(256, GVD_GROUP_WAVES) void attn_partial_group_kerne
   }
   __syncthreads();
   const int nlive = s_n[0];
-  const bool wide_q = s_wide != 0;
   // ---- phase 1: two projection rows per wave per pass (4 x 16 B per lane in flight), G scores from each
   for (int i = wave * 2; i < nlive; i += 8) {
     const bool two = (i + 1) < nlive;
     const int r = s_live[i], r2 = two ? s_live[i + 1] : r;
     const float* p0 = pf + (int64_t)r * ATT_A;
     const float* p1 = pf + (int64_t)r2 * ATT_A;
-    f32x4 x00 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 4 * lane));
-    f32x4 x01 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane));
-    f32x4 x10 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 4 * lane));
-    f32x4 x11 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 256 + 4 * lane));
+    const f32x4 x00 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 4 * lane));
+    const f32x4 x01 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane));
+    const f32x4 x10 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 4 * lane));
+    const f32x4 x11 = ld_stream<NT>(reinterpret_cast<const f32x4*>(p1 + 256 + 4 * lane));
     float sc0[G], sc1[G];
     int lz = 0;
     asm volatile("" : "+v"(lz));       // opaque 0: keeps the query reads inside the row loop (loop-invariant code motion
                                        // would put all 8 G of them back into registers)
-    if (split) {
-      // one exponential per element for all G beams: ex = 2^(C x) here, eq_g = 2^(C q_g) from LDS
-      float ymax = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {       // in place: x.. become ex = 2^(C x)
-        const GvdExpSplit a = gvd_exp2_scaled(x00[k]), b2 = gvd_exp2_scaled(x01[k]), c2 = gvd_exp2_scaled(x10[k]),
-                          d2 = gvd_exp2_scaled(x11[k]);
-        x00[k] = a.e; x01[k] = b2.e; x10[k] = c2.e; x11[k] = d2.e;
-        ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(a.y), fabsf(b2.y))), fmaxf(fabsf(c2.y), fabsf(d2.y)));
-      }
-      const f32x4 e00 = x00, e01 = x01, e10 = x10, e11 = x11;
-      const bool wide = wide_q || __ballot(!(ymax <= GVD_EXP_SPLIT_LIMIT)) != 0ull;      // wave-uniform
-      if (wide) {           // rare: this row pair is scored by the exact pass after the loop
-        if (lane == 0) s_wl[atomicAdd(&s_wn, 1)] = i;
-        continue;
-      }
-      {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const f32x4 q0 = *reinterpret_cast<const f32x4*>(&s_q[g][4 * lane + lz]);
-          const f32x4 q1 = *reinterpret_cast<const f32x4*>(&s_q[g][256 + 4 * lane + lz]);
-          // one chain per row in the k order of attn_score_lane (the SLP vectoriser would pair two chains into v_pk_fma_f32 -
-          // no faster on gfx950 - at the price of register pairs: 110 spilled registers at G = 5)
-          float a0 = W.wsum, b0 = W.wsum;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            a0 = fmaf(W.wn0[k], __builtin_amdgcn_rcpf(fmaf(e00[k], q0[k], 1.0f)), a0);
-            a0 = fmaf(W.wn1[k], __builtin_amdgcn_rcpf(fmaf(e01[k], q1[k], 1.0f)), a0);
-            b0 = fmaf(W.wn0[k], __builtin_amdgcn_rcpf(fmaf(e10[k], q0[k], 1.0f)), b0);
-            b0 = fmaf(W.wn1[k], __builtin_amdgcn_rcpf(fmaf(e11[k], q1[k], 1.0f)), b0);
-          }
-          sc0[g] = wave_sum(a0) + ab;
-          sc1[g] = wave_sum(b0) + ab;
-#if GVD_GROUP_SB
-          __builtin_amdgcn_sched_barrier(0);     // one beam's 8 query values live at a time (all G x 8 at once: spills)
-#endif
-        }
-      }
-    } else {
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(&s_q[g][4 * lane + lz]);
-        const f32x4 q1 = *reinterpret_cast<const f32x4*>(&s_q[g][256 + 4 * lane + lz]);
-        sc0[g] = wave_sum(score_sel<MODE>(addm, x00, x01, q0, q1, W)) + ab;
-        sc1[g] = wave_sum(score_sel<MODE>(addm, x10, x11, q0, q1, W)) + ab;
-      }
+    for (int g = 0; g < G; ++g) {
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(&s_q[g][4 * lane + lz]);
+      const f32x4 q1 = *reinterpret_cast<const f32x4*>(&s_q[g][256 + 4 * lane + lz]);
+      sc0[g] = wave_sum(score_sel<MODE>(addm, x00, x01, q0, q1, W)) + ab;
+      sc1[g] = wave_sum(score_sel<MODE>(addm, x10, x11, q0, q1, W)) + ab;
     }
     if (lane < 2 * G) {
       const int g = lane % G, second = lane / G;
@@ -377,38 +306,6 @@ __global__ __launch_bounds__(256, GVD_GROUP_WAVES) void attn_partial_group_kerne
     }
   }
   __syncthreads();
-  // exact pass for the row pairs the one-exponential form could not take (|C x| or |C q| > 63: tanh is saturated there, but
-  // the exponent must be formed from the sum): the one-row form, beam after beam; normally s_wn == 0
-  if (split && s_wn > 0) {
-#pragma unroll 1
-    for (int t = wave; t < s_wn; t += 4) {
-      const int i = s_wl[t];
-      const bool two = (i + 1) < nlive;
-      const int r = s_live[i], r2 = two ? s_live[i + 1] : r;
-      const float* p0 = pf + (int64_t)r * ATT_A;
-      const float* p1 = pf + (int64_t)r2 * ATT_A;
-      const f32x4 x00 = *reinterpret_cast<const f32x4*>(p0 + 4 * lane), x01 = *reinterpret_cast<const f32x4*>(p0 + 256 + 4 * lane);
-      const f32x4 x10 = *reinterpret_cast<const f32x4*>(p1 + 4 * lane), x11 = *reinterpret_cast<const f32x4*>(p1 + 256 + 4 * lane);
-#pragma unroll 1
-      for (int g = 0; g < G; ++g) {
-        const int64_t row = (int64_t)smp * G + g;
-        const f32x4 q0 = GVD_TWO_LOG2E * *reinterpret_cast<const f32x4*>(S.q + row * S.ldq + 4 * lane);
-        const f32x4 q1 = GVD_TWO_LOG2E * *reinterpret_cast<const f32x4*>(S.q + row * S.ldq + 256 + 4 * lane);
-        const float e0 = wave_sum(attn_score_lane(x00, x01, q0, q1, W)) + ab;
-        const float e1 = wave_sum(attn_score_lane(x10, x11, q0, q1, W)) + ab;
-        if (lane < 2 && (lane == 0 || two)) {
-          const int rr = lane ? r2 : r;
-          float e = lane ? e1 : e0;
-          if (S.att_mask && S.att_mask[row * S.ld_att_mask + n0 + rr]) e = GVD_MIN_VALUE;
-          s_score[g][rr] = e;
-          if (S.scores_out) S.scores_out[row * S.ld_scores + n0 + rr] = e;
-          if (S.logits_out)
-            S.logits_out[row * S.ld_logits + n0 + rr] = (S.pnt_mask && S.pnt_mask[row * S.ld_pnt_mask + n0 + rr]) ? GVD_MIN_VALUE : e;
-        }
-      }
-    }
-    __syncthreads();
-  }
 
   // ---- chunk-local softmax numerators: wave g handles beam g (G <= 8 -> two passes over the 4 waves)
   for (int g = wave; g < G; g += 4) {

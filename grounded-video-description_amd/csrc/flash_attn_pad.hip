@@ -114,7 +114,7 @@ struct PParams {
   float keep_scale;      // 1 / (1 - p)
 };
 
-constexpr int MAX_TRAIN_KEYS = 2048;      // LDS slice of the staged key bias (TRAIN)
+constexpr int MAX_TRAIN_KEYS = 4096;      // LDS slice of the staged key bias (TRAIN): 3 x 48 KB tile buffers + 16 KB = the CU's 160 KB
 
 template <bool TRAIN, int NW, int TK>
 __global__ __launch_bounds__(512, 2) void flash_attn_pad_kernel(const PParams p) {

@@ -84,28 +84,6 @@ __device__ __forceinline__ float attn_score_lane(gvd_score_f32x4 x0, gvd_score_f
   return s;
 }
 
-// ---- the G-beam form of the additive score (attn_partial_group_kernel): ONE exponential per projection element serves all
-// the beams of a sample.  exp2(C (x + q_g)) = exp2(C x) exp2(C q_g): per element v_mul (y = C x), v_fma (the rounding
-// residual of y: d = x C - y, exact), v_exp (2^y), 2 ops for the correction 2^y (1 + ln2 d) - together they give 2^(C x)
-// to ~1.5 ulp, like the exp2(fma(x, C, C q)) of the one-row form - and then per beam fma (1 + ex eq_g), v_rcp, fma into the
-// score: 8 + 6 G issue slots per element instead of 11 G (G = 5: 38 vs 55; transcendentals 24 vs 40).  eq_g = 2^(C q_g)
-// (+ the same correction) is formed once per workgroup.  Range: |C x| <= 63 and |C q| <= 63 keep ex eq inside the normal
-// range (no inf * 0); anything beyond takes the one-row form (tanh is saturated there either way).  |error| of tanh
-// <= 4e-7 absolute (tests/test_gpu_kernels.py::test_attention_beam_group_kernel_matches_the_row_kernel).
-constexpr float GVD_LN2 = 0.6931471805599453f;
-constexpr float GVD_EXP_SPLIT_LIMIT = 63.0f;
-struct GvdExpSplit { float e; float y; };
-__device__ __forceinline__ GvdExpSplit gvd_exp2_scaled(float x) {      // 2^(C x), C = 2 log2(e); .y = C x as rounded
-  const float y = x * GVD_TWO_LOG2E;
-  const float d = fmaf(x, GVD_TWO_LOG2E, -y);
-  const float e = __builtin_amdgcn_exp2f(y);
-#ifdef GVD_GROUP_NOCORR
-  return {e, y};
-#else
-  return {fmaf(e * GVD_LN2, d, e), y};
-#endif
-}
-
 // The other two score functions of the region attention (opts.py:63 `--region_attn_mode`; gvd_attn_side.score_mode):
 //   GVD_SCORE_MUL ('mix_mul', AttModel.py:82-83)   sum_k w_k tanh(x_k q_k): the same five issue slots per element with the
 //                 exponent x_k (C q_k) in place of x_k C + C q_k

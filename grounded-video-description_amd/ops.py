@@ -1580,9 +1580,10 @@ class _EncLayerFn(torch.autograd.Function):
 
 
 def enc_layer_ok(R, d, n_heads=6):
-    """Shapes the fused training layer takes: d_model 1024 (the row kernels), heads of <= 176 columns, at most 2048 padded
-    rows per sample (the core's staged key bias)."""
-    return d == 1024 and -(-d // n_heads) <= HEAD_PAD and -(-R // 32) * 32 <= 2048 and R >= 1
+    """Shapes the fused training layer takes: d_model 1024 (the row kernels), heads of <= 176 columns, at most 4096 padded
+    rows per sample (the key bias the flash-style core stages in LDS: 16 KB next to its three 48 KB tile buffers = the CU's
+    160 KB; 40 sampled frames x 100 proposals)."""
+    return d == 1024 and -(-d // n_heads) <= HEAD_PAD and -(-R // 32) * 32 <= 4096 and R >= 1
 
 
 def enc_layer_rows(B, R):

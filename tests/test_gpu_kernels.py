@@ -273,24 +273,14 @@ def test_masked_lsm_loss():
 # attn_partial_group_kernel<5, true> (attention.hip: `nt`), the one bench.py's beam section times at 64 segments x 2000 regions
 @pytest.mark.parametrize('K,Bs,N,Ft', [(5, 3, 203, 10), (3, 2, 2000, 37), (2, 7, 100, 1), (4, 1, 64, 480),
                                        (5, 33, 1000, 10), (5, 17, 2000, 10), (3, 34, 1000, 10)])
-def test_attention_beam_group_kernel_matches_the_row_kernel(K, Bs, N, Ft):
-    """Beam search: the K beam rows of a sample share its features.  The grouped kernel (one workgroup per chunk and SAMPLE,
-    features read once for K queries) scores a projection element with ONE exponential for all K beams,
-    exp2(C x) exp2(C q_g) instead of exp2(C (x + q_g)) (csrc/gvd_common.h: gvd_exp2_scaled) - the same function to a few
-    ulp, not the same bits.  Checked: (i) against fp64, the grouped scores are as accurate as the row kernel's (the error of
-    both is the fp32 summation of 512 terms; bound: 4e-7 per tanh x sum |w|); (ii) masks / fills are identical; (iii) the
-    contexts agree to 2e-5 relative; (iv) samples / rows OUT of the split's range (|C x| or |C q| > 63) take the one-row form
-    and are then bit-for-bit the row kernel."""
+def test_attention_beam_group_kernel_is_bitwise_the_row_kernel(K, Bs, N, Ft):
+    """Beam search: the K beam rows of a sample share its features.  The grouped kernel (one workgroup per chunk and
+    SAMPLE, features read once for K queries) must give bit-for-bit what the per-row kernel gives on the expanded rows."""
     g = _g(K * 100 + N)
     A, H = 512, 1024
     feats, p_feats = torch.randn(Bs, N, H, generator=g), torch.randn(Bs, N, A, generator=g)
     tf, tp = torch.randn(Bs, Ft, H, generator=g), torch.randn(Bs, Ft, A, generator=g)
     q = torch.randn(Bs * K, 2 * A, generator=g)
-    # out-of-range cases: the LAST sample has one beam with a huge query component (whole sample -> one-row form), sample 0 has
-    # two projection rows with huge entries (those row pairs -> the exact pass)
-    q[Bs * K - 1, A + 7] = 40.0
-    p_feats[0, 3, 11] = -35.0
-    p_feats[0, min(N - 1, 40), 300] = 50.0
     w2, w1 = torch.randn(1, A, generator=g) * 0.1, torch.randn(1, A, generator=g) * 0.1
     b2, b1 = torch.randn(1, generator=g), torch.randn(1, generator=g)
     mask = (torch.rand(Bs * K, N + 1, generator=g) < 0.2).to(torch.uint8)
@@ -301,7 +291,7 @@ def test_attention_beam_group_kernel_matches_the_row_kernel(K, Bs, N, Ft):
     temporal = dict(feats=tf.cuda(), p_feats=tp.cuda(), q=q.cuda()[:, :A], w=w1.cuda(), alpha_bias=b1.cuda(), group=K)
     out, cr, ct = ops.attention_step(region, temporal, want_separate=True)
     torch.cuda.synchronize()
-    # the row kernel on explicitly expanded features (group = 0)
+    # the row kernel on explicitly expanded features (group = 0): the same bits
     lo2 = torch.zeros(Bs * K, N).cuda()
     region = dict(feats=feats.repeat_interleave(K, 0).cuda(), p_feats=p_feats.repeat_interleave(K, 0).cuda(),
                   q=q.cuda()[:, A:], w=w2.cuda(), alpha_bias=b2.cuda(), att_mask=mask.cuda()[:, 1:],
@@ -309,22 +299,8 @@ def test_attention_beam_group_kernel_matches_the_row_kernel(K, Bs, N, Ft):
     temporal = dict(feats=tf.repeat_interleave(K, 0).cuda(), p_feats=tp.repeat_interleave(K, 0).cuda(), q=q.cuda()[:, :A],
                     w=w1.cuda(), alpha_bias=b1.cuda())
     ref, rr, rt = ops.attention_step(region, temporal, want_separate=True)
-    lo, lo2 = lo.cpu(), lo2.cpu()
-    live = ~mask[:, 1:].bool()
-    assert torch.equal(lo == O.MIN_VALUE, lo2 == O.MIN_VALUE) and torch.equal(lo == O.MIN_VALUE, ~live)
-    # (i) fp64 truth of the live region scores
-    e64 = (torch.tanh(p_feats.repeat_interleave(K, 0).double() + q[:, A:].double().unsqueeze(1)) @ w2.double().t()).squeeze(-1) + b2.double()
-    tol = 4e-7 * float(w2.abs().sum()) + 2e-6
-    err_g = float((lo.double() - e64)[live].abs().max())
-    err_r = float((lo2.double() - e64)[live].abs().max())
-    print('region scores vs fp64: grouped %.3g, row kernel %.3g (bound %.3g)' % (err_g, err_r, tol))
-    assert err_g <= tol and err_r <= tol
-    # (iii) contexts
-    for a, b in ((out, ref), (cr, rr), (ct, rt)):
-        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
-    # (iv) out-of-range inputs run the one-row form: same bits as the row kernel
-    assert torch.equal(lo[(Bs - 1) * K:], lo2[(Bs - 1) * K:])
-    assert torch.equal(lo[:K, 3], lo2[:K, 3]) and torch.equal(lo[:K, min(N - 1, 40)], lo2[:K, min(N - 1, 40)])
+    for a, b in ((out, ref), (cr, rr), (ct, rt), (lo, lo2)):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize('barrier', ['counter', 'cg'])
@@ -909,10 +885,14 @@ def test_enc_attn_core_key_bias():
     assert not kgrad[0, 40:].any() and not kgrad[2, 1:5].any()
 
 
-def test_encoder_training_path_matches_oracle_autograd():
-    """The all-MFMA training encoder (padded region axis, packed projection, flash-style attention core, fused LayerNorm
-    forward + backward) against the oracle's restatement of transformer.py:135-190 under autograd, eval mode: output, input
-    gradient and every parameter gradient."""
+@pytest.mark.parametrize('B,R', [(3, 40), (4, 40), (3, 42), (2, 111), (1, 2500)])
+def test_encoder_training_path_matches_oracle_autograd(B, R):
+    """The all-MFMA training encoder (one autograd function per layer: packed projection, flash-style attention core, fused
+    LayerNorm forward + backward, residual gradients as dX addends) against the oracle's restatement of
+    transformer.py:135-190 under autograd, eval mode: output, input gradient and every parameter gradient.  Shapes: (3, 40)
+    B R % 32 != 0 -> region axis padded to 64; (4, 40) the rows of the batch packed back to back, no pad rows; (3, 42) and
+    (2, 111) R % 4 != 0 -> padded layout with the rows R .. R4-1 masked as keys; (1, 2500) above 2048 padded rows (the
+    16 KB key-bias stage of the flash-style core)."""
     from gvd_amd import att_model
     opt = gvd_amd.opts.default_opt(vocab_size=60)
     torch.manual_seed(3)
@@ -923,8 +903,8 @@ def test_encoder_training_path_matches_oracle_autograd():
                 ln.gamma.add_(torch.randn(1024, device='cuda') * 0.1)
                 ln.beta.add_(torch.randn(1024, device='cuda') * 0.1)
     g = _g(9)
-    x = torch.randn(3, 40, 1024, generator=g)
-    dout = torch.randn(3, 40, 1024, generator=g)
+    x = torch.randn(B, R, 1024, generator=g)
+    dout = torch.randn(B, R, 1024, generator=g)
     names = [n for n, _ in model.named_parameters() if n.startswith('obj_interact.')]
     params = dict(model.named_parameters())
     xi = x.cuda().requires_grad_(True)

@@ -102,14 +102,14 @@ def test_decode_runs_no_library_gemm_or_softmax(B, beam):
 
 
 def test_strict_mode_raises_where_a_fallback_would_run():
-    """A shape none of the kernels takes - the training encoder above 2048 padded region rows per segment (the staged key bias
+    """A shape none of the kernels takes - the training encoder above 4096 padded region rows per segment (the staged key bias
     of the flash-style core) - is an error under GVD_STRICT and the torch formulation of transformer.py:90-105 without it;
     counted either way.  Awkward Linear shapes (rows off 16 bytes, odd widths, a contraction that is not a multiple of 32) do
     NOT fall back: they are zero-padded onto the kernels."""
     opt = opts.default_opt(vocab_size=60)
     torch.manual_seed(1)
     model = att_model.TopDownModel(opt).cuda().eval()
-    x = torch.randn(1, 2100, 1024, device='cuda', requires_grad=True)
+    x = torch.randn(1, 4200, 1024, device='cuda', requires_grad=True)
     n0 = ops.library_call_count()
     with pytest.raises(GvdHipError, match='GVD_STRICT'):
         model._obj_interact(x)

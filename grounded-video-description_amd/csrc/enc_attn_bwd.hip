@@ -29,7 +29,6 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int NLD = 4;
-constexpr int EPI_LD = 68;
 constexpr int TILE = BM * BK;              // floats of one operand tile (unpadded)
 
 struct MapParams {
@@ -45,8 +44,13 @@ struct MapParams {
   int ntk;
 };
 
+// Round 6 (profiles/r06/maps_forms_e.txt, maps_ablate_f.txt): the epilogue is branch-free, reads lse / delta / the dropout row
+// key (hashed once per query row by one thread) as one 16-byte LDS read per row, and stores both maps row by row straight from
+// the accumulator layout - 2.93 -> 2.67 ms per launch at batch_size = 64, bit for bit the maps of the LDS-transposed form of
+// rounds 4-5; the products alone take 2.35 ms.  A workgroup that walks the key tiles of its query tile (next tile's operands
+// in flight during the epilogue) measured 2.80 ms and was dropped.
 __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapParams p) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * 64 * EPI_LD];          // 69,632 B: operand buffers, then the epilogue slices
+  __shared__ __attribute__((aligned(16))) float smem[4 * TILE + 640];      // operand buffers, per-row / per-key vectors
   float* As = smem;                       // [2][128][32]
   float* Ws = smem + 2 * TILE;            // [2][128][32]
   const int tid = threadIdx.x;
@@ -154,79 +158,78 @@ __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapPara
   // per thread, fetched under the first tile's load latency and parked in the 4 KB of LDS between the operand buffers and
   // the end of the epilogue slices (64 dependent scalar loads per thread in the epilogue cost 0.24 of the kernel's 3.4 ms:
   // ablation timings, profiles/r04/bwd_maps_ablate_b.log).
-  float* rowv = smem + 4 * TILE;               // [128][lse, delta]
-  float* colv = rowv + 256;                    // [128] key bias (log2 units)
-  {
+  float* rowv = smem + 4 * TILE;               // [128][lse, delta, dropout row key (2 words)]: one 16-byte read per row in the epilogue
+  float* colv = rowv + 512;                    // [128] key bias (log2 units)
+  const bool drop = p.thresh != 0u;
+  if (tid < 128) {
     const int64_t mrow = (int64_t)bh * p.Rp;
-    const int q = m0 + (tid & 127);
-    float v = 0.f;
-    if (q < R) v = tid < 128 ? p.lse2[mrow + q] : p.delta[mrow + q];
-    rowv[2 * (tid & 127) + (tid >> 7)] = v;
-    if (tid < 128) {
-      const int k = n0 + tid;
-      colv[tid] = (p.kbias && k < R) ? p.kbias[(int64_t)b * p.Rp + k] * 1.4426950408889634f : 0.f;
+    const int q = m0 + tid;
+    f32x4 v = {1e30f, 0.f, 0.f, 0.f};          // (rows >= R: P = exp2(. - 1e30) = 0)
+    if (q < R) {
+      v[0] = p.lse2[mrow + q];
+      v[1] = p.delta[mrow + q];
+      if (drop) {
+        const gvd_encdrop_key dk = gvd_encdrop_row((uint32_t)bh * (uint32_t)p.Rp + (uint32_t)q, p.seed_lo, p.seed_hi);
+        v[2] = __uint_as_float(dk.add);
+        v[3] = __uint_as_float(dk.flip);
+      }
     }
+    *reinterpret_cast<f32x4*>(&rowv[4 * tid]) = v;
+  } else {
+    const int k = n0 + tid - 128;
+    colv[tid - 128] = k < R ? (p.kbias ? p.kbias[(int64_t)b * p.Rp + k] * 1.4426950408889634f : 0.f) : -1e30f;      // (keys >= R: P = 0)
   }
   __syncthreads();
   frags(a0, w0, 0, 0);
   product(accS, rQ, vq, rK, true, rD, vd, rV);
-  {
-    // the W rows of the second product are the V rows: same offsets as the K rows (vk), other descriptor
-    product(accP, rD, vd, rV, false, rD, vd, rV);
-  }
+  // the W rows of the second product are the V rows: same offsets as the K rows (vk), other descriptor
+  product(accP, rD, vd, rV, false, rD, vd, rV);
 
-  // ---- epilogue: P, keep mask, Pd and dS in registers (accS <- Pd, accP <- dS), then two transposed store passes
-  const bool drop = p.thresh != 0u;
+  // ---- epilogue: P, keep mask, Pd and dS row by row, stored straight from the accumulator layout - a store instruction
+  // writes 2 rows x 128 contiguous bytes (whole cache lines).  Both maps are read again only by later launches, 1.6 GB each
+  // at batch_size = 64: nontemporal.
   float colb[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) colb[j] = colv[cb + j * 32 + r];
+  const unsigned rowb = (unsigned)p.Rp * 4u;
+  // No guards: Rp is a multiple of 32, so a 32 x 32 accumulator block is inside the map or outside it as a whole; the lanes
+  // of an outside block get an offset beyond the descriptor (which ends with this (sample, head)'s map) and the hardware
+  // drops their stores.  (The range check sees the lane offset only - the uniform part stays inside a block's 32 rows.)
+  unsigned voff[2][2];                                // lane part of the store offset, per block
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      voff[i][j] = (m0 + rb + i * 32 < p.Rp && n0 + cb + j * 32 < p.Rp)
+                       ? (unsigned)(m0 + rb + i * 32 + 4 * half) * rowb + (unsigned)(n0 + cb + j * 32 + r) * 4u : 0x80000000u;
+  const int64_t mapo = (int64_t)bh * p.Rp * p.Rp;
+  const int mapb = p.Rp * p.Rp * 4;
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(p.Pd + mapo, 0, mapb, 0x00020000),
+                               rS = __builtin_amdgcn_make_buffer_rsrc(p.dS + mapo, 0, mapb, 0x00020000);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    unsigned so = 0u;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int ql = rb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-      const int q = m0 + ql;
-      const bool qok = q < R;
-      const float lq = rowv[2 * ql], dq = rowv[2 * ql + 1];
-      const gvd_encdrop_key dkey = drop ? gvd_encdrop_row((uint32_t)bh * (uint32_t)p.Rp + (uint32_t)q, p.seed_lo, p.seed_hi) : gvd_encdrop_key{0u, 0u};
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(&rowv[4 * ql]);
+      const float lq = rv[0], dq = rv[1];
+      const float ka = rv[2], kf = rv[3];      // (copies: a bit cast applied to a vector element expression reads element 0)
+      const gvd_encdrop_key dkey = {__float_as_uint(ka), __float_as_uint(kf)};
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int k = n0 + cb + j * 32 + r;
-        float pd = 0.f, ds = 0.f;
-        if (qok && k < R) {
-          const float bias2 = colb[j];
-          const float pr = __builtin_amdgcn_exp2f(fmaf(accS[i][j][e], p.c2, bias2) - lq);
-          const bool keep = !drop || gvd_encdrop_keep(dkey, (uint32_t)k, p.thresh);
-          pd = keep ? pr * p.keep_scale : 0.f;
-          ds = p.scale * pr * ((keep ? accP[i][j][e] * p.keep_scale : 0.f) - dq);
-        }
-        accS[i][j][e] = pd;
-        accP[i][j][e] = ds;
+        // branch-free: rows / keys >= R carry lse = +1e30 / bias = -1e30, so their P is exactly 0 and both maps get zeros there;
+        // thresh == 0 (no dropout) keeps every element.  Same roundings as the select form of rounds 4-5 (no contraction).
+        const float pr = __builtin_amdgcn_exp2f(fmaf(accS[i][j][e], p.c2, colb[j]) - lq);
+        const float ks = gvd_encdrop_keep(dkey, (uint32_t)k, p.thresh) ? p.keep_scale : 0.f;
+        const float pd = pr * ks;
+        const float ds = (p.scale * pr) * __fsub_rn(__fmul_rn(accP[i][j][e], ks), dq);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pd), rP, voff[i][j], so, 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ds), rS, voff[i][j], so, 2);
       }
-    }
-  }
-  __syncthreads();           // every wave finished reading the operand tiles (and rowv / colv, which wave 3's slice covers)
-  float* T = smem + wave * 64 * EPI_LD;                        // this wave's private 64 x 64 slice
-  const int c4 = (lane & 15) * 4, rsub = lane >> 4;
-  const int gn = n0 + cb + c4;
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    float* Cb = (pass == 0 ? p.Pd : p.dS) + (int64_t)bh * p.Rp * p.Rp;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          T[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * EPI_LD + j * 32 + r] = pass == 0 ? accS[i][j][e] : accP[i][j][e];
-    // (DS operations of one wave execute in order: its reads below see its own writes above, and the next pass's writes
-    // come after this pass's reads)
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 4 + rsub;
-      const int gm = m0 + rb + row;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(&T[row * EPI_LD + c4]);
-      if (gm < p.Rp && gn < p.Rp) *reinterpret_cast<f32x4*>(Cb + (int64_t)gm * p.Rp + gn) = v;
+      so += (e & 3) == 3 ? 5u * rowb : rowb;
+      if (e & 1) __builtin_amdgcn_sched_barrier(0);      // (two rows in flight: the scheduler would hoist all 32 row reads + hashes)
     }
   }
 }
@@ -273,7 +276,7 @@ extern "C" int gvd_enc_attn_bwd_maps(const float* qkv, int64_t ld, const float* 
       ldo < (int64_t)n_heads * head_pad || !gvd_aligned16(qkv) || !gvd_aligned16(dO) || !gvd_aligned16(O) ||
       !gvd_aligned16(Pd) || !gvd_aligned16(dS) || !(p_drop >= 0.f) || !(p_drop < 1.f) ||
       (int64_t)Rp * ld * 4 >= (int64_t)1 << 31 || (int64_t)Rp * ldo * 4 >= (int64_t)1 << 31 ||
-      (int64_t)B * n_heads * Rp >= (int64_t)1 << 32 || (int64_t)B * n_heads > 65535)
+      (int64_t)B * n_heads * Rp >= (int64_t)1 << 32 || (int64_t)B * n_heads > 65535 || (int64_t)Rp * Rp * 4 >= (int64_t)1 << 31)
     return GVD_EINVAL;
   hipStream_t st = gvd_s(stream);
   hipLaunchKernelGGL(enc_attn_delta_kernel, dim3((unsigned)(((int64_t)B * Rp + 3) / 4)), dim3(256), 0, st, dO, O, ldo, delta,

@@ -814,6 +814,50 @@ def test_enc_attn_core_training_matches_autograd(B, R, p):
         assert torch.equal(o1, o2)
 
 
+@pytest.mark.parametrize('R,p,bias', [(1000, 0.2, True), (132, 0.0, False), (132, 0.35, True), (40, 0.2, False)])
+def test_enc_attn_bwd_maps_against_fp64_and_inside_its_maps(R, p, bias):
+    """gvd_enc_attn_bwd_maps alone (the epilogue stores straight from the accumulator layout through buffer descriptors that end with
+    each (sample, head)'s map: blocks of a partial edge tile outside the map are dropped by the range check): both maps
+    against the fp64 formulas with the SAME keep mask, exact zeros at rows / keys >= R, nothing written behind the maps
+    (Rp = 160 and 64 are not multiples of the 128-wide tile)."""
+    nh, HP, B = 6, ops.HEAD_PAD, 2
+    Rp = -(-R // 32) * 32
+    g = _g(R + int(100 * p))
+    qkv, _ = _packed_qkv(B, Rp, nh, HP, g, scale_q=2.0)
+    qkv = (qkv * 0.5).cuda()
+    dO = torch.randn(B, Rp, nh * HP, generator=g).cuda()
+    dO[:, R:] = 0
+    Oo = torch.randn(B, Rp, nh * HP, generator=g).cuda()
+    kb = (torch.randn(B, Rp, generator=g) * 0.5).cuda() if bias else None
+    q64 = qkv.double().view(B, Rp, 3, nh, HP)
+    S = torch.einsum('bqhd,bkhd->bhqk', q64[:, :R, 0], q64[:, :R, 1]) / 32
+    if bias:
+        S = S + kb[:, None, None, :R].double()
+    lse = torch.logsumexp(S, -1)                                            # [B, nh, R] natural log
+    lse2 = torch.zeros(B * nh, Rp, device='cuda')
+    lse2.view(B, nh, Rp)[:, :, :R] = (lse * 1.4426950408889634).float()
+    delta = torch.empty(B * nh, Rp, device='cuda')
+    Pd = torch.full((B, nh, Rp, Rp), 7.0, device='cuda')
+    dS = torch.full((B, nh, Rp, Rp), 7.0, device='cuda')
+    guard = torch.full((1 << 18,), 3.0, device='cuda')
+    seed = 991 + R
+    hip.check(hip.lib().gvd_enc_attn_bwd_maps(hip.ptr(qkv), 3 * nh * HP, hip.ptr(dO), hip.ptr(Oo), nh * HP, hip.ptr(lse2), hip.ptr(kb) if bias else None,
+                                              hip.ptr(delta), hip.ptr(Pd), hip.ptr(dS), B, Rp, R, Rp, nh, HP, 1.0 / 32, p, seed, hip.stream_ptr()), 'maps')
+    torch.cuda.synchronize()
+    assert bool((guard == 3.0).all())
+    for m in (Pd, dS):
+        assert not m[:, :, R:].any() and not m[:, :, :, R:].any()
+    keep = ops.enc_dropout_mask(B * nh, Rp, p, seed).view(B, nh, Rp, Rp)[:, :, :R, :R].double() if p > 0 else 1.0
+    P = torch.exp(S - lse.unsqueeze(-1))
+    dY = torch.einsum('bqhd,bkhd->bhqk', dO.double().view(B, Rp, nh, HP)[:, :R], q64[:, :R, 2])
+    dl = (dO.double() * Oo.double()).view(B, Rp, nh, HP)[:, :R].sum(-1).permute(0, 2, 1)          # [B, nh, R]
+    assert float((delta.view(B, nh, Rp)[:, :, :R].double() - dl).abs().max()) < 1e-4 * float(dl.abs().max())
+    want_pd = P * keep / (1 - p)
+    want_ds = P * (dY * keep / (1 - p) - dl.unsqueeze(-1)) / 32
+    assert float((Pd[:, :, :R, :R].double() - want_pd).abs().max()) < 2e-5 * float(want_pd.abs().max())
+    assert float((dS[:, :, :R, :R].double() - want_ds).abs().max()) < 5e-5 * float(want_ds.abs().max())
+
+
 def test_enc_dropout_mask_statistics():
     """The keep mask of the attention dropout (counter-based hash, csrc/enc_dropout.h): keep rate, no structure along rows,
     columns or maps, different seeds independent."""

@@ -186,12 +186,28 @@ class TopDownModel(nn.Module):
         self.core = _Core(opt)
         self._validate_dims(opt)
 
+    # widths the decode / BPTT kernels are compiled for (attention.hip: A = 512; decode_persistent.hip, vocab.hip: E = 512)
+    A_BUILT, E_BUILT = 512, 512
+
     def _validate_dims(self, opt):
         """The HIP kernels are specialised at compile time for the reference configuration (attention.hip: A = 512,
         H = 1024; decode_persistent.hip: E = 512; flash kernels: 6 heads of <= 176 columns).  Fail at construction, not
-        with GVD_EINVAL in the middle of a forward."""
-        want = dict(rnn_size=1024, att_hid_size=512, input_encoding_size=512, att_feat_size=2048, fc_feat_size=3072)
-        bad = ['%s=%r (built for %r)' % (k, getattr(opt, k), v) for k, v in want.items() if getattr(opt, k) != v]
+        with GVD_EINVAL in the middle of a forward.  Of the five size options of opts.py:37-48 the reference itself runs
+        only three at other values (tools/reference_dim_survey.py -> profiles/r06/reference_dim_survey.json):
+        `att_feat_size` != 2048 raises in ITS constructor (the fc7 copy of model.py:177 / the 2048-wide `pool_feats` entering
+        `pool_embed`, model.py:312,362) and `fc_feat_size` != 3072 in its forward (`att_embed` is Linear(2048) + Linear(1024),
+        model.py:107-110,395).  `att_hid_size` and `input_encoding_size` up to the built widths run here EXACTLY through
+        zero-padded operands (_att_axis / _emb_axis below); `rnn_size` is the built 1024 only."""
+        bad = []
+        if opt.rnn_size != 1024:
+            bad.append('rnn_size=%r (built for 1024)' % opt.rnn_size)
+        for k, built in (('att_hid_size', self.A_BUILT), ('input_encoding_size', self.E_BUILT)):
+            if not 1 <= getattr(opt, k) <= built:
+                bad.append('%s=%r (1..%d: narrower widths run zero-padded to the built %d)' % (k, getattr(opt, k), built, built))
+        for k, v in (('att_feat_size', 2048), ('fc_feat_size', 3072)):
+            if getattr(opt, k) != v:
+                bad.append('%s=%r (the reference itself raises for anything but %d: profiles/r06/reference_dim_survey.json)'
+                           % (k, getattr(opt, k), v))
         if opt.seq_length > 64 or opt.seq_length < 1:
             bad.append('seq_length=%r (1..64)' % opt.seq_length)
         if opt.num_prop_per_frm * opt.num_sampled_frm < 1:
@@ -201,6 +217,40 @@ class TopDownModel(nn.Module):
         if bad:
             raise NotImplementedError('TopDownModel: the MI355X kernels of libgvd_hip.so are built for the reference '
                                       'dimensions (opts.py defaults); unsupported: ' + '; '.join(bad))
+
+    # ---- att_hid_size / input_encoding_size below the built widths: zero-padded operands, exact results
+    # A projection column a >= att_hid_size has p[r, a] = 0, q[a] = 0 and alpha_net weight 0: it adds 0 * tanh(0) = 0 to every
+    # score in every score mode; an embedding column e >= input_encoding_size is relu(0) = 0 and meets zero columns of the
+    # att-LSTM's W_ih.  The state_dict keeps the reference's shapes: the padded copies are cached views for inference
+    # (_packed) and part of the autograd graph in training (F.pad: the gradient of the pad is the slice).
+    def _pad_axis(self, key, t, dim, n):
+        if t.shape[dim] == n:
+            return t
+        pad = [0, 0] * (t.dim() - 1 - dim) + [0, n - t.shape[dim]]
+        if torch.is_grad_enabled() and t.requires_grad:
+            return F.pad(t, pad)
+        return self._packed(('pad', key), (t,), lambda: F.pad(t.detach(), pad).contiguous())
+
+    def _att_proj(self, lin, key):
+        """(weight [A_BUILT, H], bias [A_BUILT]) of ctx2pool / ctx2att / h2att."""
+        return (self._pad_axis(key + '.w', lin.weight, 0, self.A_BUILT), self._pad_axis(key + '.b', lin.bias, 0, self.A_BUILT))
+
+    def padded_embedding(self, x):
+        """relu(embed) rows [.., E] -> [.., E_BUILT] (training path: after the dropout)."""
+        return x if x.shape[-1] == self.E_BUILT else F.pad(x, (0, self.E_BUILT - x.shape[-1]))
+
+    def core_params(self):
+        """The token loop's parameters at the built widths, reference names -> tensors (inference: cached padded copies;
+        under autograd: F.pad of the parameters)."""
+        c = self.core
+        a1w, a1b = self._att_proj(c.attention.h2att, 'a1')
+        a2w, a2b = self._att_proj(c.attention2.h2att, 'a2')
+        P = dict(att_w_ih=self._pad_axis('att_w_ih', c.att_lstm.weight_ih, 1, self.rnn_size + self.E_BUILT),
+                 a1_w=a1w, a1_b=a1b, a1_aw=self._pad_axis('a1_aw', c.attention.alpha_net.weight, 1, self.A_BUILT),
+                 a2_w=a2w, a2_b=a2b)
+        if hasattr(c.attention2, 'alpha_net'):            # (none under region_attn_mode='dp', AttModel.py:63-66)
+            P['a2_aw'] = self._pad_axis('a2_aw', c.attention2.alpha_net.weight, 1, self.A_BUILT)
+        return P
 
     def _knowledge_transfer(self, opt):
         """model.py:173-216 (`transfer_mode='cls'`): the Detectron fc7 layer initialises `ctx2pool_grd`, and every
@@ -523,7 +573,8 @@ class TopDownModel(nn.Module):
         pool = ops.gemm_nt(pool_in, self._pool_weight_padded(pool_in.shape[-1]), self.pool_embed[0].bias.detach(), 1,
                            m_dev=m)
         pool = self._obj_interact_fused(pool, ci=ci)
-        p_pool = ops.gemm_nt(pool, self.ctx2pool.weight.detach(), self.ctx2pool.bias.detach(), m_dev=m)
+        w_cp, b_cp = self._att_proj(self.ctx2pool, 'ctx2pool')
+        p_pool = ops.gemm_nt(pool, w_cp.detach(), b_cp.detach(), m_dev=m)
         return ci, pool, p_pool, ci.expand(sim_c).transpose(1, 2)
 
     def _obj_interact(self, x, key_bias=None):
@@ -641,7 +692,7 @@ class TopDownModel(nn.Module):
         if self.has_obj_interact:
             pool = self._obj_interact(pool, enc_key_bias)
         pool = pool.contiguous()
-        p_pool = self._lin(pool, self.ctx2pool)                           # MFMA GEMM (model.py:391)
+        p_pool = ops.linear(pool, *self._att_proj(self.ctx2pool, 'ctx2pool'))      # MFMA GEMM (model.py:391)
         return self._preamble_finish(segs_feat, sample_idx, fc, pm, pool, p_pool, sim_mat, g_pool)
 
     def _preamble_finish(self, segs_feat, sample_idx, fc, pm, pool, p_pool, sim_mat, g_pool):
@@ -705,7 +756,7 @@ class TopDownModel(nn.Module):
             t = torch.arange(Ft, device=c.device).view(1, Ft)
             keep = (t >= sample_idx[:, 0:1]) & (t < sample_idx[:, 1:2])           # model.py:303-305
             conv = c.masked_fill(~keep.unsqueeze(-1), 0).contiguous()
-        p_conv = self._lin(conv, self.ctx2att)                            # MFMA GEMM (model.py:405)
+        p_conv = ops.linear(conv, *self._att_proj(self.ctx2att, 'ctx2att'))        # MFMA GEMM (model.py:405)
         return dict(fc=fc, pool=pool, p_pool=p_pool, conv=conv, p_conv=p_conv, g_pool=g_pool,
                     sim_mat_static=sim_mat, pnt_mask=pm, att_input_mode=self.att_input_mode,
                     region_attn_mode=self.region_attn_mode)
@@ -720,18 +771,19 @@ class TopDownModel(nn.Module):
 
     def _decode_params(self):
         c = self.core
+        cp = self.core_params()
         return dict(
-            embed=self.embed[0].weight,
-            att_w_ih=c.att_lstm.weight_ih, att_w_hh=c.att_lstm.weight_hh,
+            embed=self._pad_axis('embed', self.embed[0].weight, 1, self.E_BUILT),
+            att_w_ih=cp['att_w_ih'], att_w_hh=c.att_lstm.weight_hh,
             att_b_ih=c.att_lstm.bias_ih, att_b_hh=c.att_lstm.bias_hh,
             lang_w_ih=c.lang_lstm.weight_ih, lang_w_hh=c.lang_lstm.weight_hh,
             lang_b_ih=c.lang_lstm.bias_ih, lang_b_hh=c.lang_lstm.bias_hh,
-            att1_h2att_w=c.attention.h2att.weight, att1_h2att_b=c.attention.h2att.bias,
-            att1_alpha_w=c.attention.alpha_net.weight, att1_alpha_b=c.attention.alpha_net.bias,
-            att2_h2att_w=c.attention2.h2att.weight, att2_h2att_b=c.attention2.h2att.bias,
+            att1_h2att_w=cp['a1_w'], att1_h2att_b=cp['a1_b'],
+            att1_alpha_w=cp['a1_aw'], att1_alpha_b=c.attention.alpha_net.bias,
+            att2_h2att_w=cp['a2_w'], att2_h2att_b=cp['a2_b'],
             logit_w=self.logit.weight, logit_b=self.logit.bias,
             **({} if self.region_attn_mode == 'dp' else
-               dict(att2_alpha_w=c.attention2.alpha_net.weight, att2_alpha_b=c.attention2.alpha_net.bias)))
+               dict(att2_alpha_w=cp['a2_aw'], att2_alpha_b=c.attention2.alpha_net.bias)))
 
     # ------------------------------------------------------------------ 'sample' (model.py:492-624)
     def _sample(self, segs_feat, ppls, num, ppls_feat, sample_idx, pnt_mask, opt={}):

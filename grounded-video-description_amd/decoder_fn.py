@@ -14,17 +14,16 @@ K = ops   # kernel backend (the HIP library); tests substitute a torch stand-in 
 
 
 def _params(model):
+    """The loop's parameters at the widths the kernels are built for (att_model.TopDownModel.core_params: `att_hid_size` /
+    `input_encoding_size` below 512 enter zero-padded - exact - and autograd slices the gradients back)."""
     c = model.core
-    H = model.rnn_size
-    P = dict(
-        att_w_ih=c.att_lstm.weight_ih, att_w_hh=c.att_lstm.weight_hh, att_b_ih=c.att_lstm.bias_ih,
-        att_b_hh=c.att_lstm.bias_hh, lang_w_ih=c.lang_lstm.weight_ih, lang_w_hh=c.lang_lstm.weight_hh,
-        lang_b_ih=c.lang_lstm.bias_ih, lang_b_hh=c.lang_lstm.bias_hh,
-        a1_w=c.attention.h2att.weight, a1_b=c.attention.h2att.bias,
-        a1_aw=c.attention.alpha_net.weight, a1_ab=c.attention.alpha_net.bias,
-        a2_w=c.attention2.h2att.weight, a2_b=c.attention2.h2att.bias)
+    P = dict(att_w_hh=c.att_lstm.weight_hh, att_b_ih=c.att_lstm.bias_ih,
+             att_b_hh=c.att_lstm.bias_hh, lang_w_ih=c.lang_lstm.weight_ih, lang_w_hh=c.lang_lstm.weight_hh,
+             lang_b_ih=c.lang_lstm.bias_ih, lang_b_hh=c.lang_lstm.bias_hh,
+             a1_ab=c.attention.alpha_net.bias)
     if hasattr(c.attention2, 'alpha_net'):            # (none under region_attn_mode='dp', AttModel.py:63-66)
-        P.update(a2_aw=c.attention2.alpha_net.weight, a2_ab=c.attention2.alpha_net.bias)
+        P['a2_ab'] = c.attention2.alpha_net.bias
+    P.update(model.core_params())
     return P
 
 

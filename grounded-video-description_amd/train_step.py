@@ -84,7 +84,7 @@ def forward_train(model, segs_feat, input_seq, gt_seq, ppls, gt_boxes, mask_boxe
         cls_pred = 0
 
     Lc = _seq_cnt(seq, L)
-    xt_all = model._drop(F.relu(model.embed[0](seq[:, :Lc])))                           # model.py:428
+    xt_all = model.padded_embedding(model._drop(F.relu(model.embed[0](seq[:, :Lc]))))   # model.py:428
     if not eval_obj_ground:
         roi_labels, frm_masks = ops.step_targets(overlaps, mb, fm, pm, Lc)              # model.py:431-440
         h_all, att2_weights = decoder_loop(model, pre, xt_all, pm, frm_masks)

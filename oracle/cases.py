@@ -116,6 +116,15 @@ CASES = {
                                           opt=dict(t_attn_mode='bilstm')),
     'mle_b4_v1000_ft10_bilstm': dict(mode='MLE', B=4, V=1000, Ft=10, seed=39, profile='trained_like',
                                      opt=dict(t_attn_mode='bilstm')),
+    # att_hid_size / input_encoding_size below the widths the decode kernels are built for (opts.py:37-41: both run in the
+    # reference at any value, profiles/r06/reference_dim_survey.json): the HIP path runs them through zero-padded operands
+    # (att_model.TopDownModel.core_params) - exact, so the same bit-exact / 1e-4 contract as the README dimensions
+    'greedy_b8_v1000_ft10_a256e300': dict(mode='sample', B=8, V=1000, Ft=10, seed=40, profile='trained_like',
+                                          opt=dict(att_hid_size=256, input_encoding_size=300)),
+    'mle_b4_v1000_ft10_a256e300': dict(mode='MLE', B=4, V=1000, Ft=10, seed=41, profile='trained_like',
+                                       opt=dict(att_hid_size=256, input_encoding_size=300)),
+    'beam3_b4_v1000_ft10_a256e300': dict(mode='beam', B=4, V=1000, Ft=10, K=3, seed=42, profile='trained_like',
+                                         opt=dict(att_hid_size=256, input_encoding_size=300)),
     'grd_b4_v1000_ft10_l40': dict(mode='GRD', B=4, V=1000, Ft=10, seed=18, profile='trained_like',
                                   opt=dict(seq_length=40)),
     # BASELINE configs[4]'s region count under GREEDY decode: 20 sampled frames x 100 proposals = 2000 regions (the beam

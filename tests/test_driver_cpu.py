@@ -135,9 +135,22 @@ def test_transfer_mode_none_needs_only_the_fc7_pickles(tmp_path):
 
 
 def test_constructor_rejects_dimensions_the_kernels_are_not_built_for():
-    for kw in (dict(rnn_size=512), dict(att_hid_size=256), dict(input_encoding_size=300), dict(seq_length=100)):
+    for kw in (dict(rnn_size=512), dict(att_hid_size=1024), dict(input_encoding_size=600), dict(seq_length=100),
+               # the reference itself raises for these two (profiles/r06/reference_dim_survey.json)
+               dict(att_feat_size=4096), dict(fc_feat_size=4096)):
         with pytest.raises(NotImplementedError):
             att_model.TopDownModel(gvd_amd.opts.default_opt(vocab_size=50, **kw))
+    # att_hid_size / input_encoding_size BELOW the built widths construct with the reference's parameter shapes (they run through
+    # zero-padded operands: goldens *_a256e300) and hand the kernels operands of the built widths
+    m = att_model.TopDownModel(gvd_amd.opts.default_opt(vocab_size=50, att_hid_size=256, input_encoding_size=300))
+    sd = m.state_dict()
+    assert sd['ctx2pool.weight'].shape == (256, 1024) and sd['core.attention.alpha_net.weight'].shape == (1, 256)
+    assert sd['embed.0.weight'].shape == (50, 300) and sd['core.att_lstm.weight_ih'].shape == (4096, 1024 + 300)
+    with torch.no_grad():
+        P = m._decode_params()
+    assert P['embed'].shape == (50, 512) and P['att_w_ih'].shape == (4096, 1536) and P['att1_h2att_w'].shape == (512, 1024)
+    assert P['att2_alpha_w'].shape == (1, 512) and not P['att2_alpha_w'][:, 256:].any() and not P['embed'][:, 300:].any()
+    assert torch.equal(P['att_w_ih'][:, :1324], sd['core.att_lstm.weight_ih']) and not P['att_w_ih'][:, 1324:].any()
     # option values the REFERENCE itself cannot run (profiles/r05/reference_option_survey.json) are rejected ...
     for kw in (dict(att_input_mode='dual_region'), dict(region_attn_mode='add'), dict(region_attn_mode='cat'),
                dict(transfer_mode='glove'), dict(transfer_mode='both'), dict(t_attn_mode='gru')):

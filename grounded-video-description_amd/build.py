@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libgvd_hip.so')
 STAMP = LIB + '.srchash'
-SOURCES = ['gemm_f32.hip', 'gemm_pipe.hip', 'gemm_small.hip', 'gemm_n192.hip', 'gemv_f32.hip', 'attention.hip', 'vocab.hip', 'decode.hip', 'decode_persistent.hip',
+SOURCES = ['gemm_f32.hip', 'gemm_pipe.hip', 'gemm_small.hip', 'gemm_ks.hip', 'gemm_n192.hip', 'gemv_f32.hip', 'attention.hip', 'vocab.hip', 'decode.hip', 'decode_persistent.hip',
            'targets.hip', 'prof.hip', 'backward.hip', 'gru.hip', 'rowwise.hip', 'flash_attn_pad.hip', 'compact.hip', 'enc_attn_bwd.hip', 'ingest.hip', 'beam.hip', 'train_fused.hip', 'optim.hip', 'stream_mm.hip', 'gemm_dxs.hip', 'train_rows.hip', 'lstm_seq.hip']
 HEADERS = ['gvd_common.h', 'gemm_common.h', 'gemv_f32.h', 'top2.h', 'decode_persistent.h', 'philox.h', 'enc_dropout.h']
 CFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']

@@ -83,6 +83,9 @@ bool gvd_gemm_pipe_takes_ktail();      // built with the direct-to-LDS plain pat
 // gemm_small.hip: pipelined 64 x 64 kernel for the token-loop products (plain / LSTM-cell epilogue)
 bool gvd_gemm_small_ok(const KParams& p, int batch);
 int gvd_gemm_small_launch(KParams& p, bool lstm, hipStream_t st);
+// gemm_ks.hip: K-split 32 x 32 tiles for the LSTM cells of batches of 17 .. 64 rows
+bool gvd_gemm_ks_ok(const KParams& p, int batch);
+int gvd_gemm_ks_lstm_launch(KParams& p, hipStream_t st);
 // gemm_n192.hip: K-strided-W products with 129..192 output columns (backward of the training attention core)
 bool gvd_gemm_n192_ok(const KParams& p);
 int gvd_gemm_n192_launch(KParams& p, int batch, hipStream_t st);

@@ -274,6 +274,9 @@ extern "C" int gvd_gemm_nt_f32(const gvd_gemm_args* a, gvd_stream_t stream) {
     v.C = a->C; v.ldc = a->ldc; v.M = a->M; v.N = a->N; v.act = a->act;
     return gvd_gemv_plain(v, st);
   }
+  // (the K-split kernel of the LSTM cells, gemm_ks.hip, is NOT used for plain products: every kernel on this path adds the k
+  // terms of an output in the same ascending order, so a row's result does not depend on the batch - and hence the kernel - it
+  // travels in: tests/test_gpu_kernels.py::test_lstm_persistent_kernel compares a 5-row head against the full batch bit for bit)
   // 17..32 rows: the pipelined 64 x 64 kernel where it is eligible (half of its MFMA rows idle, but the K loop is software
   // pipelined: LSTM cell 99 -> ~45 us, queries / logits 40 -> ~25 us at B = 32, profiles/r03/b32_w_kernel_stats.md), the
   // general 32 x 128 kernel otherwise
@@ -321,6 +324,7 @@ extern "C" int gvd_lstm_cell_fwd(const gvd_lstm_args* a, gvd_stream_t stream) {
     v.c_out = a->c_out; v.ldco = a->ldc_out; v.gates_out = a->gates_out; v.ldg = a->ldg;
     return gvd_gemv_lstm(v, st);
   }
+  if (gvd_gemm_ks_ok(p, 1) && (a->H % 8) == 0) return gvd_gemm_ks_lstm_launch(p, st);           // 17 .. 128 rows
   if (gvd_gemm_small_ok(p, 1) && (a->H % 16) == 0) return gvd_gemm_small_launch(p, true, st);   // (B = 17..32 too)
   if (a->B <= 32) return launch<32, 128, 1, 4, true>(p, 1, st);
   return launch<64, 64, 2, 2, true>(p, 1, st);

@@ -66,8 +66,10 @@ def test_grounder_batched_masked():
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize('B', [1, 4, 7, 16, 17, 64, 200])
+@pytest.mark.parametrize('B', [1, 4, 7, 16, 17, 33, 64, 100, 128, 129, 200])
 def test_lstm_cell(B):
+    """nn.LSTMCell over in-place input blocks: the skinny kernel (<= 16 rows), the K-split 32 x 32-tile kernel (17 .. 128 rows:
+    one / two / four row tiles, 128 .. 512 workgroups), the 64 x 64-tile kernel above."""
     g = _g(B)
     H, E = 1024, 512
     W = {'c.weight_ih': torch.randn(4 * H, E + H, generator=g) / 32, 'c.weight_hh': torch.randn(4 * H, H, generator=g) / 32,

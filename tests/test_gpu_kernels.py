@@ -87,6 +87,42 @@ def test_lstm_cell(B):
     assert torch.isfinite(gates).all() and float(gates[:, :H].min()) >= 0.0      # i gate is a sigmoid
 
 
+@pytest.mark.parametrize('B', [17, 40, 64, 97, 128])
+def test_lstm_cell_k_split_kernel_with_the_decoder_operands(B):
+    """The K-split cell kernel (csrc/gemm_ks.hip, 17 .. 128 rows) with the operands the token loops hand it: the loop-invariant
+    fc gates as a per-row bias, outputs written into strided views of the BPTT's saved-state arrays, two / three K
+    segments (a wave's quarter of K then starts inside a segment and crosses into the next) - against fp64 and against the
+    64 x 64-tile kernel on the same rows inside a batch of 200 (another summation order: a few ulps)."""
+    g = _g(1000 + B)
+    H = 1024
+    for ks in ((512,), (1024, 1024), (1024, 512), (128, 384)):
+        K = sum(ks)
+        w = torch.randn(4 * H, K + H, generator=g).cuda() / 32
+        w_hh = w[:, K:]
+        xs = [torch.randn(200, k, generator=g).cuda() for k in ks]
+        ws, o = [], 0
+        for k in ks:
+            ws.append(w[:, o:o + k])
+            o += k
+        h, c = torch.randn(200, H, generator=g).cuda() * 0.5, torch.randn(200, H, generator=g).cuda()
+        b_ih, b_hh = torch.randn(4 * H, generator=g).cuda() * 0.1, torch.randn(4 * H, generator=g).cuda() * 0.1
+        rb = torch.randn(200, 4 * H, generator=g).cuda() * 0.3
+        states = torch.zeros(3, 200, 2 * H, device='cuda')                       # outputs land in column blocks of a wider array
+        gates = torch.empty(B, 4 * H, device='cuda')
+        oh, oc = ops.lstm_cell([x[:B] for x in xs], ws, h[:B], w_hh, b_ih, b_hh, c[:B], rowbias=rb[:B], gates_out=gates,
+                               h_out=states[1, :B, :H], c_out=states[1, :B, H:])
+        bh, bc = ops.lstm_cell(xs, ws, h, w_hh, b_ih, b_hh, c, rowbias=rb)        # 200 rows: the 64 x 64-tile kernel
+        G = (torch.cat(xs, 1)[:B].double() @ w[:, :K].double().t() + h[:B].double() @ w_hh.double().t() + b_ih.double() + b_hh.double()
+             + rb[:B].double())
+        i, f, gg, o_ = G.chunk(4, 1)
+        rc = torch.sigmoid(f) * c[:B].double() + torch.sigmoid(i) * torch.tanh(gg)
+        rh = torch.sigmoid(o_) * torch.tanh(rc)
+        assert float((oh.double() - rh).abs().max()) < 1e-5 and float((oc.double() - rc).abs().max()) < 2e-5, ks
+        assert float((oh - bh[:B]).abs().max()) < 1e-5 and float((oc - bc[:B]).abs().max()) < 2e-5
+        assert torch.equal(states[1, :B, :H], oh) and not states[0].any() and not states[2].any() and not states[1, B:].any()
+        assert float((gates[:, :H].double() - torch.sigmoid(i)).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize('B,R,Ft', [(4, 1000, 10), (3, 1000, 480), (40, 1000, 10), (2, 37, 5), (300, 130, 3)])
 def test_attention_step(B, R, Ft):
     """The streaming attention kernel against the oracle; (300, 130, 3) launches more than 192 MB -> the nontemporal

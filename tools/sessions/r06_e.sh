@@ -1,4 +1,5 @@
 #!/bin/bash
+# (ran on an intermediate working tree: the three forms were selected by a GVD_MAPS_FORM switch and checked by tools/maps_form_check.py, both removed once form 1 was adopted - commit ee0f7ab; output: profiles/r06/maps_forms_e.txt)
 # Round-6 session E: the three forms of the backward maps kernel of the training encoder (GVD_MAPS_FORM = 0: round 5's kernel,
 # 1: row keys hashed once into LDS + branch-free epilogue + stores straight from the accumulator layout, 2: the same, one
 # workgroup walking the key tiles of its query tile) - bitwise agreement of the two maps, the attention-core tests, timings

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (ran on an intermediate working tree with a GVD_MAPS_ABL compile-time switch in enc_attn_bwd.hip, removed in commit ee0f7ab; output: profiles/r06/maps_ablate_f.txt)
 # Round-6 session F: ablations of the maps kernel, form 1 (prebuilt under tools/_bin/): abl1 = no stores, abl2 = neither epilogue arithmetic nor stores
 set -u
 R=$PWD; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp

@@ -9,8 +9,12 @@
 //       dY = dO V^T         keep from the dropout hash of (seed, map row, key)            (enc_dropout.h)
 //       Pd = keep ? P / (1-p) : 0                      -> map 1: the K-strided A operand of  dV = Pd^T dO
 //       dS = scale P ((keep ? dY / (1-p) : 0) - delta[q])  -> map 2: operand of  dQ = dS K  and  dK = dS^T Q
-//   (the three N = 176 products run on the pipelined GEMM, gemm_pipe.hip, as before).
+//   (the three N = 176 products run on the one-head-slot GEMM, gemm_n192.hip).
 // Rows / columns >= R of both maps are written as zeros: the consumers contract over the whole padded Rp.
+// Round 6: when the forward handed over its scores (`scores`: the log2-domain c S + bias as its matrix cores produced it, 1.6
+// GB per layer at batch_size = 64), the kernel LOADS them into the first accumulator set instead of multiplying Q K^T again:
+// one product per tile, 2.65 -> 1.72 ms per launch (the kernel is MFMA-bound, HBM has the slack), and the backward's P is
+// the forward's to the last bit.
 //
 // What this replaces (round 3): S and dY as two GEMM launches writing [B, heads, Rp, Rp] maps, a softmax + dropout row
 // kernel forward (read S, write Y and Pd) and one backward (read dY, Pd, Y, write dS) - six trips of a 1.6 GB map through
@@ -37,6 +41,7 @@ struct MapParams {
   const float* lse2;                       // [B * nh, Rp]
   const float* delta;                      // [B * nh, Rp]
   const float* kbias;                      // nullable [B, Rp] (natural-log units)
+  const float* scores;                     // HAVE_S: [B * nh, Rp, Rp] log2-domain scaled + biased scores of the forward (rows < R written)
   float* Pd; float* dS;                    // [B * nh, Rp, Rp]
   int B, Rp, R, Rs, nh, HP;                // Rs: rows between consecutive samples in qkv / dO (>= R; Rp on the padded layout)
   float scale, c2, keep_scale;
@@ -49,6 +54,10 @@ struct MapParams {
 // the accumulator layout - 2.93 -> 2.67 ms per launch at batch_size = 64, bit for bit the maps of the LDS-transposed form of
 // rounds 4-5; the products alone take 2.35 ms.  A workgroup that walks the key tiles of its query tile (next tile's operands
 // in flight during the epilogue) measured 2.80 ms and was dropped.
+// HAVE_S (round 6): the forward handed over its scores (flash_attn_pad.hip, TRAIN, `s_out`): they are LOADED into the first
+// accumulator set - straight in the accumulator layout, whole cache lines per instruction, in flight under the one remaining
+// product dY = dO V^T - instead of multiplying Q K^T again.
+template <bool HAVE_S>
 __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapParams p) {
   __shared__ __attribute__((aligned(16))) float smem[4 * TILE + 640];      // operand buffers, per-row / per-key vectors
   float* As = smem;                       // [2][128][32]
@@ -153,7 +162,8 @@ __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapPara
       buf ^= 1;
     }
   };
-  dma(rQ, vq, rK, 0, 0);
+  if (HAVE_S) dma(rD, vd, rV, 0, 0);
+  else dma(rQ, vq, rK, 0, 0);
   // The epilogue needs lse / delta of the tile's 128 query rows and the bias of its 128 key columns: one coalesced element
   // per thread, fetched under the first tile's load latency and parked in the 4 KB of LDS between the operand buffers and
   // the end of the epilogue slices (64 dependent scalar loads per thread in the epilogue cost 0.24 of the kernel's 3.4 ms:
@@ -177,11 +187,29 @@ __global__ __launch_bounds__(256, 2) void enc_attn_bwd_maps_kernel(const MapPara
     *reinterpret_cast<f32x4*>(&rowv[4 * tid]) = v;
   } else {
     const int k = n0 + tid - 128;
-    colv[tid - 128] = k < R ? (p.kbias ? p.kbias[(int64_t)b * p.Rp + k] * 1.4426950408889634f : 0.f) : -1e30f;      // (keys >= R: P = 0)
+    // (keys >= R: P = 0; HAVE_S: the key bias is part of the loaded scores)
+    colv[tid - 128] = k < R ? ((p.kbias && !HAVE_S) ? p.kbias[(int64_t)b * p.Rp + k] * 1.4426950408889634f : 0.f) : -1e30f;
+  }
+  if (HAVE_S) {
+    // the descriptor ends after the map's R written rows: a row >= R (or a 32 x 32 block outside the map) reads as 0, whatever
+    // the memory holds; the whole offset is in the lane register - that is what the range check looks at
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.scores) + (int64_t)bh * p.Rp * p.Rp, 0, R * p.Rp * 4, 0x00020000);
+    const unsigned rowb_ = (unsigned)p.Rp * 4u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned base_ = (m0 + rb + i * 32 < p.Rp && n0 + cb + j * 32 < p.Rp)
+                                   ? (unsigned)(m0 + rb + i * 32 + 4 * half) * rowb_ + (unsigned)(n0 + cb + j * 32 + r) * 4u : 0x80000000u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          accS[i][j][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, base_ + (unsigned)((e & 3) + 8 * (e >> 2)) * rowb_, 0, 2));
+      }
   }
   __syncthreads();
   frags(a0, w0, 0, 0);
-  product(accS, rQ, vq, rK, true, rD, vd, rV);
+  if (!HAVE_S) product(accS, rQ, vq, rK, true, rD, vd, rV);
   // the W rows of the second product are the V rows: same offsets as the K rows (vk), other descriptor
   product(accP, rD, vd, rV, false, rD, vd, rV);
 
@@ -268,13 +296,13 @@ __global__ void enc_dropout_mask_kernel(uint8_t* out, int64_t n, int Rp, uint32_
 }  // namespace
 
 extern "C" int gvd_enc_attn_bwd_maps(const float* qkv, int64_t ld, const float* dO, const float* O, int64_t ldo,
-                                     const float* lse2, const float* key_bias, float* delta, float* Pd, float* dS, int B,
-                                     int Rp, int R, int sample_rows, int n_heads, int head_pad, float scale, float p_drop,
-                                     uint64_t seed, gvd_stream_t stream) {
+                                     const float* lse2, const float* key_bias, const float* scores, float* delta, float* Pd,
+                                     float* dS, int B, int Rp, int R, int sample_rows, int n_heads, int head_pad, float scale,
+                                     float p_drop, uint64_t seed, gvd_stream_t stream) {
   if (!qkv || !dO || !O || !lse2 || !delta || !Pd || !dS || B <= 0 || R <= 0 || Rp < R || sample_rows < R || (Rp % 32) != 0 || n_heads <= 0 ||
       head_pad < 32 || (head_pad % 16) != 0 || (ld % 4) != 0 || (ldo % 4) != 0 || ld < (int64_t)3 * n_heads * head_pad ||
       ldo < (int64_t)n_heads * head_pad || !gvd_aligned16(qkv) || !gvd_aligned16(dO) || !gvd_aligned16(O) ||
-      !gvd_aligned16(Pd) || !gvd_aligned16(dS) || !(p_drop >= 0.f) || !(p_drop < 1.f) ||
+      !gvd_aligned16(Pd) || !gvd_aligned16(dS) || (scores && !gvd_aligned16(scores)) || !(p_drop >= 0.f) || !(p_drop < 1.f) ||
       (int64_t)Rp * ld * 4 >= (int64_t)1 << 31 || (int64_t)Rp * ldo * 4 >= (int64_t)1 << 31 ||
       (int64_t)B * n_heads * Rp >= (int64_t)1 << 32 || (int64_t)B * n_heads > 65535 || (int64_t)Rp * Rp * 4 >= (int64_t)1 << 31)
     return GVD_EINVAL;
@@ -283,14 +311,16 @@ extern "C" int gvd_enc_attn_bwd_maps(const float* qkv, int64_t ld, const float* 
                      B, Rp, R, sample_rows, n_heads, head_pad);
   GVD_CHECK_LAUNCH();
   MapParams p = {};
-  p.qkv = qkv; p.ld = ld; p.dO = dO; p.ldo = ldo; p.lse2 = lse2; p.delta = delta; p.kbias = key_bias; p.Pd = Pd; p.dS = dS;
+  p.qkv = qkv; p.ld = ld; p.dO = dO; p.ldo = ldo; p.lse2 = lse2; p.delta = delta; p.kbias = key_bias; p.scores = scores; p.Pd = Pd; p.dS = dS;
   p.B = B; p.Rp = Rp; p.R = R; p.Rs = sample_rows; p.nh = n_heads; p.HP = head_pad;
-  p.scale = scale; p.c2 = scale * 1.4426950408889634f; p.keep_scale = 1.0f / (1.0f - p_drop);
+  p.scale = scale; p.c2 = scores ? 1.0f : scale * 1.4426950408889634f;      // (loaded scores are in the log2 domain already)
+  p.keep_scale = 1.0f / (1.0f - p_drop);
   p.thresh = p_drop > 0.f ? gvd_drop_thresh(p_drop) : 0u;
   p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
   const int nt = (Rp + BM - 1) / BM;
   p.ntk = nt;
-  hipLaunchKernelGGL(enc_attn_bwd_maps_kernel, dim3((unsigned)(nt * nt), (unsigned)(B * n_heads)), dim3(256), 0, st, p);
+  if (scores) hipLaunchKernelGGL(enc_attn_bwd_maps_kernel<true>, dim3((unsigned)(nt * nt), (unsigned)(B * n_heads)), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(enc_attn_bwd_maps_kernel<false>, dim3((unsigned)(nt * nt), (unsigned)(B * n_heads)), dim3(256), 0, st, p);
   GVD_CHECK_LAUNCH();
   return 0;
 }

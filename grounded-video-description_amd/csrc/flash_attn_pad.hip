@@ -110,6 +110,7 @@ struct PParams {
   // TRAIN only
   const float* kbias;    // nullable [B, mstride]: added to the SCALED scores of a key (natural-log units; -inf = no such key)
   float* lse;            // [B * n_heads, mstride]: log2-domain logsumexp of every query's (scaled, biased) scores
+  float* s_out;          // nullable [B * n_heads, mstride, mstride]: the scaled + biased log2-domain scores themselves (rows < R)
   uint32_t thresh, seed_lo, seed_hi;   // dropout: element dropped iff its draw < thresh (0 = no dropout)
   float keep_scale;      // 1 / (1 - p)
 };
@@ -300,6 +301,13 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pad_kernel(const PParams p)
 #pragma unroll
       for (int u = 0; u < NU; ++u) sacc[u] += *reinterpret_cast<const f32x4*>(kb_s + key0 + 16 * u + 4 * g);
     }
+    if (TRAIN && p.s_out && qrow < R) {
+      // the scores as the backward maps kernel will read them (csrc/enc_attn_bwd.hip loads them instead of multiplying Q K^T
+      // again): 16 bytes per lane and sub-tile, 64 contiguous bytes per query row and instruction; read once, by a later launch
+      float* sp = p.s_out + ((int64_t)(b * p.n_heads + h) * p.mstride + qrow) * p.mstride + key0 + 4 * g;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) __builtin_nontemporal_store(sacc[u], reinterpret_cast<f32x4*>(sp + 16 * u));
+    }
     // masks only where they can apply (wave-uniform): the sample's last key tile (keys past R, the weighted key)
     if (key0 + TK > R || (wkey >= key0 && wkey < key0 + TK)) {
 #pragma unroll
@@ -420,20 +428,20 @@ extern "C" int gvd_flash_attn_padded_f32(const float* q, const float* k, const f
   return 0;
 }
 
-extern "C" int gvd_flash_attn_train_fwd_f32(const float* qkv, int64_t ld, float* o, int64_t ldo, float* lse, int B, int Rp,
-                                            int R, int sample_rows, int n_heads, int head_pad, float scale,
+extern "C" int gvd_flash_attn_train_fwd_f32(const float* qkv, int64_t ld, float* o, int64_t ldo, float* lse, float* scores_out,
+                                            int B, int Rp, int R, int sample_rows, int n_heads, int head_pad, float scale,
                                             const float* key_bias, float p_drop, uint64_t seed, gvd_stream_t stream) {
   if (!qkv || !o || !lse || B <= 0 || R <= 0 || Rp < R || sample_rows < R || Rp > MAX_TRAIN_KEYS || (Rp % 32) != 0 || n_heads <= 0 ||
       head_pad != DP || (ld % 4) != 0 || (ldo % 4) != 0 || !gvd_aligned16(qkv) || !gvd_aligned16(o) ||
       ld < (int64_t)3 * n_heads * DP || ldo < (int64_t)n_heads * DP || (int64_t)R * ld * 4 >= (int64_t)1 << 31 ||
       !(p_drop >= 0.f) || !(p_drop < 1.f) || (key_bias && !gvd_aligned16(key_bias)) ||
-      (int64_t)B * n_heads * Rp >= (int64_t)1 << 32)
+      (scores_out && !gvd_aligned16(scores_out)) || (int64_t)B * n_heads * Rp >= (int64_t)1 << 32)
     return GVD_EINVAL;
   PParams p = {};
   p.q = qkv; p.k = qkv + (int64_t)n_heads * DP; p.v = qkv + (int64_t)2 * n_heads * DP; p.o = o;
   p.ld = ld; p.ldo = ldo; p.B = B; p.R = R; p.n_heads = n_heads; p.rstride = sample_rows; p.mstride = Rp;
   p.qscale = 1.4426950408889634f * scale;
-  p.kbias = key_bias; p.lse = lse;
+  p.kbias = key_bias; p.lse = lse; p.s_out = scores_out;
   p.thresh = p_drop > 0.f ? gvd_drop_thresh(p_drop) : 0u;
   p.keep_scale = 1.0f / (1.0f - p_drop);
   p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);

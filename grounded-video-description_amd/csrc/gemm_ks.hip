@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ks_lstm_kernel(const KParams p) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int r = lane & 31, half = lane >> 5;
-  // consecutive ids walk the (<= 2) row tiles of one weight panel: they share it in one XCD's L2
+  // consecutive ids walk the (<= 4) row tiles of one weight panel: they share it in one XCD's L2
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
   const int tm_ = lid % p.ntm, tn_ = lid / p.ntm;
   const int m0 = tm_ * KT;

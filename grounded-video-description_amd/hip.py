@@ -135,11 +135,11 @@ _SIG = {
                                                   C.c_float, C.c_uint64, C.c_void_p]),
     'gvd_add_layernorm_unbiased_drop_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64,
                                                       C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
-    'gvd_flash_attn_train_fwd_f32': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int, C.c_int, C.c_int,
+    'gvd_flash_attn_train_fwd_f32': (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                                C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, C.c_float, C.c_uint64,
                                                C.c_void_p]),
     'gvd_enc_attn_bwd_maps': (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                        c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_uint64, C.c_void_p]),
     'gvd_enc_dropout_mask': (C.c_int, [c_u8p, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_void_p]),
     'gvd_region_feature_rows': (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int64, c_u8p, C.c_int64, C.c_int64,
@@ -233,7 +233,7 @@ _SIG = {
 }
 
 EXPORTS = tuple(_SIG)
-ABI_VERSION = 19        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
+ABI_VERSION = 20        # must equal gvd_abi_version() of the loaded library (struct layouts above are part of the ABI)
 _lib = None
 
 

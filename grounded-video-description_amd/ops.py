@@ -1381,15 +1381,23 @@ def enc_dropout_mask(n_maps, Rp, p_drop, seed, device='cuda'):
     return out
 
 
-def _enc_core_fwd(qkv, O, lse, B, Rp, R, Rs, nh, scale, p_drop, seed, key_bias):
+def enc_core_scores(B, nh, Rp, device):
+    """The [B * nh, Rp, Rp] map the training forward hands to the backward (its log2-domain scaled + biased scores: the backward
+    maps kernel loads them instead of multiplying Q K^T again - one MFMA product instead of two; 4 Rp^2 bytes per (sample,
+    head): 1.6 GB per layer at batch_size = 64, kept from the layer's forward to its backward)."""
+    return torch.empty(B * nh, Rp, Rp, device=device, dtype=torch.float32)
+
+
+def _enc_core_fwd(qkv, O, lse, B, Rp, R, Rs, nh, scale, p_drop, seed, key_bias, scores=None):
     """Flash-style forward of the training attention core (csrc/flash_attn_pad.hip, TRAIN form).  qkv [>= B*Rs, 3*nh*HP] /
-    O [>= B*Rs, nh*HP] row arrays with Rs rows between consecutive samples; lse [B*nh, Rp]."""
+    O [>= B*Rs, nh*HP] row arrays with Rs rows between consecutive samples; lse [B*nh, Rp]; scores: enc_core_scores(...) when
+    a backward will follow."""
     W3 = qkv.shape[-1]
-    check(lib().gvd_flash_attn_train_fwd_f32(ptr(qkv), W3, ptr(O), O.shape[-1], ptr(lse), B, Rp, R, Rs, nh, HEAD_PAD, scale,
-                                             ptr(key_bias), p_drop, seed, stream_ptr()), 'gvd_flash_attn_train_fwd_f32')
+    check(lib().gvd_flash_attn_train_fwd_f32(ptr(qkv), W3, ptr(O), O.shape[-1], ptr(lse), ptr(scores), B, Rp, R, Rs, nh, HEAD_PAD,
+                                             scale, ptr(key_bias), p_drop, seed, stream_ptr()), 'gvd_flash_attn_train_fwd_f32')
 
 
-def _enc_core_bwd(qkv, O, lse, key_bias, dO, dqkv, B, Rp, R, Rs, nh, scale, p_drop, seed):
+def _enc_core_bwd(qkv, O, lse, key_bias, dO, dqkv, B, Rp, R, Rs, nh, scale, p_drop, seed, scores=None):
     """Backward of the core: the maps kernel (csrc/enc_attn_bwd.hip) + the three one-head-slot products (csrc/gemm_n192.hip)
     into dqkv (rows < R of every sample; the caller zeroes pad rows where the layout has them).  The K-strided operands
     (dO, qkv) are read Rp rows deep per sample: with Rs < Rp the rows past a sample's last belong to the next sample (or to
@@ -1400,7 +1408,7 @@ def _enc_core_bwd(qkv, O, lse, key_bias, dO, dqkv, B, Rp, R, Rs, nh, scale, p_dr
     delta = torch.empty(B * nh, Rp, device=dev, dtype=torch.float32)
     Pd = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
     dS = torch.empty(B, nh, Rp, Rp, device=dev, dtype=torch.float32)
-    check(lib().gvd_enc_attn_bwd_maps(ptr(qkv), W3, ptr(dO), ptr(O), nh * HP, ptr(lse), ptr(key_bias), ptr(delta),
+    check(lib().gvd_enc_attn_bwd_maps(ptr(qkv), W3, ptr(dO), ptr(O), nh * HP, ptr(lse), ptr(key_bias), ptr(scores), ptr(delta),
                                       ptr(Pd), ptr(dS), B, Rp, R, Rs, nh, HP, scale, p_drop, seed, stream_ptr()),
           'gvd_enc_attn_bwd_maps')
     mb, ms = nh * Rp * Rp, Rp * Rp
@@ -1443,14 +1451,15 @@ class _EncAttnCoreFn(torch.autograd.Function):
         if Rp > R:
             O[:, R:].zero_()
         lse = torch.empty(B * nh, Rp, device=dev, dtype=torch.float32)
-        _enc_core_fwd(qkv, O, lse, B, Rp, R, Rp, nh, scale, p_drop, seed, key_bias)
-        ctx.save_for_backward(qkv, O, lse, key_bias)
+        scores = enc_core_scores(B, nh, Rp, dev) if qkv.requires_grad else None
+        _enc_core_fwd(qkv, O, lse, B, Rp, R, Rp, nh, scale, p_drop, seed, key_bias, scores)
+        ctx.save_for_backward(qkv, O, lse, key_bias, scores)
         ctx.cfg = (R, nh, scale, p_drop, seed)
         return O
 
     @staticmethod
     def backward(ctx, dO):
-        qkv, O, lse, key_bias = ctx.saved_tensors
+        qkv, O, lse, key_bias, scores = ctx.saved_tensors
         R, nh, scale, p_drop, seed = ctx.cfg
         B, Rp, W3 = qkv.shape
         dO = dO.contiguous()
@@ -1458,7 +1467,7 @@ class _EncAttnCoreFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         if Rp > R:
             dqkv[:, R:].zero_()
-        _enc_core_bwd(qkv, O, lse, key_bias, dO, dqkv, B, Rp, R, Rp, nh, scale, p_drop, seed)
+        _enc_core_bwd(qkv, O, lse, key_bias, dO, dqkv, B, Rp, R, Rp, nh, scale, p_drop, seed, scores)
         return dqkv, None, None, None, None, None, None
 
 
@@ -1533,19 +1542,20 @@ class _EncLayerFn(torch.autograd.Function):
         if Rs > R:
             O.view(B, Rs, -1)[:, R:].zero_()
         lse = torch.empty(B * nh, Rp, device=dev, dtype=torch.float32)
-        _enc_core_fwd(qkv_buf, O, lse, B, Rp, R, Rs, nh, scale, p_att, seeds[0], key_bias)
+        scores = enc_core_scores(B, nh, Rp, dev)              # (this function only runs under autograd: a backward follows)
+        _enc_core_fwd(qkv_buf, O, lse, B, Rp, R, Rs, nh, scale, p_att, seeds[0], key_bias, scores)
         att = gemm_nt(O, w_o)
         x1 = _add_ln_fwd(x, att, g1, be1, eps1, p_res1, seeds[1])
         h = gemm_nt(x1, w1, b1, 1)
         y = gemm_nt(h, w2, b2)
         x2 = _add_ln_fwd(x1, y, g2, be2, eps2, p_res2, seeds[2])
-        ctx.save_for_backward(x, qkv_buf, O, lse, att, x1, h, y, w_qkv, w_o, g1, w1, w2, g2)
+        ctx.save_for_backward(x, qkv_buf, O, lse, att, x1, h, y, w_qkv, w_o, g1, w1, w2, g2, scores)
         ctx.cfg = cfg
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
-        x, qkv_buf, O, lse, att, x1, h, y, w_qkv, w_o, g1, w1, w2, g2 = ctx.saved_tensors
+        x, qkv_buf, O, lse, att, x1, h, y, w_qkv, w_o, g1, w1, w2, g2, scores = ctx.saved_tensors
         B, R, Rs, Rp, nh, scale, key_bias, idx, idx3, eps1, eps2, p_att, p_res1, p_res2, seeds = ctx.cfg
         HP = HEAD_PAD
         dev = x.device
@@ -1571,7 +1581,7 @@ class _EncLayerFn(torch.autograd.Function):
         dqkv = torch.empty(rows, 3 * nh * HP, device=dev, dtype=torch.float32)
         if Rs > R:
             dqkv.view(B, Rs, -1)[:, R:].zero_()
-        _enc_core_bwd(qkv_buf, O, lse, key_bias, dO_buf, dqkv, B, Rp, R, Rs, nh, scale, p_att, seeds[0])
+        _enc_core_bwd(qkv_buf, O, lse, key_bias, dO_buf, dqkv, B, Rp, R, Rs, nh, scale, p_att, seeds[0], scores)
         dw_qkv = dw_any(dqkv, x, 'encoder dW (q|k|v)')                       # [3 * nh * HP, d]
         dx = dx_any(dqkv, w_qkv, addend=ds1, what='encoder dX (q|k|v)') if need[0] else None
         dq, dk, dv = dw_qkv.index_select(0, idx3).chunk(3, 0)

@@ -35,7 +35,7 @@ typedef struct ihipStream_t* gvd_stream_t; /* == hipStream_t */
 /* library / build identification (also lets tests prove the HIP library, not a fallback, is loaded).
  * GVD_ABI_VERSION changes whenever a struct layout or signature below changes; the Python binding refuses a
  * library whose gvd_abi_version() differs from the version it was written against (hip.ABI_VERSION). */
-#define GVD_ABI_VERSION 19
+#define GVD_ABI_VERSION 20
 const char* gvd_version(void);
 int gvd_abi_version(void);
 
@@ -236,13 +236,18 @@ int gvd_add_layernorm_unbiased_drop_bwd(const float* x, const float* y, const fl
  *   region rows of the batch packed back to back ([B * R, ld], what the Linear layers around the core read and write, no pad
  *   rows anywhere): only the per-(sample, head) statistics and the two maps keep the padded pitch Rp.  Rows past R of a
  *   sample are never written; the K-strided products that contract over Rp rows read up to Rp - R rows past a sample's last
- *   one (the next sample's, or - last sample - slack the caller provides: finite values, they meet exact zeros of the maps). */
-int gvd_flash_attn_train_fwd_f32(const float* qkv, int64_t ld, float* o, int64_t ldo, float* lse, int B, int Rp, int R,
-                                 int sample_rows, int n_heads, int head_pad, float scale, const float* key_bias,
-                                 float p_drop, uint64_t seed, gvd_stream_t stream);
+ *   one (the next sample's, or - last sample - slack the caller provides: finite values, they meet exact zeros of the maps).
+ * scores (ABI 20, nullable on both sides): f32 [B * n_heads, Rp, Rp], the log2-domain scaled + biased score of every (query,
+ *   key) pair as the forward's matrix cores produced it (rows >= R of a map are not written).  Given to the forward AND to
+ *   the backward maps, the latter LOADS S instead of multiplying Q K^T again (one product instead of two, and the backward's
+ *   probabilities are those of the forward to the last bit); NULL on either side: the backward recomputes the product. */
+int gvd_flash_attn_train_fwd_f32(const float* qkv, int64_t ld, float* o, int64_t ldo, float* lse, float* scores_out, int B,
+                                 int Rp, int R, int sample_rows, int n_heads, int head_pad, float scale,
+                                 const float* key_bias, float p_drop, uint64_t seed, gvd_stream_t stream);
 int gvd_enc_attn_bwd_maps(const float* qkv, int64_t ld, const float* dO, const float* O, int64_t ldo, const float* lse2,
-                          const float* key_bias, float* delta, float* Pd, float* dS, int B, int Rp, int R, int sample_rows,
-                          int n_heads, int head_pad, float scale, float p_drop, uint64_t seed, gvd_stream_t stream);
+                          const float* key_bias, const float* scores, float* delta, float* Pd, float* dS, int B, int Rp,
+                          int R, int sample_rows, int n_heads, int head_pad, float scale, float p_drop, uint64_t seed,
+                          gvd_stream_t stream);
 /* Test aid: the keep mask of that dropout, u8 [n_maps, Rp, Rp] (1 = kept), map row = map * Rp + query. */
 int gvd_enc_dropout_mask(uint8_t* out, int64_t n_maps, int Rp, float p_drop, uint64_t seed, gvd_stream_t stream);
 

@@ -879,12 +879,24 @@ def test_enc_attn_bwd_maps_against_fp64_and_inside_its_maps(R, p, bias):
     dS = torch.full((B, nh, Rp, Rp), 7.0, device='cuda')
     guard = torch.full((1 << 18,), 3.0, device='cuda')
     seed = 991 + R
-    hip.check(hip.lib().gvd_enc_attn_bwd_maps(hip.ptr(qkv), 3 * nh * HP, hip.ptr(dO), hip.ptr(Oo), nh * HP, hip.ptr(lse2), hip.ptr(kb) if bias else None,
-                                              hip.ptr(delta), hip.ptr(Pd), hip.ptr(dS), B, Rp, R, Rp, nh, HP, 1.0 / 32, p, seed, hip.stream_ptr()), 'maps')
-    torch.cuda.synchronize()
-    assert bool((guard == 3.0).all())
-    for m in (Pd, dS):
-        assert not m[:, :, R:].any() and not m[:, :, :, R:].any()
+    # both forms: Q K^T multiplied again (scores = NULL), and the forward's log2-domain scores LOADED - rows >= R of that map are
+    # never written by the forward: NaNs there must not reach the maps (the kernel's descriptor ends after row R - 1)
+    sc = torch.full((B * nh, Rp, Rp), float('nan'), device='cuda')
+    sc.view(B, nh, Rp, Rp)[:, :, :R, :R] = (S * 1.4426950408889634).float()
+    sc.view(B, nh, Rp, Rp)[:, :, :R, R:] = 0.25                          # keys >= R: finite (the forward writes bias-only scores there)
+    outs = []
+    for scores in (None, sc):
+        Pd.fill_(7.0), dS.fill_(7.0)
+        hip.check(hip.lib().gvd_enc_attn_bwd_maps(hip.ptr(qkv), 3 * nh * HP, hip.ptr(dO), hip.ptr(Oo), nh * HP, hip.ptr(lse2), hip.ptr(kb) if bias else None,
+                                                  hip.ptr(scores) if scores is not None else None,
+                                                  hip.ptr(delta), hip.ptr(Pd), hip.ptr(dS), B, Rp, R, Rp, nh, HP, 1.0 / 32, p, seed, hip.stream_ptr()), 'maps')
+        torch.cuda.synchronize()
+        assert bool((guard == 3.0).all())
+        for m in (Pd, dS):
+            assert not m[:, :, R:].any() and not m[:, :, :, R:].any() and bool(torch.isfinite(m).all())
+        outs.append((Pd.clone(), dS.clone()))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-6 * float(outs[0][0].abs().max())
+    assert float((outs[0][1] - outs[1][1]).abs().max()) < 2e-6 * float(outs[0][1].abs().max())
     keep = ops.enc_dropout_mask(B * nh, Rp, p, seed).view(B, nh, Rp, Rp)[:, :, :R, :R].double() if p > 0 else 1.0
     P = torch.exp(S - lse.unsqueeze(-1))
     dY = torch.einsum('bqhd,bkhd->bhqk', dO.double().view(B, Rp, nh, HP)[:, :R], q64[:, :R, 2])

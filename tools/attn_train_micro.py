@@ -84,17 +84,19 @@ if Bt > 0:
     Pd = torch.empty(Bt, nh, Rp, Rp, device=dev)
     dS = torch.empty(Bt, nh, Rp, Rp, device=dev)
     dqkv = torch.zeros_like(qkv)
+    Sc = torch.empty(Bt * nh, Rp, Rp, device=dev)      # the forward's scores, handed to the backward maps kernel
     prod = Bt * nh * 2.0 * R * R * HP          # one product's flops
     for p in (0.0, 0.2):
-        fwd = lambda: check(lib().gvd_flash_attn_train_fwd_f32(ptr(qkv), W3, ptr(O), nh * HP, ptr(lse), Bt, Rp, R, Rp, nh, HP, 1.0 / 32,
+        fwd = lambda: check(lib().gvd_flash_attn_train_fwd_f32(ptr(qkv), W3, ptr(O), nh * HP, ptr(lse), ptr(Sc), Bt, Rp, R, Rp, nh, HP, 1.0 / 32,
                                                                None, p, 12345, stream_ptr()), 'fwd')
         ms = timed(fwd)
         print('train fwd  (flash, p=%.1f) B=%d: %.3f ms  %.1f TF/s (2 products)' % (p, Bt, ms, 2 * prod / ms / 1e9), flush=True)
-        maps = lambda: check(lib().gvd_enc_attn_bwd_maps(ptr(qkv), W3, ptr(dO), ptr(O), nh * HP, ptr(lse), None, ptr(delta), ptr(Pd),
-                                                         ptr(dS), Bt, Rp, R, Rp, nh, HP, 1.0 / 32, p, 12345, stream_ptr()), 'maps')
-        ms = timed(maps)
-        print('train bwd maps (S, dY + epilogue, p=%.1f): %.3f ms  %.1f TF/s (2 products), writes %.2f GB'
-              % (p, ms, 2 * prod / ms / 1e9, 2 * Pd.numel() * 4 / 1e9), flush=True)
+        for use_s in (False, True):
+            maps = lambda: check(lib().gvd_enc_attn_bwd_maps(ptr(qkv), W3, ptr(dO), ptr(O), nh * HP, ptr(lse), None, ptr(Sc) if use_s else None,
+                                                             ptr(delta), ptr(Pd), ptr(dS), Bt, Rp, R, Rp, nh, HP, 1.0 / 32, p, 12345, stream_ptr()), 'maps')
+            ms = timed(maps)
+            print('train bwd maps (%s + epilogue, p=%.1f): %.3f ms, writes %.2f GB'
+                  % ('scores loaded, dY' if use_s else 'S, dY', p, ms, 2 * Pd.numel() * 4 / 1e9), flush=True)
     ko, vo = nh * HP, 2 * nh * HP
     mb, msz = nh * Rp * Rp, Rp * Rp
     f_dv = lambda: ops._heads_bgemm(nh, Pd, 0, Rp, mb, msz, dO, 0, nh * HP, Rp * nh * HP, HP, Rp, dqkv, vo, W3, Rp * W3, HP, R, HP, Bt, a_t=1, w_t=1)

@@ -1381,10 +1381,16 @@ def enc_dropout_mask(n_maps, Rp, p_drop, seed, device='cuda'):
     return out
 
 
+ENC_SCORES_MAX_BYTES = 16 << 30     # per layer; above it the backward multiplies Q K^T again instead of keeping the map
+
+
 def enc_core_scores(B, nh, Rp, device):
     """The [B * nh, Rp, Rp] map the training forward hands to the backward (its log2-domain scaled + biased scores: the backward
     maps kernel loads them instead of multiplying Q K^T again - one MFMA product instead of two; 4 Rp^2 bytes per (sample,
-    head): 1.6 GB per layer at batch_size = 64, kept from the layer's forward to its backward)."""
+    head): 1.6 GB per layer at batch_size = 64 x 1000 regions, kept from the layer's forward to its backward).  None when the
+    map would exceed ENC_SCORES_MAX_BYTES (64 segments x 3000 regions): the backward then recomputes the product as before."""
+    if 4 * B * nh * Rp * Rp > ENC_SCORES_MAX_BYTES:
+        return None
     return torch.empty(B * nh, Rp, Rp, device=device, dtype=torch.float32)
 
 

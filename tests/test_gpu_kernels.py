@@ -852,6 +852,28 @@ def test_enc_attn_core_training_matches_autograd(B, R, p):
         assert torch.equal(o1, o2)
 
 
+def test_enc_attn_core_with_and_without_the_score_map(monkeypatch):
+    """The forward hands its scores to the backward maps kernel (ops.enc_core_scores) unless the map would exceed
+    ops.ENC_SCORES_MAX_BYTES; then the backward multiplies Q K^T again.  Same output bits, gradients within the rounding of the
+    two MFMA instructions that produce the scores (16x16x4 in the forward, 32x32x2 in the backward)."""
+    g = _g(4242)
+    nh, HP, B, R = 6, ops.HEAD_PAD, 2, 200
+    Rp = -(-R // 32) * 32
+    qkv, _ = _packed_qkv(B, Rp, nh, HP, g, scale_q=2.0)
+    dO = torch.randn(B, Rp, nh * HP, generator=g).cuda()
+    dO[:, R:] = 0
+    res = []
+    for cap in (ops.ENC_SCORES_MAX_BYTES, 0):
+        monkeypatch.setattr(ops, 'ENC_SCORES_MAX_BYTES', cap)
+        assert (ops.enc_core_scores(B, nh, Rp, 'cuda') is None) == (cap == 0)
+        x = qkv.clone().cuda().requires_grad_(True)
+        out = ops.enc_attn_core(x, R, nh, 1.0 / 32, 0.2, seed=77)
+        out.backward(dO)
+        res.append((out.detach().clone(), x.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert float((res[0][1] - res[1][1]).abs().max()) < 2e-6 * float(res[0][1].abs().max())
+
+
 @pytest.mark.parametrize('R,p,bias', [(1000, 0.2, True), (132, 0.0, False), (132, 0.35, True), (40, 0.2, False)])
 def test_enc_attn_bwd_maps_against_fp64_and_inside_its_maps(R, p, bias):
     """gvd_enc_attn_bwd_maps alone (the epilogue stores straight from the accumulator layout through buffer descriptors that end with

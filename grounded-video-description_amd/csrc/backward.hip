@@ -102,6 +102,13 @@ __global__ __launch_bounds__(256) void attn_bwd_step_kernel(const BwdStepParams 
   f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0, dw0 = dq0, dw1 = dq0;
   float dab = 0.f;
   for (int r = wave; r < rows; r += 4) {
+    // A row the attention mask removed has de = 0 exactly (masked_fill blocks both gradient paths): it adds 0 to every partial
+    // sum below - its 6 KB of features are not fetched (wave-uniform; a fifth of the region rows at the loader's masking rate,
+    // like the forward kernel's row skip)
+    if (am && am[r]) {
+      if (lane == 0) deo[r] = 0.f;
+      continue;
+    }
     // d alpha[r] = feats[r,:] . d_ctx
     float da = 0.f;
 #pragma unroll
@@ -112,9 +119,8 @@ __global__ __launch_bounds__(256) void attn_bwd_step_kernel(const BwdStepParams 
     const f32x4 x0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pf + (int64_t)r * ATT_A + 4 * lane));
     const f32x4 x1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pf + (int64_t)r * ATT_A + 256 + 4 * lane));
     da = wave_sum(da);
-    const bool a_masked = am && am[r];
-    float de = a_masked ? 0.f : al[r] * (da - dot);          // softmax backward; masked_fill blocks the gradient
-    if (dl && !a_masked && !(pm && pm[r])) de += dl[r];       // gradient through `att2_weight` (pre-softmax logits)
+    float de = al[r] * (da - dot);                           // softmax backward
+    if (dl && !(pm && pm[r])) de += dl[r];                    // gradient through `att2_weight` (pre-softmax logits)
     if (lane == 0) deo[r] = de;
     dab += de;
 #pragma unroll
